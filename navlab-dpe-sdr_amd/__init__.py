@@ -1,0 +1,9 @@
+"""navlab-dpe-sdr_amd -- MI355X-native DPE correlator engine (sampleblock -> BCS -> BCM hot path).
+
+Python side = thin ctypes host layer over the C-ABI in csrc/ (include/dpe_hip.h), plus
+synthetic-input and file-format utilities.  Imported as `navlab_dpe_sdr_amd` through the
+root-level shim navlab_dpe_sdr_amd.py (the directory name carries a hyphen).
+"""
+from . import handoff, synth  # noqa: F401
+
+__all__ = ["handoff", "synth"]

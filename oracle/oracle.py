@@ -1,0 +1,277 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY (never imported by the product package).
+
+ctypes binding of oracle/libdpe_oracle.so (plain-C fp64 restatement, CUDARecv semantics)
+plus a numpy FFT-based full-length restatement of BatchCorrScores::Update that follows the
+reference step by step (cudarecv/modules/src/batchcorrscores.cu:1043-1180, twin:
+pygnss/pythonreceiver/scalar/correlator.py:367-465).
+
+Pinned against tests/golden/*.npz (generated from the reference's Python twin by
+tests/golden/make_golden.py); see oracle/dpe_oracle.h for the parity-pin statement.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EPH_FIELDS = ["sqrt_A", "e", "i_0", "OMEGA_0", "omega", "M_0", "delta_n", "OMEGADOT", "IDOT",
+              "C_rc", "C_rs", "C_uc", "C_us", "C_ic", "C_is", "t_oe", "t_oc",
+              "a_f0", "a_f1", "a_f2", "T_GD"]
+EPH_N = len(EPH_FIELDS)
+
+# constants: cudarecv/utils/inc/consthelper.h:5-27
+CONST_C = 299792458.0
+CONST_PI = 3.1415926535898
+F_L1 = 1.57542e9
+F_CA = 1.023e6
+L_CA = 1023
+T_CA = 0.001
+OEDOT = 7.2921151467e-5
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libdpe_oracle.so")
+    src = os.path.join(_HERE, "dpe_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.dpo_time_idx.restype = C.c_double
+        _LIB.dpo_time_idx.argtypes = [C.c_int64, C.c_double]
+        _LIB.dpo_argmax_first.restype = C.c_int64
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _d(a):
+    return _p(a, C.c_double)
+
+
+def _i(a):
+    return _p(a, C.c_int)
+
+
+def ca_code(prn):
+    out = np.zeros(1023, dtype=np.int8)
+    lib().dpo_gen_ca_code(C.c_int(int(prn)), _p(out, C.c_int8))
+    return out
+
+
+def nav_bit_boundary(cp_ela, cp_ref, rc, fc, fs):
+    f = lib().dpo_nav_bit_boundary
+    f.restype = C.c_int
+    return f(C.c_int(int(cp_ela)), C.c_int(int(cp_ref)), C.c_double(rc), C.c_double(fc), C.c_double(fs))
+
+
+def carr_fft_len(S):
+    """batchcorrscores.cu:761 carrSTot = 8 * roundUpToNextPowerOfTwo(S) (auxil.cpp:98-109)."""
+    p = 1
+    while p < S:
+        p <<= 1
+    return 8 * p
+
+
+def bcs_sv(iq, fs, prn, rc, ri, fc, fi, cp_ela, cp_ref, lag_lo, lag_hi, bin_lo, bin_hi, C_fft=None):
+    """One SV of BatchCorrScores (direct-sum C oracle).  iq: int16[2*S] interleaved."""
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    S = iq.size // 2
+    if C_fft is None:
+        C_fft = carr_fft_len(S)
+    chips = ca_code(prn)
+    code = np.zeros(2 * (lag_hi - lag_lo + 1))
+    carr = np.zeros(2 * (bin_hi - bin_lo + 1))
+    info = np.zeros(2, dtype=np.int32)
+    mean = np.zeros(2)
+    rcode = lib().dpo_bcs_sv(_p(iq, C.c_int16), C.c_int(S), C.c_double(fs), _p(chips, C.c_int8),
+                             C.c_double(rc), C.c_double(ri), C.c_double(fc), C.c_double(fi),
+                             C.c_int(int(cp_ela)), C.c_int(int(cp_ref)),
+                             C.c_int(lag_lo), C.c_int(lag_hi), C.c_int64(C_fft),
+                             C.c_int(bin_lo), C.c_int(bin_hi), _d(code), _d(carr), _i(info), _d(mean))
+    assert rcode == 0
+    return (code.view(np.complex128), carr.view(np.complex128),
+            dict(idx_next=int(info[0]), no_flip_larger=bool(info[1]), mean=complex(mean[0], mean[1])))
+
+
+def bcs_sv_fft(iq, fs, prn, rc, ri, fc, fi, cp_ela, cp_ref, C_fft=None):
+    """Full-length FFT restatement of one SV of BatchCorrScores::Update (numpy).
+
+    Returns (codeScores[S], carrScores[C], info), both fft-shifted exactly like
+    codeCorrOut_d / carrfftOut_d (batchcorrscores.cu:1153,1180)."""
+    iq = np.asarray(iq, dtype=np.int16)
+    S = iq.size // 2
+    if C_fft is None:
+        C_fft = carr_fft_len(S)
+    raw = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)        # :216
+    t = np.round(np.arange(S) / fs * 1.0e9) / 1.0e9                            # :191-193
+    mean = raw.sum() / np.float64(np.float32(S))                                # :1065
+    wipe = np.conj(np.exp(1j * (2 * CONST_PI * (fi * t + ri))))                 # :294-300
+    chips = ca_code(prn).astype(np.float64)
+    r = chips[np.mod(np.floor(t * fc + rc).astype(np.int64), L_CA)]             # :347-349
+    idx_next = nav_bit_boundary(cp_ela, cp_ref, rc, fc, fs)                     # :247-253
+    has_flip = 0 < idx_next < S
+    rf = np.zeros(S)
+    if has_flip:                                                                # :352-367
+        rf = r.copy()
+        rf[idx_next:] = -rf[idx_next:]
+    b = raw * wipe                                                              # :1113
+    bf = np.fft.fft(b)                                                          # :1120
+    c_no = np.fft.ifft(np.conj(np.fft.fft(r)) * bf)                             # :1099-1144
+    c_fl = np.fft.ifft(np.conj(np.fft.fft(rf)) * bf)
+    no_flip_larger = (not has_flip) or (abs(c_no[0]) > abs(c_fl[0]))            # :512
+    code = np.fft.fftshift(c_no if no_flip_larger else c_fl)                    # :1153
+    rch = r if no_flip_larger else rf
+    base = (b - mean * wipe) * rch                                              # :480,:440-448
+    carr = np.fft.fftshift(np.fft.fft(base, C_fft))                             # :1179-1180
+    return code, carr, dict(idx_next=idx_next, no_flip_larger=bool(no_flip_larger), mean=complex(mean))
+
+
+def bcm_pos(sat, code_win, win_lo, center, grid, R, fc, cp_ref_tow, cp_ela_end, cp_ref, rc_end,
+            rx_time, fs, num_samps, lpower=1):
+    """BCM_PosMeasML.  sat: K x 8 mid-time states; code_win: K x winLen complex."""
+    sat = np.ascontiguousarray(sat, dtype=np.float64)
+    K = sat.shape[0]
+    cw = np.ascontiguousarray(code_win, dtype=np.complex128)
+    grid = np.ascontiguousarray(grid, dtype=np.float64)
+    G = grid.shape[0]
+    scores = np.zeros(G)
+    oob = C.c_int64(0)
+    ii = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    dd = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    a_tow, a_ela, a_ref = ii(cp_ref_tow), ii(cp_ela_end), ii(cp_ref)
+    a_fc, a_rc, a_c, a_R = dd(fc), dd(rc_end), dd(center), dd(R)
+    lib().dpo_bcm_pos(_d(sat), _d(cw.view(np.float64)), C.c_int(int(win_lo)), C.c_int(cw.shape[1]),
+                      _d(a_c), _d(grid), C.c_int64(G), _d(a_R), _d(a_fc), _i(a_tow), _i(a_ela),
+                      _i(a_ref), _d(a_rc), C.c_double(rx_time), C.c_int(K), C.c_double(fs),
+                      C.c_int(int(num_samps)), C.c_int(int(lpower)), _d(scores), C.byref(oob))
+    return scores, oob.value
+
+
+def bcm_vel(sat, carr_win, win_lo, center, grid, R, fi, rx_time, fs, num_fft, doppler_sign=1, lpower=1):
+    sat = np.ascontiguousarray(sat, dtype=np.float64)
+    K = sat.shape[0]
+    cw = np.ascontiguousarray(carr_win, dtype=np.complex128)
+    grid = np.ascontiguousarray(grid, dtype=np.float64)
+    G = grid.shape[0]
+    scores = np.zeros(G)
+    oob = C.c_int64(0)
+    dd = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    a_fi, a_c, a_R = dd(fi), dd(center), dd(R)
+    lib().dpo_bcm_vel(_d(sat), _d(cw.view(np.float64)), C.c_int64(int(win_lo)), C.c_int(cw.shape[1]),
+                      _d(a_c), _d(grid), C.c_int64(G), _d(a_R), _d(a_fi), C.c_double(rx_time),
+                      C.c_int(K), C.c_double(fs), C.c_int64(int(num_fft)), C.c_int(int(doppler_sign)),
+                      C.c_int(int(lpower)), _d(scores), C.byref(oob))
+    return scores, oob.value
+
+
+def argmax_first(v):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    return int(lib().dpo_argmax_first(_d(v), C.c_int64(v.size)))
+
+
+def make_meas(pos_idx, vel_idx, center, pos_grid, vel_grid, R):
+    z = np.zeros(8)
+    Rv = np.zeros(64)
+    dd = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    a_c, a_pg, a_vg, a_R = dd(center), dd(pos_grid), dd(vel_grid), dd(R)
+    lib().dpo_make_meas(C.c_int64(int(pos_idx)), C.c_int64(int(vel_idx)), _d(a_c), _d(a_pg), _d(a_vg),
+                        _d(a_R), _d(z), _d(Rv))
+    return z, Rv.reshape(8, 8)
+
+
+def init_grid(grid_type, dims, spacing):
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    spacing = np.ascontiguousarray(spacing, dtype=np.float64)
+    G = int(np.prod(dims.astype(np.int64)))
+    grid = np.zeros((G, 4))
+    tg = np.zeros(int(dims[3]))
+    lib().dpo_init_grid(C.c_int(int(grid_type)), _i(dims), _d(spacing), _d(grid), _d(tg))
+    return grid, tg
+
+
+def sat_pos(eph, tx_time):
+    eph = np.ascontiguousarray(eph, dtype=np.float64)
+    st = np.zeros(8)
+    f = lib().dpo_sat_pos
+    f.restype = C.c_int
+    rc = f(_d(eph), C.c_double(tx_time), _d(st))
+    return st, rc
+
+
+def ecef2ll(p):
+    p = np.ascontiguousarray(p[:3], dtype=np.float64)
+    ll = np.zeros(2)
+    lib().dpo_ecef2ll(_d(p), _d(ll))
+    return ll
+
+
+def enu2ecef(ll):
+    ll = np.ascontiguousarray(ll, dtype=np.float64)
+    R = np.zeros(9)
+    lib().dpo_enu2ecef(_d(ll), _d(R))
+    return R
+
+
+class _ChanT(C.Structure):
+    _fields_ = [("K", C.c_int)] + \
+               [(n, C.POINTER(C.c_double)) for n in ("rcStart", "rcEnd", "riStart", "riEnd", "fc", "fi", "txTime")] + \
+               [(n, C.POINTER(C.c_int)) for n in ("cpElaStart", "cpElaEnd", "cpRef", "cpRefTOW")] + \
+               [("satStates", C.POINTER(C.c_double)), ("eph", C.POINTER(C.c_double)), ("dopplerSign", C.c_int)]
+
+
+class ChanMgr:
+    """cuChanMgr restatement (cuchanmgr.cu:1004-1268): Start() then Update() per window."""
+
+    def __init__(self, prns, rc, ri, fc, fi, cp, cp_ref, cp_ref_tow, eph, rx_time, T, doppler_sign=1):
+        K = len(prns)
+        self.K, self.prns, self.T = K, list(prns), float(np.round(T * 1e6) / 1e6)
+        d = lambda a: np.array(a, dtype=np.float64).copy()
+        i = lambda a: np.array(a, dtype=np.int32).copy()
+        self.rcStart, self.rcEnd = np.zeros(K), d(rc)
+        self.riStart, self.riEnd = np.zeros(K), d(ri)
+        self.fc, self.fi, self.txTime = d(fc), d(fi), np.zeros(K)
+        self.cpElaStart, self.cpElaEnd = np.zeros(K, dtype=np.int32), i(cp)
+        self.cpRef, self.cpRefTOW = i(cp_ref), i(cp_ref_tow)
+        self.satStates = np.zeros((K, 8))
+        self.eph = np.ascontiguousarray(eph, dtype=np.float64)
+        self.rxTime = float(rx_time)
+        self.dopplerSign = int(doppler_sign)
+        self._s = _ChanT(K, _d(self.rcStart), _d(self.rcEnd), _d(self.riStart), _d(self.riEnd),
+                         _d(self.fc), _d(self.fi), _d(self.txTime), _i(self.cpElaStart),
+                         _i(self.cpElaEnd), _i(self.cpRef), _i(self.cpRefTOW), _d(self.satStates),
+                         _d(self.eph), self.dopplerSign)
+
+    def start(self, x_k1k1, x_kk1, time_grid):
+        """cuchanmgr.cu:1100-1132."""
+        x1 = np.ascontiguousarray(x_k1k1, dtype=np.float64)
+        lib().dpo_chm_compute_sat_states(C.byref(self._s))
+        lib().dpo_chm_time_update(C.byref(self._s), _d(x1), C.c_double(self.rxTime), C.c_double(self.T))
+        self.rxTime += self.T
+        return self.grid_prep(x_kk1, time_grid)
+
+    def update(self, x_k1k1, x_kk1, time_grid):
+        """cuchanmgr.cu:1237-1264."""
+        x1 = np.ascontiguousarray(x_k1k1, dtype=np.float64)
+        lib().dpo_chm_propagate(C.byref(self._s), _d(x1), C.c_double(self.rxTime), C.c_double(self.T))
+        self.rxTime += self.T
+        return self.grid_prep(x_kk1, time_grid)
+
+    def grid_prep(self, x_kk1, time_grid):
+        x = np.ascontiguousarray(x_kk1, dtype=np.float64)
+        tg = np.ascontiguousarray(time_grid, dtype=np.float64)
+        batch = np.zeros((self.K, tg.size, 8))
+        R = np.zeros(9)
+        lib().dpo_chm_grid_prep(C.c_double(self.rxTime), _d(self.txTime), _d(x), _d(self.satStates),
+                                C.c_int(self.K), _d(tg), C.c_int(tg.size), _d(batch), _d(R))
+        self.batchSatStates, self.enu2ecef = batch, R
+        return batch, R

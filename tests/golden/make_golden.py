@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own Python twin.
+
+Run in the dev container only (needs /root/reference, read-only):
+
+    python tests/golden/make_golden.py
+
+What it does: copies /root/reference/pygnss/pythonreceiver to a scratch dir under /tmp,
+converts it with lib2to3 (the reference is Python 2.7), sets numpy.mat = numpy.asmatrix
+(removed in NumPy 2), imports it from there and records input/output vectors of the
+reference callables that the CUDA authors used as their oracle:
+
+  O1 Correlator._make_L1_CAcode_chips            correlator.py:474-515
+  O3 Correlator.vector_correlate_unfolded        correlator.py:367-465
+  O4 satpos.satellite_clock_correction/locate_satellite   satpos.py:8-185
+  O5 utils.ECEF_to_LLA / ECEF_to_ENU rotation    utils.py:13-81,235-275
+  O6 NavigationGuesses.generate_spread_grid      receiver.py:995-1026
+  O7 Receiver.dp_track internals (one iteration) receiver.py:205-397, channel.py:194-245
+
+Only DATA (inputs + expected outputs) is written; no reference source is copied into the
+repo.  The two harness adaptations below are marked HARNESS and do not touch arithmetic.
+"""
+import os
+import shutil
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+SCRATCH = "/tmp/dpe_golden_pygnss"
+
+sys.path.insert(0, ROOT)
+import navlab_dpe_sdr_amd as dpe  # noqa: E402  (product-side synthetic generator + handoff reader)
+
+
+def import_pygnss():
+    if os.path.isdir(SCRATCH):
+        shutil.rmtree(SCRATCH)
+    os.makedirs(SCRATCH)
+    shutil.copytree(os.path.join(REF, "pygnss", "pythonreceiver"), os.path.join(SCRATCH, "pythonreceiver"))
+    subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n", "pythonreceiver"], cwd=SCRATCH,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    np.mat = np.asmatrix  # HARNESS: removed in NumPy 2
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, SCRATCH)
+    from pythonreceiver import receiver
+    from pythonreceiver.libgnss import rawfile, satpos, utils
+    from pythonreceiver.scalar import correlator
+    from pythonreceiver.vector import ekf
+    return types.SimpleNamespace(receiver=receiver, rawfile=rawfile, satpos=satpos, utils=utils,
+                                 correlator=correlator, ekf=ekf)
+
+
+class Eph:
+    """Container with the attribute names pygnss' libgnss.ephemeris.Ephemerides exposes."""
+
+    def __init__(self, ho, k):
+        for j, name in enumerate(dpe.handoff.EPH_FIELDS):
+            setattr(self, name, float(ho["eph"][k, j]))
+        self.timestamp = {"cp": float(ho["cp_timestamp"][k]), "TOW": float(ho["TOW"][k])}
+
+
+def open_rawfile(pg, path, fs, T):
+    dt = np.dtype([("i", np.short), ("q", np.short)])
+    rf = pg.rawfile.RawFile(abspath=path, fs=fs, fi=0.0, ds=1.0, datatype=dt, notes="synthetic", verbose=False)
+    # HARNESS: under py3 dict_keys != list, so the reference's format dispatch falls through
+    rf.format_rawsnippet = rf.format_rawsnippet_datatype_complex
+    rf.set_rawsnippet_settings(T=T, T_big=T, verbose=False)
+    return rf
+
+
+def main():
+    pg = import_pygnss()
+    ho = dpe.handoff.read_handoff(os.path.join(REF, "demofiles", "handoff_params_usrp6.csv"))
+    prns = [int(p) for p in ho["prn_list"]]
+    K = len(prns)
+
+    # ---- O1: C/A chips, PRN 1..37
+    chips = np.stack([pg.correlator.Correlator(p).chips.astype(np.int8) for p in range(1, 38)])
+    np.savez_compressed(os.path.join(HERE, "o1_ca_chips.npz"), chips=chips)
+
+    # ---- O3: vector_correlate_unfolded on seeded synthetic windows
+    def run_o3(tag, fs, T, seed, ch, amp, flip):
+        S = int(round(T * fs))
+        iq = dpe.synth.gen_iq(seed, fs, S, ch, amp=amp, flip=flip)
+        path = os.path.join(SCRATCH, "o3_%s.dat" % tag)
+        iq.tofile(path)
+        rf = open_rawfile(pg, path, fs, T)
+        rf.update_rawsnippet()
+        Cf = int(rf.carr_fftpts)
+        code, carr, cpc, win, idxn = [], [], [], [], []
+        for k in range(len(ch["prn"])):
+            cor = pg.correlator.Correlator(int(ch["prn"][k]))
+            cc, cf, cp_compl = cor.vector_correlate_unfolded(
+                rf, ch["rc"][k], ch["ri"][k], ch["fc"][k], ch["fi"][k], float(ch["cp"][k]), float(ch["cp_ref"][k]))
+            code.append(np.asarray(cc)[S // 2 - 64: S // 2 + 65])
+            carr.append(np.asarray(cf)[Cf // 2 - 256: Cf // 2 + 257])
+            cpc.append(float(cp_compl))
+        np.savez_compressed(os.path.join(HERE, "o3_%s.npz" % tag), iq=iq, fs=fs, T=T, S=S, N=rf.N, C=Cf,
+                            first16=np.asarray(rf.rawsnippet)[:16], prn=ch["prn"], rc=ch["rc"], ri=ch["ri"],
+                            fc=ch["fc"], fi=ch["fi"], cp=ch["cp"], cp_ref=ch["cp_ref"],
+                            code=np.stack(code), carr=np.stack(carr), cp_compl=np.array(cpc), flip=np.asarray(flip))
+        rf.close_rawfile()
+
+    ch_ho = dict(prn=ho["prn_list"], rc=ho["rc"], ri=ho["ri"], fc=ho["fc"], fi=ho["fi"], cp=ho["cp"],
+                 cp_ref=ho["cp_timestamp"])
+    flips = np.array([1, 0, 1, 1, 0, 0, 1, 0], dtype=bool)
+    run_o3("handoff_20ms", 2.5e6, 0.02, 11, ch_ho, 200.0, flips)          # nav-bit edge inside window
+    ch_b = dpe.synth.random_channels(5, 4)
+    ch_b["cp_ref"] = ch_b["cp"] - np.array([0, 1, 2, 7], dtype=np.int32)  # next edge >= 13 ms away
+    run_o3("short_5ms", 2.5e6, 0.005, 12, ch_b, 48.0, np.zeros(4, dtype=bool))  # no edge inside window
+
+    # ---- O4: satellite clock correction + position/velocity at the handoff transmit times
+    tx = ho["TOW"] + (ho["cp"] - ho["cp_timestamp"]) * 1e-3 + ho["rc"] / 1.023e6
+    sat = np.zeros((K, 8))
+    for k in range(K):
+        e = Eph(ho, k)
+        clkb, clkd = pg.satpos.satellite_clock_correction(e, tx[k])
+        sat[k] = np.asarray(pg.satpos.locate_satellite(e, tx[k] - clkb, clkb, clkd)).ravel()
+    np.savez_compressed(os.path.join(HERE, "o4_satpos.npz"), tx=tx, sat=sat, eph=ho["eph"], prn=ho["prn_list"])
+
+    # ---- O5: ECEF->LLA, ENU rotation
+    X = np.asmatrix(ho["X_ECEF"]).T
+    lla = pg.utils.ECEF_to_LLA(X[0:3], in_degrees=False)
+    _, Rm = pg.utils.ECEF_to_ENU(refState=X[0:3], curState=X[0:3])
+    np.savez_compressed(os.path.join(HERE, "o5_frames.npz"), X_ECEF=ho["X_ECEF"], lat=lla["lat"][0],
+                        lon=lla["lon"][0], alt=lla["alt"][0], R_ECEF2ENU=np.asarray(Rm))
+
+    # ---- O6: spread grid
+    ng = pg.receiver.NavigationGuesses()
+    np.savez_compressed(os.path.join(HERE, "o6_spread_grid.npz"), dX=np.asarray(ng.dX), dT=np.asarray(ng.dT),
+                        dXdot=np.asarray(ng.dXdot), dTdot=np.asarray(ng.dTdot))
+
+    # ---- O7: one DP iteration on the handoff state with a geometry-consistent synthetic window
+    fs, T = 2.5e6, 0.02
+    S = int(round(fs * T))
+    iq = dpe.synth.gen_iq(21, fs, S, ch_ho, amp=200.0, flip=flips)
+    path = os.path.join(SCRATCH, "o7.dat")
+    iq.tofile(path)
+    rf = open_rawfile(pg, path, fs, T)
+    rx = pg.receiver.Receiver(rf, mcount_max=8)
+    rx.add_channels(prns)
+    for k, p in enumerate(prns):
+        rx.channels[p].ephemerides = Eph(ho, k)
+    rx.ekf = pg.ekf.ExtendedKalmanFilter(np.asmatrix(ho["X_ECEF"]).T, T=T)
+    rx.navguess = pg.receiver.NavigationGuesses()
+    # what Receiver.load_cudarecv_handoff (receiver.py:129-178) sets, minus the file seek
+    rx.rxTime = ho["rxTime"]
+    rx.ekf.X_ECEF = np.matrix(ho["X_ECEF"]).T
+    rx.rxTime_a = rx.rxTime - (rx.ekf.X_ECEF[3, 0] / 299792458.0)
+    for k, p in enumerate(prns):
+        c = rx.channels[p]
+        c.rc[0], c.ri[0], c.fc[0], c.fi[0], c.cp[0] = ho["rc"][k], ho["ri"][k], ho["fc"][k], ho["fi"][k], float(ho["cp"][k])
+    # Receiver.dp_track body (receiver.py:205-225), one iteration, with taps
+    rf.seek_rawfile(rf.S_skip)
+    rf.update_rawsnippet()
+    rx.dp_time_update_state()
+    rx.dp_time_update_channels_unfolded()
+    rx._mcount += 1
+    mc = rx._mcount
+    Cf = int(rf.carr_fftpts)
+    end = {n: np.array([getattr(rx.channels[p], n)[mc] for p in prns]) for n in ("rc", "ri", "fc", "fi", "cp")}
+    code = np.stack([np.asarray(rx.channels[p].code_corr)[S // 2 - 64: S // 2 + 65] for p in prns])
+    carr = np.stack([np.asarray(rx.channels[p].carr_fft)[Cf // 2 - 256: Cf // 2 + 257] for p in prns])
+    X_ECEF = np.asarray(rx.ekf.X_ECEF).ravel().copy()
+    gfv, gfp = rx.navguess.get_nav_guesses(rx.ekf.X_ECEF, rx.rxTime_a, ECEF_only=True)
+    rx.dp_measurement_estimation_unfolded(gXk_grid=(gfv, gfp))
+    pos_corr, vel_fft = np.asarray(rx.pos_corr).ravel(), np.asarray(rx.vel_fft).ravel()
+    e = np.asarray(rx.dp_measurement_estimation_unfolded()).ravel()
+    top_p = np.argsort(-pos_corr, kind="stable")[:32]
+    top_v = np.argsort(-vel_fft, kind="stable")[:32]
+    sel = [0, 1, 24, 25, 624, 625, 195312, 390624]
+    np.savez_compressed(
+        os.path.join(HERE, "o7_dp_iteration.npz"), iq=iq, fs=fs, T=T, S=S, C=Cf, prn=ho["prn_list"],
+        X_ECEF=X_ECEF, rxTime=rx.rxTime, rxTime_a=rx.rxTime_a, end_rc=end["rc"], end_ri=end["ri"],
+        end_fc=end["fc"], end_fi=end["fi"], end_cp=end["cp"], code=code, carr=carr,
+        argmax_pos=int(np.argmax(pos_corr)), argmax_vel=int(np.argmax(vel_fft)), e=e,
+        pos_every97=pos_corr[::97], vel_every97=vel_fft[::97], top_pos_idx=top_p, top_pos=pos_corr[top_p],
+        top_vel_idx=top_v, top_vel=vel_fft[top_v], gX_sel=np.asarray(gfv)[:, sel], sel=np.array(sel))
+    rf.close_rawfile()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""CPU: the CUDA-semantics oracle chain (ChanMgr.start -> BCS -> BCM -> MakeMeas) against the
+O7 fixture = one Receiver.dp_track iteration of the reference's Python twin on the handoff state.
+
+Measured residual of the two formulations of the Earth-rotation correction:
+scores agree to <1e-10 relative, channel end-parameters bit-identical, identical arg-max."""
+import os
+
+import numpy as np
+
+import navlab_dpe_sdr_amd as dpe
+
+HANDOFF = os.path.join(os.path.dirname(__file__), "golden", "handoff_params_usrp6.csv")
+
+
+def test_o7_dp_iteration(golden, oracle):
+    o = oracle
+    ho = dpe.handoff.read_handoff(HANDOFF)
+    g = golden("o7_dp_iteration")
+    K, fs, S, C = 8, float(g["fs"]), int(g["S"]), int(g["C"])
+    cm = o.ChanMgr(ho["prn_list"], ho["rc"], ho["ri"], ho["fc"], ho["fi"], ho["cp"], ho["cp_timestamp"],
+                   ho["TOW"], ho["eph"], ho["rxTime"], 0.02)
+    pos, vel = dpe.synth.spread_grid()
+    tg = np.unique(pos[:, 3])
+    X = ho["X_ECEF"]
+    batch, R = cm.start(X, X, tg)
+    # first-window bootstrap: Start-referenced params are the handoff values
+    assert np.array_equal(cm.rcStart, ho["rc"]) and np.array_equal(cm.cpElaStart, ho["cp"])
+    assert np.abs(cm.rcEnd - g["end_rc"]).max() < 1e-7
+    assert np.array_equal(cm.cpElaEnd, g["end_cp"].astype(np.int32))
+    assert np.abs(cm.riEnd - g["end_ri"]).max() < 1e-12
+    assert cm.rxTime == float(g["rxTime"])
+    code, carr = [], []
+    for k in range(K):
+        c, f, _ = o.bcs_sv(g["iq"], fs, int(ho["prn_list"][k]), cm.rcStart[k], cm.riStart[k], cm.fc[k], cm.fi[k],
+                           int(cm.cpElaStart[k]), int(cm.cpRef[k]), -64, 64, -256, 256, C)
+        code.append(c)
+        carr.append(f)
+    code, carr = np.stack(code), np.stack(carr)
+    assert np.abs(code - g["code"]).max() < 1e-10 * np.abs(g["code"]).max()
+    assert np.abs(carr - g["carr"]).max() < 1e-10 * np.abs(g["carr"]).max()
+    sat = batch[:, tg.size // 2]                       # mid-time state, batchcorrmanifold.cu:1775
+    sp, oobp = o.bcm_pos(sat, code, S // 2 - 64, X, pos, R, cm.fc, cm.cpRefTOW, cm.cpElaEnd, cm.cpRef,
+                         cm.rcEnd, cm.rxTime, fs, S, 1)
+    sv, oobv = o.bcm_vel(sat, carr, C // 2 - 256, X, vel, R, cm.fi, cm.rxTime, fs, C, 1, 1)
+    assert oobp == 0 and oobv == 0
+    assert np.abs(sp[::97] - g["pos_every97"]).max() < 1e-9 * g["pos_every97"].max()
+    assert np.abs(sv[::97] - g["vel_every97"]).max() < 1e-9 * g["vel_every97"].max()
+    assert np.abs(sp[g["top_pos_idx"]] - g["top_pos"]).max() < 1e-9 * g["top_pos"].max()
+    assert np.abs(sv[g["top_vel_idx"]] - g["top_vel"]).max() < 1e-9 * g["top_vel"].max()
+    ip, iv = o.argmax_first(sp), o.argmax_first(sv)
+    assert ip == int(g["argmax_pos"]) and iv == int(g["argmax_vel"])
+    z, Rv = o.make_meas(ip, iv, X, pos, vel, R)
+    assert np.abs((z - X) - g["e"]).max() < 1e-6       # position fix: same grid point, < 1 um
+    assert np.array_equal(Rv, np.eye(8))
