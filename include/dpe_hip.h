@@ -1,0 +1,191 @@
+/*
+ * dpe_hip.h -- C-ABI of the MI355X-native DPE correlator engine (libdpe_hip.so).
+ *
+ * Drop-in boundary for the sampleblock -> BatchCorrScores -> BatchCorrManifold path of
+ * Stanford-NavLab/NavLab-DPE-SDR (cudarecv).  Plain pointers, sizes and int status codes
+ * (0 ok, -1 failure -- the reference's convention, cudarecv/auxil/inc/errorhandler.h:43-45,
+ * 100-102); no C++ or torch types.  dpe_last_error() returns the message the reference
+ * would have printed to std::cerr.
+ *
+ * Differences from the reference interface that are deliberate:
+ *  - lengths are 32/64-bit (reference: unsigned short, dsp.h:109, sampleblock.h:81);
+ *  - several windows ("batch") can be processed per call, each with its own channel state;
+ *  - BatchCorrScores produces WINDOWED score banks (code lags [-L,+L] about the fftshift
+ *    centre S/2, Doppler bins [-B,+B] about C/2) in fp32 instead of the dense K*S / K*C
+ *    complex128 arrays; dpe_bcs_export_dense() writes the reference layout on request;
+ *  - per-channel parameters are passed from HOST memory (the reference keeps them in
+ *    device arrays written by cuChanMgr kernels, dpeflow.cpp:169-191).
+ */
+#ifndef DPE_HIP_H_
+#define DPE_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
+#define DPE_ABI_VERSION 1
+
+typedef void *dpe_stream_t;        /* hipStream_t (reference: cudaStream_t* flow stream, module.h:23) */
+typedef struct dpe_bcs dpe_bcs;    /* opaque: one BatchCorrScores instance */
+typedef struct dpe_bcm dpe_bcm;    /* opaque: one BatchCorrManifold instance */
+
+/* ------------------------------------------------------------------ general -------- */
+int dpe_abi_version(void);
+const char *dpe_last_error(void);                 /* thread-local message of the last failure */
+int dpe_device_info(char *name, int nameLen, int *cuCount, int64_t *hbmBytes);
+
+/* 37 x 1023 C/A chips (+1/-1), PRN p at row p-1.  Replaces BCS_GenCACode
+ * (batchcorrscores.cu:117-177); unlike the reference, PRN 37 is generated too. */
+int dpe_gen_ca_code(int8_t *chips /* [37*1023] host */);
+
+/* ------------------------------------------------------------------ SampleBlock ---- */
+/* Replaces the device side of dsp::SampleBlock (sampleblock.cu:356-410,465-515): copies one
+ * block of interleaved little-endian int16 I/Q (4 bytes/sample) from host to a device
+ * buffer on `stream`.  hostPinned: 1 if `src` is page-locked (reference: cudaMallocHost). */
+int dpe_sampleblock_upload(int16_t *dst_dev, const int16_t *src_host, int64_t nSamples,
+                           dpe_stream_t stream);
+int dpe_host_alloc_pinned(void **ptr, int64_t bytes);
+int dpe_host_free_pinned(void *ptr);
+/* Plain device-memory plumbing for hosts that do not bring their own allocator. */
+int dpe_device_alloc(void **ptr_dev, int64_t bytes);
+int dpe_device_free(void *ptr_dev);
+int dpe_memcpy_h2d(void *dst_dev, const void *src_host, int64_t bytes, dpe_stream_t stream);
+int dpe_memcpy_d2h(void *dst_host, const void *src_dev, int64_t bytes, dpe_stream_t stream); /* synchronises */
+int dpe_stream_create(dpe_stream_t *stream);
+int dpe_stream_destroy(dpe_stream_t stream);
+int dpe_stream_synchronize(dpe_stream_t stream);
+
+/* ------------------------------------------------------------------ BatchCorrScores - */
+typedef struct dpe_bcs_config {
+    int32_t samplesPerWindow;   /* S  = SamplingFrequency*SampleLength (sampleblock.cu:169) */
+    int32_t lagHalfWidth;       /* L: code lags [-L,+L] kept about the fftshift centre S/2 */
+    int32_t binHalfWidth;       /* B: Doppler bins [-B,+B] kept about C/2 */
+    int32_t maxWindows;         /* windows per dpe_bcs_update call (>=1) */
+    int32_t maxChannels;        /* <= DPE_MAX_CHAN */
+    int32_t reserved;
+    double samplingFrequency;   /* fs, Hz (BCS input 9, batchcorrscores.cu:690,754) */
+} dpe_bcs_config;
+
+/* One tracked SV of one window, referenced to the START of the window: BCS inputs 1-7
+ * (batchcorrscores.cu:682-688; produced by cuChanMgr, dpeflow.cpp:169-176). */
+typedef struct dpe_chan_start {
+    double codePhaseStart;      /* chips  */
+    double carrierPhaseStart;   /* cycles */
+    double codeFrequency;       /* chips/s */
+    double carrierFrequency;    /* Hz */
+    int32_t cpElapsedStart;     /* code periods since tracking start */
+    int32_t cpReference;        /* code period of the reference Z-count */
+    int32_t prn;                /* 1..37 (ValidPRNs) */
+    int32_t reserved;
+} dpe_chan_start;
+
+int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out);     /* BatchCorrScores::Start  :710-886 */
+int dpe_bcs_destroy(dpe_bcs *h);                                   /* BatchCorrScores::Stop   :888-973 */
+/* BatchCorrScores::Update :975-1208.  samples_dev: nWindows blocks of 2*S int16, block w at
+ * samples_dev + w*windowStrideSamples*2.  chan_host: [nWindows][nChan].  Asynchronous on
+ * `stream`; outputs are valid once the stream is synchronised. */
+int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples,
+                   int32_t nWindows, int32_t nChan, const dpe_chan_start *chan_host,
+                   dpe_stream_t stream);
+/* Output ports CodeScores / CarrScores / NumFFTPoints (batchcorrscores.cu:696-698,869-874).
+ * codeBank_dev: float2 [maxWindows][maxChannels][2L+1]; entry j = reference
+ * codeCorrOut_d[k*S + S/2 - L + j].  carrBank_dev: float2 [..][..][2B+1]; entry j = reference
+ * carrfftOut_d[k*C + C/2 - B + j].  Pointers are owned by the handle. */
+int dpe_bcs_outputs(dpe_bcs *h, const float **codeBank_dev, const float **carrBank_dev,
+                    int32_t *nLag, int32_t *nBin, int64_t *numFFTPoints);
+/* Diagnostics of the last update, host arrays [nWindows*nChan]: nav-bit boundary sample
+ * index (BCS_NavBitBoundary :237-258), replica choice (BCS_ChooseCodeCorr :512-516) and the
+ * per-window DC mean [nWindows*2] (:1065-1066).  Synchronises `stream`. */
+int dpe_bcs_read_info(dpe_bcs *h, int32_t *idxNext, int32_t *noFlipLarger, double *mean,
+                      dpe_stream_t stream);
+/* Writes window `window` of the banks into the reference's dense layout: complex128
+ * codeScores_dev[K*S], carrScores_dev[K*C] (zero outside the banks).  Either may be NULL. */
+int dpe_bcs_export_dense(dpe_bcs *h, int32_t window, double *codeScores_dev,
+                         double *carrScores_dev, dpe_stream_t stream);
+
+/* ------------------------------------------------------------------ BatchCorrManifold */
+typedef struct dpe_bcm_config {
+    int32_t samplesPerWindow;   /* S  (numSamps, batchcorrmanifold.cu:2536) */
+    int32_t lagHalfWidth;       /* must equal the L of the banks passed to dpe_bcm_update */
+    int32_t binHalfWidth;       /* must equal the B of the banks */
+    int32_t lPower;             /* LPower param (batchcorrmanifold.cu:2290) */
+    int32_t maxWindows;
+    int32_t maxChannels;
+    int64_t numFFTPoints;       /* C  (BCM input 11) */
+    double samplingFrequency;   /* fs (BCM input 7) */
+    /* Manifold grids, HOST, row i = {x,y,z,delta_t} ENU offsets in metres (m/s for vel):
+     * statePosManifold_t / stateVelManifold_t (gridhelper.h:11-25).  This is the LOCAL shard
+     * of the global grid; gridIndexOffset is the global index of local point 0 (multi-GPU). */
+    const double *posGrid;
+    const double *velGrid;
+    int64_t posGridSize;
+    int64_t velGridSize;
+    int64_t posGridIndexOffset;
+    int64_t velGridIndexOffset;
+    int32_t writeScores;        /* 1: keep per-point fp32 scores (PosScores port), 0: arg-max only */
+    int32_t reserved;
+} dpe_bcm_config;
+
+/* Per-window inputs of BatchCorrManifold::Update (batchcorrmanifold.cu:2261-2279,2512-2540). */
+typedef struct dpe_bcm_window {
+    double xCurrkk1[8];         /* grid centre [x,y,z,c*dt, vx,vy,vz,c*dt_dot] ECEF (input 2) */
+    double enu2ecef[9];         /* row-major ENU->ECEF (input 12, cuchanmgr.cu:54-73) */
+    double rxTime;              /* receiver clock at window end (input 5) */
+    int32_t dopplerSign;        /* +1/-1 (input 10) */
+    int32_t reserved;
+} dpe_bcm_window;
+
+/* One tracked SV of one window, referenced to the END of the window (inputs 4,8,9,14,16-18). */
+typedef struct dpe_chan_end {
+    double satState[8];         /* mid-time entry of SatStates: batch[k*dimT + dimT/2] (:1775) */
+    double codePhaseEnd;        /* chips */
+    double codeFrequency;
+    double carrierFrequency;
+    int32_t cpRefTOW;
+    int32_t cpElapsedEnd;
+    int32_t cpRef;
+    int32_t reserved;
+} dpe_chan_end;
+
+typedef struct dpe_bcm_result {
+    double zVal[8];             /* BCM_MakePosMeas/MakeVelMeas :1977-2068 */
+    int64_t posIndex;           /* global grid index of the ML point (first maximum) */
+    int64_t velIndex;
+    float posScore;
+    float velScore;
+    int64_t posOutOfWindow;     /* (point,SV) pairs whose index left the bank (reference: UB) */
+    int64_t velOutOfWindow;
+} dpe_bcm_result;
+
+int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out);     /* BatchCorrManifold::Start :2315-2463 */
+int dpe_bcm_destroy(dpe_bcm *h);                                   /* ::Stop :2467-2498 */
+/* BatchCorrManifold::Update :2502-2635 for nWindows windows.  Asynchronous on `stream`. */
+int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev,
+                   int32_t nWindows, int32_t nChan, const dpe_bcm_window *win_host,
+                   const dpe_chan_end *chan_host, dpe_stream_t stream);
+/* Synchronises `stream` and returns the per-window ML results (zVal/RVal ports; RVal is the
+ * 8x8 identity the reference writes, :2003-2011,2055-2063).  results: [nWindows]. */
+int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream);
+/* PosScores port (:2300,2404) and its velocity twin: float [maxWindows][gridSize]. */
+int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velScores_dev);
+/* Packed arg-max keys of the last update, device uint64 [maxWindows][2] (pos,vel):
+ * (score bits << 32) | (0xFFFFFFFF - globalIndex): an integer max over shards reproduces
+ * the "first maximum" tie-break of thrust::max_element (:2589-2590).  For RCCL all-reduce. */
+int dpe_bcm_keys(dpe_bcm *h, const uint64_t **keys_dev);
+/* Measurement from externally reduced keys (multi-GPU): host keys [nWindows][2]. */
+int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWindows,
+                              const double *posGridGlobal, const double *velGridGlobal,
+                              dpe_bcm_result *results);
+
+/* Timing helper for bench.py: HIP events on the stream the kernels run on. */
+int dpe_event_create(void **ev);
+int dpe_event_record(void *ev, dpe_stream_t stream);
+int dpe_event_elapsed_ms(void *start, void *stop, float *ms);  /* synchronises `stop` */
+int dpe_event_destroy(void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,383 @@
+// dpe_bcm.hip -- BatchCorrManifold for MI355X (gfx950): score every point of the ENU-dt
+// (and velocity-drift) manifold grid against the per-SV score banks, fused arg-max.
+//
+// Replaces BCM_PosMeasML / BCM_VelMeasML + thrust::max_element + BCM_MakePosMeas/MakeVelMeas
+// (cudarecv/modules/src/batchcorrmanifold.cu:1710-1828,1861-1963,2589-2596).
+//
+// The reference evaluates, per (grid point, SV), an fp64 range with ~2e7 m magnitude and maps it
+// to a fractional index into the SV's score row.  Here the geometry is expanded about the grid
+// centre on the HOST in fp64 (per window, per SV: unit line of sight in ENU, index at the centre,
+// index-per-metre scale, 1/(2 range)); the kernel then needs only fp32 DIFFERENCES:
+//   pos:  d_rho = |d - R delta| - |d| = -a + (q - a^2) h (1 + 2 a h) + O(|delta|^4 / range^3),
+//         a = u_enu . delta, q = |delta|^2, h = 1/(2 range)       (error < 1e-6 m for |delta| < 10 km)
+//         idx  = idx0 + g (delta_t + d_rho)                         (g = fs F_CA / (fc C), :1783-1791)
+//   vel:  idx  = idx0 + g_v (u_enu . delta_v - delta_tdot)          (exactly linear, :1917-1936)
+// followed by the reference's floor / floor(+1) linear interpolation (:1798-1812) and |.|^L.
+//
+// HBM traffic per window per manifold: 16 B/point grid read (float4, coalesced) + 4 B/point score
+// write; banks (K x (2L+1) float4 pairs) and SV coefficients live in LDS.
+#include "dpe_common.h"
+
+namespace dpe {
+
+struct BcmSvDev {
+    float ue, un, uu;  // unit line of sight (receiver -> SV) in the ENU frame of the grid
+    float g;           // bank entries per metre of (delta_t + d_rho)   [vel: -(entries per m/s)]
+    float h;           // 1 / (2 range)  (0 for the velocity manifold)
+    float idx0;        // bank-relative fractional index at the grid centre
+    float pad0, pad1;
+};
+
+constexpr int kPtsPerThread = 4;
+constexpr int kPtsPerBlock = 256 * kPtsPerThread;
+
+template <int LP, bool SECOND>
+__global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict__ grid, long long G, int K, int nEnt,
+                                                       int maxK, int lpower, const BcmSvDev *__restrict__ sv,
+                                                       const float2 *__restrict__ bank, float *__restrict__ scores,
+                                                       unsigned long long *__restrict__ keys,
+                                                       unsigned long long *__restrict__ oob, long long indexOffset,
+                                                       int keyStride, int keySlot)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float4 *sBank = reinterpret_cast<float4 *>(smem);                       // [K][nEnt] {c.re,c.im,d.re,d.im}
+    BcmSvDev *sSv = reinterpret_cast<BcmSvDev *>(smem + sizeof(float4) * (size_t)K * nEnt);
+    __shared__ unsigned long long sKey[4];
+    __shared__ unsigned int sOob[4];
+
+    const int w = blockIdx.y, tid = threadIdx.x;
+    const float2 *bw = bank + (size_t)w * maxK * nEnt;
+    for (int i = tid; i < K * nEnt; i += 256) {
+        const int k = i / nEnt, j = i - k * nEnt;
+        const float2 c0 = bw[(size_t)k * nEnt + j];
+        const float2 c1 = (j + 1 < nEnt) ? bw[(size_t)k * nEnt + j + 1] : c0;
+        sBank[i] = make_float4(c0.x, c0.y, c1.x - c0.x, c1.y - c0.y);
+    }
+    for (int i = tid; i < K; i += 256) sSv[i] = sv[(size_t)w * maxK + i];
+    __syncthreads();
+
+    unsigned long long best = 0ull;
+    unsigned int nOob = 0;
+    const long long base = (long long)blockIdx.x * kPtsPerBlock;
+#pragma unroll
+    for (int it = 0; it < kPtsPerThread; ++it) {
+        const long long i = base + it * 256 + tid;
+        if (i < G) {
+            const float4 d = grid[i];
+            const float q = d.x * d.x + d.y * d.y + d.z * d.z;
+            float score = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const BcmSvDev s = sSv[k];
+                const float a = fmaf(s.uu, d.z, fmaf(s.un, d.y, s.ue * d.x));
+                float x = d.w - a;
+                if (SECOND) {
+                    const float t = fmaf(-a, a, q);
+                    const float ah = a * s.h;
+                    x = fmaf(t * s.h, fmaf(2.f, ah, 1.f), x);
+                }
+                const float idx = fmaf(s.g, x, s.idx0);
+                const float fl = floorf(idx);
+                const float wgt = idx - fl;
+                const int e = (int)fl;
+                const bool ok = (unsigned)e < (unsigned)(nEnt - 1);
+                const float4 b = sBank[k * nEnt + (ok ? e : 0)];
+                const float vr = fmaf(wgt, b.z, b.x), vi = fmaf(wgt, b.w, b.y);
+                const float m2 = vr * vr + vi * vi;
+                float c;
+                if (LP == 1) c = sqrtf(m2);
+                else if (LP == 2) c = m2;
+                else c = powf(sqrtf(m2), (float)lpower);
+                score += ok ? c : 0.f;
+                nOob += ok ? 0u : 1u;
+            }
+            if (scores) scores[(size_t)w * G + i] = score;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) |
+                                           (unsigned long long)(0xFFFFFFFFu - (unsigned int)(i + indexOffset));
+            best = key > best ? key : best;
+        }
+    }
+    // block arg-max: larger score wins, ties -> smaller global index (thrust::max_element, :2589)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+        nOob += __shfl_xor(nOob, off, 64);
+    }
+    if ((tid & 63) == 0) { sKey[tid >> 6] = best; sOob[tid >> 6] = nOob; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = sKey[0];
+        b = sKey[1] > b ? sKey[1] : b;
+        b = sKey[2] > b ? sKey[2] : b;
+        b = sKey[3] > b ? sKey[3] : b;
+        atomicMax(&keys[(size_t)w * keyStride + keySlot], b);  // integer max: order-independent
+        const unsigned int n = sOob[0] + sOob[1] + sOob[2] + sOob[3];
+        if (n) atomicAdd(&oob[(size_t)w * keyStride + keySlot], (unsigned long long)n);
+    }
+}
+
+}  // namespace dpe
+
+// ============================================================================================
+struct dpe_bcm {
+    dpe_bcm_config cfg;
+    std::vector<double> posGrid_h, velGrid_h;  // local shard, fp64 (for zVal)
+    float4 *posGrid_d = nullptr, *velGrid_d = nullptr;
+    float *posScores_d = nullptr, *velScores_d = nullptr;
+    dpe::BcmSvDev *sv_d = nullptr, *sv_h = nullptr;  // [2][W][maxK]  (manifold-major)
+    unsigned long long *keys_d = nullptr, *oob_d = nullptr;  // [W][2]
+    std::vector<dpe_bcm_window> win_h;
+    int lastW = 0;
+};
+
+static int upload_grid(const double *src, int64_t G, std::vector<double> &keep, float4 **dst)
+{
+    using namespace dpe;
+    keep.assign(src, src + 4 * G);
+    std::vector<float4> f((size_t)G);
+    for (int64_t i = 0; i < G; ++i)
+        f[i] = make_float4((float)src[4 * i], (float)src[4 * i + 1], (float)src[4 * i + 2], (float)src[4 * i + 3]);
+    *dst = dev_alloc<float4>((size_t)G);
+    DPE_REQUIRE(*dst, "[BatchCorrManifold] create: grid allocation failed (%lld points)", (long long)G);
+    DPE_CHECK_HIP(hipMemcpy(*dst, f.data(), sizeof(float4) * (size_t)G, hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <bool SECOND>
+static void launch_scan(int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
+                        int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores, unsigned long long *keys,
+                        unsigned long long *oob, long long off, int slot)
+{
+    using namespace dpe;
+    if (lp == 1)
+        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+    else if (lp == 2)
+        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+    else
+        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+}
+
+extern "C" {
+
+int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
+{
+    using namespace dpe;
+    DPE_REQUIRE(cfg && out, "[BatchCorrManifold] create: null argument");
+    DPE_REQUIRE(cfg->samplesPerWindow > 0 && (cfg->samplesPerWindow % 2) == 0,
+                "[BatchCorrManifold] create: samplesPerWindow must be even and positive");
+    DPE_REQUIRE(cfg->samplingFrequency > 0 && cfg->numFFTPoints > 0, "[BatchCorrManifold] create: bad fs / numFFTPoints");
+    DPE_REQUIRE(cfg->maxWindows >= 1 && cfg->maxChannels >= 1 && cfg->maxChannels <= DPE_MAX_CHAN,
+                "[BatchCorrManifold] create: maxWindows/maxChannels out of range");
+    DPE_REQUIRE(cfg->lagHalfWidth >= 1 && cfg->binHalfWidth >= 1 && cfg->lPower >= 1, "[BatchCorrManifold] create: bad L/B/LPower");
+    DPE_REQUIRE(cfg->posGrid && cfg->velGrid && cfg->posGridSize > 0 && cfg->velGridSize > 0,
+                "[BatchCorrManifold] create: grids missing");
+    DPE_REQUIRE(cfg->posGridSize + cfg->posGridIndexOffset < 0xFFFFFFFFll &&
+                cfg->velGridSize + cfg->velGridIndexOffset < 0xFFFFFFFFll,
+                "[BatchCorrManifold] create: global grid index exceeds 32 bits");
+    const size_t ldsNeed = (size_t)cfg->maxChannels *
+                           ((size_t)(2 * (cfg->lagHalfWidth > cfg->binHalfWidth ? cfg->lagHalfWidth : cfg->binHalfWidth) + 1) * 16 + 32);
+    DPE_REQUIRE(ldsNeed <= 150 * 1024, "[BatchCorrManifold] create: score banks (%zu B) exceed the 160 KB LDS", ldsNeed);
+    // validity of the range expansion (file header): |delta| must stay far below the SV range
+    double maxR2 = 0;
+    for (int64_t i = 0; i < cfg->posGridSize; ++i) {
+        const double *p = cfg->posGrid + 4 * i;
+        const double r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        if (r2 > maxR2) maxR2 = r2;
+    }
+    DPE_REQUIRE(maxR2 < 2.0e4 * 2.0e4, "[BatchCorrManifold] create: position grid extends beyond 20 km from its centre");
+    dpe_bcm *h = new dpe_bcm();
+    h->cfg = *cfg;
+    h->cfg.posGrid = h->cfg.velGrid = nullptr;
+    const size_t W = cfg->maxWindows, K = cfg->maxChannels;
+    if (upload_grid(cfg->posGrid, cfg->posGridSize, h->posGrid_h, &h->posGrid_d) ||
+        upload_grid(cfg->velGrid, cfg->velGridSize, h->velGrid_h, &h->velGrid_d)) {
+        dpe_bcm_destroy(h);
+        return -1;
+    }
+    if (cfg->writeScores) {
+        h->posScores_d = dev_alloc<float>(W * (size_t)cfg->posGridSize);
+        h->velScores_d = dev_alloc<float>(W * (size_t)cfg->velGridSize);
+    }
+    h->sv_d = dev_alloc<BcmSvDev>(2 * W * K);
+    h->keys_d = dev_alloc<unsigned long long>(2 * W);
+    h->oob_d = dev_alloc<unsigned long long>(2 * W);
+    if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->oob_d ||
+        hipHostMalloc((void **)&h->sv_h, 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess) {
+        set_error("[BatchCorrManifold] create: device allocation failed");
+        dpe_bcm_destroy(h);
+        return -1;
+    }
+    // dynamic LDS above 64 KB needs the opt-in attribute
+    const int maxLds = 155 * 1024;
+    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+    h->win_h.resize(W);
+    *out = h;
+    return 0;
+}
+
+int dpe_bcm_destroy(dpe_bcm *h)
+{
+    if (!h) return 0;
+    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->oob_d};
+    for (void *b : bufs) (void)hipFree(b);
+    if (h->sv_h) (void)hipHostFree(h->sv_h);
+    delete h;
+    return 0;
+}
+
+int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nWindows, int32_t nChan,
+                   const dpe_bcm_window *win_host, const dpe_chan_end *chan_host, dpe_stream_t stream_)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && codeBank_dev && carrBank_dev && win_host && chan_host, "[BatchCorrManifold] Update: null argument");
+    DPE_REQUIRE(nWindows >= 1 && nWindows <= h->cfg.maxWindows, "[BatchCorrManifold] Update: nWindows %d out of range", nWindows);
+    DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrManifold] Update: nChan %d out of range", nChan);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int S = h->cfg.samplesPerWindow, L = h->cfg.lagHalfWidth, B = h->cfg.binHalfWidth;
+    const int maxK = h->cfg.maxChannels, W = h->cfg.maxWindows;
+    const double fs = h->cfg.samplingFrequency, Cf = (double)h->cfg.numFFTPoints;
+    for (int w = 0; w < nWindows; ++w) {
+        const dpe_bcm_window &win = win_host[w];
+        DPE_REQUIRE(win.dopplerSign == 1 || win.dopplerSign == -1, "[BatchCorrManifold] Update: dopplerSign must be +/-1");
+        h->win_h[w] = win;
+        const double *c = win.xCurrkk1, *R = win.enu2ecef;
+        for (int k = 0; k < nChan; ++k) {
+            const dpe_chan_end &ch = chan_host[(size_t)w * nChan + k];
+            const double *s = ch.satState;
+            const double dx = s[0] - c[0], dy = s[1] - c[1], dz = s[2] - c[2];       // :1779-1781
+            const double range = std::sqrt(dx * dx + dy * dy + dz * dz);               // :1782
+            const double ux = dx / range, uy = dy / range, uz = dz / range;
+            const double ue = R[0] * ux + R[3] * uy + R[6] * uz;                        // R^T u
+            const double un = R[1] * ux + R[4] * uy + R[7] * uz;
+            const double uu = R[2] * ux + R[5] * uy + R[8] * uz;
+            // position manifold, centre index (:1783-1791)
+            const double pr = range - kC * s[3] + c[3];
+            const double txT = win.rxTime - pr / kC;
+            const double cfd = txT - ch.cpRefTOW - ((ch.cpElapsedEnd - ch.cpRef) * kTCA);
+            const double rc0 = cfd * kFCA - ch.codePhaseEnd;
+            const double basePos = (fs / ch.codeFrequency) * (-rc0) + S / 2.0;
+            BcmSvDev &p = h->sv_h[(size_t)(0 * W + w) * maxK + k];
+            p.ue = (float)ue; p.un = (float)un; p.uu = (float)uu;
+            p.g = (float)(fs * kFCA / (ch.codeFrequency * kC));
+            p.h = (float)(0.5 / range);
+            p.idx0 = (float)(basePos - (double)(S / 2 - L));
+            p.pad0 = p.pad1 = 0.f;
+            // velocity manifold, centre index (:1917-1936)
+            const double ex = c[4] - kOEDot * c[1], ey = c[5] + kOEDot * c[0], ez = c[6];
+            const double lrr = ux * (ex - s[4]) + uy * (ey - s[5]) + uz * (ez - s[6]);
+            const double fbc = kFL1 * ((lrr - c[7]) / kC + s[7]) / win.dopplerSign;
+            const double baseVel = (Cf / fs) * (fbc - ch.carrierFrequency) + Cf / 2.0;
+            const double gv = (Cf / fs) * kFL1 / (kC * win.dopplerSign);
+            BcmSvDev &v = h->sv_h[(size_t)(1 * W + w) * maxK + k];
+            v.ue = (float)ue; v.un = (float)un; v.uu = (float)uu;
+            v.g = (float)(-gv);   // kernel forms x = delta_tdot - a
+            v.h = 0.f;
+            v.idx0 = (float)(baseVel - (double)(h->cfg.numFFTPoints / 2 - B));
+            v.pad0 = v.pad1 = 0.f;
+        }
+    }
+    h->lastW = nWindows;
+    // one copy covers both manifolds' coefficient blocks
+    DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
+    DPE_CHECK_HIP(hipMemsetAsync(h->keys_d, 0, sizeof(unsigned long long) * 2 * nWindows, stream));
+    DPE_CHECK_HIP(hipMemsetAsync(h->oob_d, 0, sizeof(unsigned long long) * 2 * nWindows, stream));
+    const int nLag = 2 * L + 1, nBin = 2 * B + 1;
+    {
+        const long long G = h->cfg.posGridSize;
+        const dim3 grid((unsigned)((G + kPtsPerBlock - 1) / kPtsPerBlock), nWindows);
+        const size_t lds = (size_t)nChan * nLag * sizeof(float4) + (size_t)nChan * sizeof(BcmSvDev);
+        launch_scan<true>(h->cfg.lPower, grid, lds, stream, h->posGrid_d, G, nChan, nLag, maxK, h->sv_d,
+                          reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, h->keys_d, h->oob_d,
+                          h->cfg.posGridIndexOffset, 0);
+    }
+    {
+        const long long G = h->cfg.velGridSize;
+        const dim3 grid((unsigned)((G + kPtsPerBlock - 1) / kPtsPerBlock), nWindows);
+        const size_t lds = (size_t)nChan * nBin * sizeof(float4) + (size_t)nChan * sizeof(BcmSvDev);
+        launch_scan<false>(h->cfg.lPower, grid, lds, stream, h->velGrid_d, G, nChan, nBin, maxK,
+                           h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev), h->velScores_d,
+                           h->keys_d, h->oob_d, h->cfg.velGridIndexOffset, 1);
+    }
+    DPE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static void make_meas(const dpe_bcm_window &win, const double *p, const double *v, double z[8])
+{
+    const double *R = win.enu2ecef, *c = win.xCurrkk1;
+    z[0] = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + c[0];   // BCM_MakePosMeas :1990-1999
+    z[1] = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + c[1];
+    z[2] = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + c[2];
+    z[3] = p[3] + c[3];
+    z[4] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + c[4];   // BCM_MakeVelMeas :2042-2051
+    z[5] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + c[5];
+    z[6] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + c[6];
+    z[7] = v[3] + c[7];
+}
+
+static void decode_key(unsigned long long key, float *score, int64_t *index)
+{
+    const unsigned int bits = (unsigned int)(key >> 32);
+    memcpy(score, &bits, sizeof(float));
+    *index = (int64_t)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+}
+
+int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h && results && h->lastW > 0, "[BatchCorrManifold] results: no update yet");
+    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    const int W = h->lastW;
+    std::vector<unsigned long long> keys(2 * W), oob(2 * W);
+    DPE_CHECK_HIP(hipMemcpy(keys.data(), h->keys_d, sizeof(unsigned long long) * 2 * W, hipMemcpyDeviceToHost));
+    DPE_CHECK_HIP(hipMemcpy(oob.data(), h->oob_d, sizeof(unsigned long long) * 2 * W, hipMemcpyDeviceToHost));
+    for (int w = 0; w < W; ++w) {
+        dpe_bcm_result &r = results[w];
+        decode_key(keys[2 * w], &r.posScore, &r.posIndex);
+        decode_key(keys[2 * w + 1], &r.velScore, &r.velIndex);
+        r.posOutOfWindow = (int64_t)oob[2 * w];
+        r.velOutOfWindow = (int64_t)oob[2 * w + 1];
+        const int64_t pl = r.posIndex - h->cfg.posGridIndexOffset, vl = r.velIndex - h->cfg.velGridIndexOffset;
+        DPE_REQUIRE(pl >= 0 && pl < h->cfg.posGridSize && vl >= 0 && vl < h->cfg.velGridSize,
+                    "[BatchCorrManifold] results: arg-max index outside the local shard");
+        make_meas(h->win_h[w], h->posGrid_h.data() + 4 * pl, h->velGrid_h.data() + 4 * vl, r.zVal);
+    }
+    return 0;
+}
+
+int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velScores_dev)
+{
+    DPE_REQUIRE(h, "[BatchCorrManifold] scores: null handle");
+    DPE_REQUIRE(h->cfg.writeScores, "[BatchCorrManifold] scores: created with writeScores=0");
+    if (posScores_dev) *posScores_dev = h->posScores_d;
+    if (velScores_dev) *velScores_dev = h->velScores_d;
+    return 0;
+}
+
+int dpe_bcm_keys(dpe_bcm *h, const uint64_t **keys_dev)
+{
+    DPE_REQUIRE(h && keys_dev, "[BatchCorrManifold] keys: null argument");
+    *keys_dev = reinterpret_cast<const uint64_t *>(h->keys_d);
+    return 0;
+}
+
+int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWindows, const double *posGridGlobal,
+                              const double *velGridGlobal, dpe_bcm_result *results)
+{
+    DPE_REQUIRE(h && keys_host && posGridGlobal && velGridGlobal && results, "[BatchCorrManifold] results_from_keys: null argument");
+    DPE_REQUIRE(nWindows >= 1 && nWindows <= h->lastW, "[BatchCorrManifold] results_from_keys: bad nWindows");
+    for (int w = 0; w < nWindows; ++w) {
+        dpe_bcm_result &r = results[w];
+        decode_key(keys_host[2 * w], &r.posScore, &r.posIndex);
+        decode_key(keys_host[2 * w + 1], &r.velScore, &r.velIndex);
+        r.posOutOfWindow = r.velOutOfWindow = -1;
+        make_meas(h->win_h[w], posGridGlobal + 4 * r.posIndex, velGridGlobal + 4 * r.velIndex, r.zVal);
+    }
+    return 0;
+}
+
+}  // extern "C"

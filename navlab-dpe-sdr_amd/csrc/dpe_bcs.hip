@@ -1,0 +1,515 @@
+// dpe_bcs.hip -- BatchCorrScores for MI355X (gfx950): int16 I/Q -> windowed code-lag bank +
+// windowed Doppler-bin bank per SV, for a batch of windows.
+//
+// Replaces the reference chain  BCS_Load -> thrust::reduce(mean) -> BCS_ComputeDopplerWipeoff
+// -> BCS_ComputeCodeReplica -> 5x cufftExecZ2Z(S) -> BCS_ChooseCodeCorr -> fftshift ->
+// BCS_SubtractDCOffset -> BCS_ChoosyBatchMultiplyAndPad -> cufftExecZ2Z(C) -> fftshift
+// (cudarecv/modules/src/batchcorrscores.cu:1043-1180) by ONE streaming pass over the samples:
+//
+//   code bank   corr[l] = sum_n b[n] r[(n-l) mod S]         (== ifft(conj(fft r) fft b), :1099-1144)
+//               for the lags l in [-L,+L] the manifold grid can reach, split at the nav-bit
+//               boundary (X: replica index < idxNext, Y: >=) so that no-flip = X+Y, flip = X-Y;
+//   carr bank   F[b] = sum_n c[n] exp(-j 2 pi n b / C)      (== zero-padded FFT bin b, :1179)
+//               for bins b in [-B,+B], from per-256-sample power moments M_p = sum x^p c[n]
+//               (x = n - block centre) and a degree-5 Taylor factor per block -- exact to
+//               (2 pi 127.5 B / C)^6 / 720 (checked at create), ~15x fewer flops than direct.
+//
+// Data layout (HBM): samples int16 I,Q interleaved, read once per SV with 16-byte lane loads;
+// chip table int8 [37][1024] -> LDS per block; replica +/-1 (nav-bit side masked) per wave
+// sub-tile in LDS; per-block partial lag sums and per-sub-tile moments in global scratch,
+// reduced in fixed order (no float atomics: bit-reproducible run to run).
+#include "dpe_common.h"
+
+namespace dpe {
+
+constexpr int kSub = 256;   // samples per wave sub-tile (4 per lane) == moment block
+constexpr int kNMom = 6;    // power moments 0..5
+
+struct BcsChanDev {
+    double rc;        // code phase at sample 0 (chips)
+    double codeStep;  // chips per sample  = fc / fs
+    double ri;        // carrier phase at sample 0 (cycles)
+    double carrStep;  // cycles per sample = fi / fs
+    float rotRe, rotIm;  // exp(-j 2 pi carrStep)
+    int32_t idxNext;  // BCS_NavBitBoundary
+    int32_t hasFlip;  // 0 < idxNext < S
+    int32_t prn;
+    int32_t pad;
+};
+
+// ------------------------------------------------------------------------------------------
+// DC sum (thrust::reduce at batchcorrscores.cu:1065): exact int64 sums, order-independent.
+__global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
+                                                      long long *__restrict__ sums)
+{
+    const int w = blockIdx.y;
+    const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);
+    int sI = 0, sQ = 0;  // <= ~S/gridDim.x/256 samples per thread: no int32 overflow below 65k each
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < S; n += gridDim.x * blockDim.x) {
+        const int v = x[n];
+        sI += (short)(v & 0xFFFF);
+        sQ += v >> 16;
+    }
+    long long tI = sI, tQ = sQ;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tI += __shfl_xor(tI, off, 64);
+        tQ += __shfl_xor(tQ, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sums[2 * w]), (unsigned long long)tI);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sums[2 * w + 1]), (unsigned long long)tQ);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int LH>
+__global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
+                                                       int K, int nSub, int tilesPerBlock, int nBlk, int vecOK,
+                                                       const BcsChanDev *__restrict__ chan,
+                                                       const long long *__restrict__ sums,
+                                                       const int8_t *__restrict__ chipTable,
+                                                       float2 *__restrict__ part, float2 *__restrict__ mom)
+{
+    constexpr int NL = 2 * LH + 1;      // lags
+    constexpr int NREP = kSub + 2 * LH;  // replica entries per sub-tile (with halo)
+    constexpr int NRR = 4 + 2 * LH;      // entries one lane touches
+    __shared__ int8_t sChips[1024];
+    __shared__ __align__(16) float sRep[4][NREP + 4];
+    __shared__ float2 sAcc[4][NL];
+
+    const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const BcsChanDev ch = chan[w * K + k];
+    for (int i = tid; i < 1024; i += 256) sChips[i] = chipTable[(ch.prn - 1) * 1024 + i];
+    // DC mean = sum / (float)S in fp64 (batchcorrscores.cu:1065-1066,1210-1216), then fp32
+    const float mRe = (float)((double)sums[2 * w] / (double)(float)S);
+    const float mIm = (float)((double)sums[2 * w + 1] / (double)(float)S);
+    const int16_t *x = iq + (size_t)w * winStride * 2;
+    float xp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xp[i] = (float)(4 * lane + i) - 127.5f;
+    __syncthreads();
+
+    for (int side = 0; side < 2; ++side) {
+        float2 acc[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[j] = make_float2(0.f, 0.f);
+
+        for (int t = 0; t < tilesPerBlock; ++t) {
+            const int sub = (blk * tilesPerBlock + t) * 4 + wave;
+            const int sub0 = sub * kSub;
+            const int lo = sub0 - LH, hi = sub0 + kSub - 1 + LH;
+            bool active = sub < nSub;
+            if (active) {
+                if (!ch.hasFlip) active = (side == 0);
+                else if (lo >= 0 && hi < S) active = (side == 0) ? (lo < ch.idxNext) : (hi >= ch.idxNext);
+            }
+            if (active) {
+                // replica r[m] = chip[floor(t_m fc + rc) mod 1023] (BCS_ComputeCodeReplica :347-349),
+                // masked to this side of the nav-bit boundary (:352-367), m wrapped circularly.
+                for (int e = lane; e < NREP; e += 64) {
+                    int m = lo + e;
+                    if (m < 0) m += S; else if (m >= S) m -= S;
+                    const double cph = fma((double)m, ch.codeStep, ch.rc);
+                    const int ci = ((int)floor(cph)) % kLCA;
+                    const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
+                    sRep[wave][e] = (sd == side) ? (float)sChips[ci] : 0.f;
+                }
+            }
+            __syncthreads();
+            float2 M[kNMom];
+#pragma unroll
+            for (int p = 0; p < kNMom; ++p) M[p] = make_float2(0.f, 0.f);
+            if (active) {
+                const int n0 = sub0 + 4 * lane;
+                float re[4], im[4];
+                if (vecOK && n0 + 3 < S) {
+                    const int4 v = *reinterpret_cast<const int4 *>(x + 2 * (size_t)n0);
+                    re[0] = (float)(short)(v.x & 0xFFFF); im[0] = (float)(v.x >> 16);
+                    re[1] = (float)(short)(v.y & 0xFFFF); im[1] = (float)(v.y >> 16);
+                    re[2] = (float)(short)(v.z & 0xFFFF); im[2] = (float)(v.z >> 16);
+                    re[3] = (float)(short)(v.w & 0xFFFF); im[3] = (float)(v.w >> 16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int v = 0;
+                        if (n0 + i < S) v = *reinterpret_cast<const int *>(x + 2 * (size_t)(n0 + i));
+                        re[i] = (float)(short)(v & 0xFFFF);
+                        im[i] = (float)(v >> 16);
+                    }
+                }
+                // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300):
+                // fp64 phase seed per lane, hardware sin/cos in revolutions, 3 fp32 rotations.
+                double ph = fma((double)n0, ch.carrStep, ch.ri);
+                ph -= floor(ph);
+                const float f = (float)ph;
+                float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
+                float rr[NRR];
+#pragma unroll
+                for (int q = 0; q < NRR / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&sRep[wave][4 * lane + 4 * q]);
+                    rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // rawWiped = raw * wipe (BCS_BatchMultiply :402)
+                    const float br = re[i] * wr - im[i] * wi;
+                    const float bi = re[i] * wi + im[i] * wr;
+                    // sample n, lag l = j-LH uses replica index n-l -> rr[i - j + 2 LH]
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        acc[j].x = fmaf(br, rr[i + 2 * LH - j], acc[j].x);
+                        acc[j].y = fmaf(bi, rr[i + 2 * LH - j], acc[j].y);
+                    }
+                    // carrier path: (raw - mean) * wipe * replica (:480, :440-448)
+                    const float r0 = (n0 + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
+                    const float cr = (br - (mRe * wr - mIm * wi)) * r0;
+                    const float cim = (bi - (mRe * wi + mIm * wr)) * r0;
+                    float pw = 1.f;
+#pragma unroll
+                    for (int p = 0; p < kNMom; ++p) {
+                        M[p].x = fmaf(pw, cr, M[p].x);
+                        M[p].y = fmaf(pw, cim, M[p].y);
+                        pw *= xp[i];
+                    }
+                    const float nr = wr * ch.rotRe - wi * ch.rotIm;
+                    wi = wr * ch.rotIm + wi * ch.rotRe;
+                    wr = nr;
+                }
+            }
+            if (sub < nSub) {
+#pragma unroll
+                for (int p = 0; p < kNMom; ++p) {
+                    M[p].x = wave_sum(M[p].x);
+                    M[p].y = wave_sum(M[p].y);
+                }
+                if (lane == 0) {
+                    float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
+#pragma unroll
+                    for (int p = 0; p < kNMom; ++p) o[p] = M[p];
+                }
+            }
+            __syncthreads();
+        }
+        // block partial of the lag sums, fixed reduction order
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const float sx = wave_sum(acc[j].x), sy = wave_sum(acc[j].y);
+            if (lane == 0) sAcc[wave][j] = make_float2(sx, sy);
+        }
+        __syncthreads();
+        for (int j = tid; j < NL; j += 256) {
+            float2 s = sAcc[0][j];
+            s.x += sAcc[1][j].x; s.y += sAcc[1][j].y;
+            s.x += sAcc[2][j].x; s.y += sAcc[2][j].y;
+            s.x += sAcc[3][j].x; s.y += sAcc[3][j].y;
+            part[((((size_t)w * K + k) * nBlk + blk) * 2 + side) * NL + j] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
+__global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSub, int nBlk, int LH, int L, int B,
+                                                           long long C, const BcsChanDev *__restrict__ chan,
+                                                           const float2 *__restrict__ part,
+                                                           const float2 *__restrict__ mom,
+                                                           float2 *__restrict__ codeBank, float2 *__restrict__ carrBank,
+                                                           int *__restrict__ info, int maxK)
+{
+    const int k = blockIdx.y, w = blockIdx.z, tid = threadIdx.x;
+    const int NL = 2 * LH + 1;
+    const BcsChanDev ch = chan[w * K + k];
+    const float2 *pp = part + ((size_t)w * K + k) * nBlk * 2 * NL;
+    __shared__ int sNoFlip;
+    __shared__ float2 sRed[4][64];
+    if (tid == 0) {
+        // BCS_ChooseCodeCorr :512-516 -- decision at lag 0 only
+        float2 X = make_float2(0.f, 0.f), Y = make_float2(0.f, 0.f);
+        for (int b = 0; b < nBlk; ++b) {
+            const float2 a = pp[(size_t)(b * 2) * NL + LH], c = pp[(size_t)(b * 2 + 1) * NL + LH];
+            X.x += a.x; X.y += a.y; Y.x += c.x; Y.y += c.y;
+        }
+        const float nr = X.x + Y.x, ni = X.y + Y.y, fr = X.x - Y.x, fi = X.y - Y.y;
+        sNoFlip = (!ch.hasFlip) || (nr * nr + ni * ni > fr * fr + fi * fi);
+    }
+    __syncthreads();
+    const int noFlip = sNoFlip;
+    const float sgn = noFlip ? 1.f : -1.f;
+
+    if (blockIdx.x == 0) {
+        if (tid == 0) info[w * K + k] = noFlip;
+        for (int j = tid; j < 2 * L + 1; j += 256) {
+            const int jj = j + (LH - L);
+            float2 X = make_float2(0.f, 0.f), Y = make_float2(0.f, 0.f);
+            for (int b = 0; b < nBlk; ++b) {
+                const float2 a = pp[(size_t)(b * 2) * NL + jj], c = pp[(size_t)(b * 2 + 1) * NL + jj];
+                X.x += a.x; X.y += a.y; Y.x += c.x; Y.y += c.y;
+            }
+            codeBank[((size_t)w * maxK + k) * (2 * L + 1) + j] = make_float2(X.x + sgn * Y.x, X.y + sgn * Y.y);
+        }
+        return;
+    }
+    // ---- Doppler bins: F[b] = sum_sub tw(sub,b) * sum_p (-j theta)^p / p! * M_p[sub]
+    const int bi = (blockIdx.x - 1) * 64 + (tid & 63);  // bank entry
+    const int grp = tid >> 6;                           // 4 groups split the sub-tiles
+    const int b = bi - B;
+    float2 F = make_float2(0.f, 0.f);
+    if (bi < 2 * B + 1) {
+        const float theta = (float)(6.283185307179586476925286766559 * (double)b / (double)C);
+        const float2 *m0 = mom + (((size_t)w * K + k) * 2) * nSub * kNMom;
+        const float2 *m1 = m0 + (size_t)nSub * kNMom;
+        const float invC = 1.0f / (float)C;  // C is a power of two: exact
+        for (int sub = grp; sub < nSub; sub += 4) {
+            const float2 *a0 = m0 + (size_t)sub * kNMom, *a1 = m1 + (size_t)sub * kNMom;
+            float ar = a0[kNMom - 1].x + sgn * a1[kNMom - 1].x;
+            float ai = a0[kNMom - 1].y + sgn * a1[kNMom - 1].y;
+#pragma unroll
+            for (int p = kNMom - 1; p >= 1; --p) {
+                const float s = theta / (float)p;
+                const float mr = a0[p - 1].x + sgn * a1[p - 1].x, mi = a0[p - 1].y + sgn * a1[p - 1].y;
+                const float nr = fmaf(s, ai, mr);
+                ai = fmaf(-s, ar, mi);
+                ar = nr;
+            }
+            // block centre n_c = 256 sub + 127.5 -> phase = -(512 sub + 255) b / (2C) revolutions
+            long long tt = ((long long)(512 * sub + 255) * (long long)b) % (2 * C);
+            if (tt < 0) tt += 2 * C;
+            float sn, cs;
+            sincospif((float)tt * invC, &sn, &cs);  // angle = pi * tt / C
+            // (cs - j sn) * (ar + j ai)
+            F.x += cs * ar + sn * ai;
+            F.y += cs * ai - sn * ar;
+        }
+    }
+    sRed[grp][tid & 63] = F;
+    __syncthreads();
+    if (grp == 0 && bi < 2 * B + 1) {
+        float2 s = sRed[0][tid];
+        s.x += sRed[1][tid].x; s.y += sRed[1][tid].y;
+        s.x += sRed[2][tid].x; s.y += sRed[2][tid].y;
+        s.x += sRed[3][tid].x; s.y += sRed[3][tid].y;
+        carrBank[((size_t)w * maxK + k) * (2 * B + 1) + bi] = s;
+    }
+}
+
+// Dense export in the reference layout (complex128, fft-shifted rows), zero outside the banks.
+__global__ void bcs_export_kernel(const float2 *__restrict__ bank, int n, long long rowLen, long long centre, int K,
+                                  int maxK, int half, double2 *__restrict__ dense)
+{
+    const int k = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float2 v = bank[(size_t)k * n + j];
+        dense[(size_t)k * rowLen + centre - half + j] = make_double2((double)v.x, (double)v.y);
+    }
+    (void)K; (void)maxK;
+}
+
+}  // namespace dpe
+
+// ============================================================================================
+struct dpe_bcs {
+    dpe_bcs_config cfg;
+    int LH;             // internal lag half width (4,8,16,32)
+    int nSub, nBlk, tilesPerBlock;
+    long long C;
+    int8_t *chipTable_d = nullptr;
+    long long *sums_d = nullptr;
+    dpe::BcsChanDev *chan_d = nullptr;
+    dpe::BcsChanDev *chan_h = nullptr;  // pinned staging
+    float2 *part_d = nullptr, *mom_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
+    int *info_d = nullptr;
+    int lastW = 0, lastK = 0;
+    std::vector<int32_t> idxNext_h;
+};
+
+static long long next_pow2(long long x)
+{
+    long long p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+extern "C" {
+
+int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
+{
+    using namespace dpe;
+    DPE_REQUIRE(cfg && out, "[BatchCorrScores] create: null argument");
+    DPE_REQUIRE(cfg->samplesPerWindow >= 1024, "[BatchCorrScores] create: samplesPerWindow %d < 1024", cfg->samplesPerWindow);
+    DPE_REQUIRE(cfg->samplingFrequency > 0, "[BatchCorrScores] create: bad samplingFrequency");
+    DPE_REQUIRE(cfg->maxWindows >= 1 && cfg->maxChannels >= 1 && cfg->maxChannels <= DPE_MAX_CHAN,
+                "[BatchCorrScores] create: maxWindows/maxChannels out of range");
+    DPE_REQUIRE(cfg->lagHalfWidth >= 1 && cfg->lagHalfWidth <= 32,
+                "[BatchCorrScores] create: lagHalfWidth %d not in [1,32]", cfg->lagHalfWidth);
+    DPE_REQUIRE(cfg->binHalfWidth >= 1, "[BatchCorrScores] create: binHalfWidth < 1");
+    const int S = cfg->samplesPerWindow;
+    const long long C = 8 * next_pow2(S);  // batchcorrscores.cu:761
+    // Taylor remainder of the moment expansion must stay below fp32 rounding (see file header)
+    const double th = 6.283185307179586 * 127.5 * cfg->binHalfWidth / (double)C;
+    DPE_REQUIRE(std::pow(th, 6) / 720.0 < 2e-7,
+                "[BatchCorrScores] create: binHalfWidth %d too wide for the moment expansion at C=%lld",
+                cfg->binHalfWidth, C);
+    // The kernels index time as n/fs; the reference rounds t_n to 1 ns (BCS_GenTimeIdcs :191-193).
+    // Accept only sampling rates for which that rounding is a no-op (all usual SDR rates).
+    const double fs = cfg->samplingFrequency;
+    for (int n = 0; n < S; n += (S > 4096 ? 97 : 1)) {
+        const double t = (double)n / fs, tr = std::round(t * 1.0e9) / 1.0e9;
+        DPE_REQUIRE(std::fabs(t - tr) <= 4e-16 * (t + 1e-9),
+                    "[BatchCorrScores] create: samplingFrequency %.3f Hz has a non-integer-ns period (unsupported)", fs);
+    }
+    dpe_bcs *h = new dpe_bcs();
+    h->cfg = *cfg;
+    h->C = C;
+    h->LH = cfg->lagHalfWidth <= 4 ? 4 : cfg->lagHalfWidth <= 8 ? 8 : cfg->lagHalfWidth <= 16 ? 16 : 32;
+    h->nSub = (S + kSub - 1) / kSub;
+    const int nTiles = (h->nSub + 3) / 4;
+    h->tilesPerBlock = (nTiles + 63) / 64;
+    h->nBlk = (nTiles + h->tilesPerBlock - 1) / h->tilesPerBlock;
+    const size_t W = cfg->maxWindows, K = cfg->maxChannels;
+    std::vector<int8_t> table(37 * 1024, 0);
+    for (int prn = 1; prn <= 37; ++prn) gen_ca_code_host(prn, table.data() + (prn - 1) * 1024);
+    h->chipTable_d = dev_alloc<int8_t>(table.size());
+    h->sums_d = dev_alloc<long long>(2 * W);
+    h->chan_d = dev_alloc<BcsChanDev>(W * K);
+    h->part_d = dev_alloc<float2>(W * K * h->nBlk * 2 * (2 * h->LH + 1));
+    h->mom_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMom);
+    h->codeBank_d = dev_alloc<float2>(W * K * (2 * cfg->lagHalfWidth + 1));
+    h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
+    h->info_d = dev_alloc<int>(W * K);
+    if (!h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->codeBank_d || !h->carrBank_d ||
+        !h->info_d || hipHostMalloc((void **)&h->chan_h, W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
+        set_error("[BatchCorrScores] create: device allocation failed");
+        dpe_bcs_destroy(h);
+        return -1;
+    }
+    DPE_CHECK_HIP(hipMemcpy(h->chipTable_d, table.data(), table.size(), hipMemcpyHostToDevice));
+    DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
+    DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
+    h->idxNext_h.assign(W * K, 0);
+    *out = h;
+    return 0;
+}
+
+int dpe_bcs_destroy(dpe_bcs *h)
+{
+    if (!h) return 0;
+    void *bufs[] = {h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->codeBank_d, h->carrBank_d, h->info_d};
+    for (void *b : bufs) (void)hipFree(b);
+    if (h->chan_h) (void)hipHostFree(h->chan_h);
+    delete h;
+    return 0;
+}
+
+int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples, int32_t nWindows,
+                   int32_t nChan, const dpe_chan_start *chan_host, dpe_stream_t stream_)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && samples_dev && chan_host, "[BatchCorrScores] Update: null argument");
+    DPE_REQUIRE(nWindows >= 1 && nWindows <= h->cfg.maxWindows, "[BatchCorrScores] Update: nWindows %d out of range", nWindows);
+    DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrScores] Update: nChan %d out of range", nChan);
+    const int S = h->cfg.samplesPerWindow;
+    DPE_REQUIRE(nWindows == 1 || windowStrideSamples >= S, "[BatchCorrScores] Update: window stride < S");
+    hipStream_t stream = (hipStream_t)stream_;
+    const double fs = h->cfg.samplingFrequency;
+    for (int i = 0; i < nWindows * nChan; ++i) {
+        const dpe_chan_start &c = chan_host[i];
+        DPE_REQUIRE(c.prn >= 1 && c.prn <= kPrnMax, "[BatchCorrScores] Update: PRN %d out of range", c.prn);
+        DPE_REQUIRE(c.codeFrequency > 0 && c.codePhaseStart >= 0, "[BatchCorrScores] Update: bad code phase/frequency");
+        BcsChanDev &d = h->chan_h[i];
+        d.rc = c.codePhaseStart;
+        d.codeStep = c.codeFrequency / fs;
+        d.ri = c.carrierPhaseStart;
+        d.carrStep = c.carrierFrequency / fs;
+        const double ang = -6.283185307179586476925286766559 * d.carrStep;
+        d.rotRe = (float)std::cos(ang);
+        d.rotIm = (float)std::sin(ang);
+        // BCS_NavBitBoundary, batchcorrscores.cu:247-253
+        const int since = (((c.cpElapsedStart - c.cpReference) % 20) + 20) % 20;
+        d.idxNext = (int)(std::floor((kLCA * (20 - since) - c.codePhaseStart) * (fs / c.codeFrequency)) + 1);
+        d.hasFlip = (d.idxNext > 0 && d.idxNext < S) ? 1 : 0;
+        d.prn = c.prn;
+        d.pad = 0;
+        h->idxNext_h[i] = d.idxNext;
+    }
+    h->lastW = nWindows;
+    h->lastK = nChan;
+    DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+    DPE_CHECK_HIP(hipMemsetAsync(h->sums_d, 0, sizeof(long long) * 2 * nWindows, stream));
+    const int sumBlocks = (S / 256 / 8 > 0) ? (S / 256 / 8 > 64 ? 64 : S / 256 / 8) : 1;
+    hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
+                       (long long)windowStrideSamples, S, h->sums_d);
+    const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
+    const dim3 grid(h->nBlk, nChan, nWindows), block(256);
+#define DPE_LAUNCH_BANK(LHV)                                                                                     \
+    hipLaunchKernelGGL(bcs_bank_kernel<LHV>, grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
+                       S, nChan, h->nSub, h->tilesPerBlock, h->nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, \
+                       h->part_d, h->mom_d)
+    switch (h->LH) {
+        case 4: DPE_LAUNCH_BANK(4); break;
+        case 8: DPE_LAUNCH_BANK(8); break;
+        case 16: DPE_LAUNCH_BANK(16); break;
+        default: DPE_LAUNCH_BANK(32); break;
+    }
+#undef DPE_LAUNCH_BANK
+    const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 63) / 64;
+    hipLaunchKernelGGL(bcs_finalize_kernel, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
+                       h->nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
+                       h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
+    DPE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int dpe_bcs_outputs(dpe_bcs *h, const float **codeBank_dev, const float **carrBank_dev, int32_t *nLag, int32_t *nBin,
+                    int64_t *numFFTPoints)
+{
+    DPE_REQUIRE(h, "[BatchCorrScores] outputs: null handle");
+    if (codeBank_dev) *codeBank_dev = reinterpret_cast<const float *>(h->codeBank_d);
+    if (carrBank_dev) *carrBank_dev = reinterpret_cast<const float *>(h->carrBank_d);
+    if (nLag) *nLag = 2 * h->cfg.lagHalfWidth + 1;
+    if (nBin) *nBin = 2 * h->cfg.binHalfWidth + 1;
+    if (numFFTPoints) *numFFTPoints = h->C;
+    return 0;
+}
+
+int dpe_bcs_read_info(dpe_bcs *h, int32_t *idxNext, int32_t *noFlipLarger, double *mean, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h && h->lastW > 0, "[BatchCorrScores] read_info: no update yet");
+    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    const int n = h->lastW * h->lastK;
+    if (idxNext) memcpy(idxNext, h->idxNext_h.data(), sizeof(int32_t) * n);
+    if (noFlipLarger) DPE_CHECK_HIP(hipMemcpy(noFlipLarger, h->info_d, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (mean) {
+        std::vector<long long> s(2 * h->lastW);
+        DPE_CHECK_HIP(hipMemcpy(s.data(), h->sums_d, sizeof(long long) * 2 * h->lastW, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 2 * h->lastW; ++i) mean[i] = (double)s[i] / (double)(float)h->cfg.samplesPerWindow;
+    }
+    return 0;
+}
+
+int dpe_bcs_export_dense(dpe_bcs *h, int32_t window, double *codeScores_dev, double *carrScores_dev, dpe_stream_t stream_)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && window >= 0 && window < h->lastW, "[BatchCorrScores] export_dense: bad window");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int K = h->lastK, maxK = h->cfg.maxChannels, S = h->cfg.samplesPerWindow;
+    const int nLag = 2 * h->cfg.lagHalfWidth + 1, nBin = 2 * h->cfg.binHalfWidth + 1;
+    if (codeScores_dev) {
+        DPE_CHECK_HIP(hipMemsetAsync(codeScores_dev, 0, sizeof(double2) * (size_t)K * S, stream));
+        hipLaunchKernelGGL(bcs_export_kernel, dim3(1, K), dim3(256), 0, stream,
+                           h->codeBank_d + (size_t)window * maxK * nLag, nLag, (long long)S, (long long)(S / 2), K, maxK,
+                           h->cfg.lagHalfWidth, reinterpret_cast<double2 *>(codeScores_dev));
+    }
+    if (carrScores_dev) {
+        DPE_CHECK_HIP(hipMemsetAsync(carrScores_dev, 0, sizeof(double2) * (size_t)K * h->C, stream));
+        hipLaunchKernelGGL(bcs_export_kernel, dim3(1, K), dim3(256), 0, stream,
+                           h->carrBank_d + (size_t)window * maxK * nBin, nBin, h->C, h->C / 2, K, maxK,
+                           h->cfg.binHalfWidth, reinterpret_cast<double2 *>(carrScores_dev));
+    }
+    DPE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+"""ctypes host layer over the C-ABI (include/dpe_hip.h).
+
+Mirrors the reference's operator interface for the hot path -- BatchCorrScores.Start/Update/
+Stop and BatchCorrManifold.Start/Update/Stop (cudarecv/modules/src/batchcorrscores.cu:710-1208,
+batchcorrmanifold.cu:2315-2635) -- with the reference's port names as keyword arguments.
+There is NO CPU fallback: if libdpe_hip.so is missing or no GPU is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpe_hip.so")
+_lib = None
+
+EXPORTS = [
+    "dpe_abi_version", "dpe_last_error", "dpe_device_info", "dpe_gen_ca_code", "dpe_sampleblock_upload",
+    "dpe_host_alloc_pinned", "dpe_host_free_pinned", "dpe_device_alloc", "dpe_device_free", "dpe_memcpy_h2d",
+    "dpe_memcpy_d2h", "dpe_stream_create", "dpe_stream_destroy", "dpe_stream_synchronize",
+    "dpe_bcs_create", "dpe_bcs_destroy", "dpe_bcs_update", "dpe_bcs_outputs", "dpe_bcs_read_info",
+    "dpe_bcs_export_dense", "dpe_bcm_create", "dpe_bcm_destroy", "dpe_bcm_update", "dpe_bcm_results",
+    "dpe_bcm_scores", "dpe_bcm_keys", "dpe_bcm_results_from_keys", "dpe_event_create", "dpe_event_record",
+    "dpe_event_elapsed_ms", "dpe_event_destroy",
+]
+
+
+class DpeError(RuntimeError):
+    pass
+
+
+class BcsConfig(C.Structure):
+    _fields_ = [("samplesPerWindow", C.c_int32), ("lagHalfWidth", C.c_int32), ("binHalfWidth", C.c_int32),
+                ("maxWindows", C.c_int32), ("maxChannels", C.c_int32), ("reserved", C.c_int32),
+                ("samplingFrequency", C.c_double)]
+
+
+class ChanStart(C.Structure):
+    _fields_ = [("codePhaseStart", C.c_double), ("carrierPhaseStart", C.c_double), ("codeFrequency", C.c_double),
+                ("carrierFrequency", C.c_double), ("cpElapsedStart", C.c_int32), ("cpReference", C.c_int32),
+                ("prn", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BcmConfig(C.Structure):
+    _fields_ = [("samplesPerWindow", C.c_int32), ("lagHalfWidth", C.c_int32), ("binHalfWidth", C.c_int32),
+                ("lPower", C.c_int32), ("maxWindows", C.c_int32), ("maxChannels", C.c_int32),
+                ("numFFTPoints", C.c_int64), ("samplingFrequency", C.c_double),
+                ("posGrid", C.POINTER(C.c_double)), ("velGrid", C.POINTER(C.c_double)),
+                ("posGridSize", C.c_int64), ("velGridSize", C.c_int64),
+                ("posGridIndexOffset", C.c_int64), ("velGridIndexOffset", C.c_int64),
+                ("writeScores", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BcmWindow(C.Structure):
+    _fields_ = [("xCurrkk1", C.c_double * 8), ("enu2ecef", C.c_double * 9), ("rxTime", C.c_double),
+                ("dopplerSign", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ChanEnd(C.Structure):
+    _fields_ = [("satState", C.c_double * 8), ("codePhaseEnd", C.c_double), ("codeFrequency", C.c_double),
+                ("carrierFrequency", C.c_double), ("cpRefTOW", C.c_int32), ("cpElapsedEnd", C.c_int32),
+                ("cpRef", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BcmResult(C.Structure):
+    _fields_ = [("zVal", C.c_double * 8), ("posIndex", C.c_int64), ("velIndex", C.c_int64),
+                ("posScore", C.c_float), ("velScore", C.c_float), ("posOutOfWindow", C.c_int64),
+                ("velOutOfWindow", C.c_int64)]
+
+
+CHAN_START_DTYPE = np.dtype([("codePhaseStart", "<f8"), ("carrierPhaseStart", "<f8"), ("codeFrequency", "<f8"),
+                             ("carrierFrequency", "<f8"), ("cpElapsedStart", "<i4"), ("cpReference", "<i4"),
+                             ("prn", "<i4"), ("reserved", "<i4")])
+CHAN_END_DTYPE = np.dtype([("satState", "<f8", (8,)), ("codePhaseEnd", "<f8"), ("codeFrequency", "<f8"),
+                           ("carrierFrequency", "<f8"), ("cpRefTOW", "<i4"), ("cpElapsedEnd", "<i4"),
+                           ("cpRef", "<i4"), ("reserved", "<i4")])
+BCM_WINDOW_DTYPE = np.dtype([("xCurrkk1", "<f8", (8,)), ("enu2ecef", "<f8", (9,)), ("rxTime", "<f8"),
+                             ("dopplerSign", "<i4"), ("reserved", "<i4")])
+assert CHAN_START_DTYPE.itemsize == C.sizeof(ChanStart)
+assert CHAN_END_DTYPE.itemsize == C.sizeof(ChanEnd)
+assert BCM_WINDOW_DTYPE.itemsize == C.sizeof(BcmWindow)
+
+
+def lib():
+    """Load libdpe_hip.so (built in-tree by __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DpeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                           % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.dpe_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(_lib, name)  # AttributeError if the ABI is incomplete
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise DpeError(lib().dpe_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(x):
+    """torch tensor / int -> raw device pointer."""
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+def _stream(stream):
+    if stream is None:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+def carr_fft_len(S):
+    p = 1
+    while p < S:
+        p <<= 1
+    return 8 * p
+
+
+def gen_ca_code():
+    out = np.zeros((37, 1023), dtype=np.int8)
+    _check(lib().dpe_gen_ca_code(out.ctypes.data_as(C.POINTER(C.c_int8))))
+    return out
+
+
+def device_info():
+    name = C.create_string_buffer(128)
+    cu, mem = C.c_int(0), C.c_int64(0)
+    _check(lib().dpe_device_info(name, 128, C.byref(cu), C.byref(mem)))
+    return name.value.decode(), cu.value, mem.value
+
+
+def d2h(ptr, nbytes, dtype, stream=None):
+    out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+    _check(lib().dpe_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_int64(nbytes), _stream(stream)))
+    return out
+
+
+def chan_start_array(prn, rc, ri, fc, fi, cp_ela, cp_ref):
+    """Pack start-referenced channel params (arrays of shape [W,K] or [K]) for BatchCorrScores."""
+    rc = np.asarray(rc, dtype=np.float64)
+    a = np.zeros(rc.shape, dtype=CHAN_START_DTYPE)
+    a["codePhaseStart"], a["carrierPhaseStart"] = rc, ri
+    a["codeFrequency"], a["carrierFrequency"] = fc, fi
+    a["cpElapsedStart"], a["cpReference"], a["prn"] = cp_ela, cp_ref, prn
+    return a
+
+
+def chan_end_array(sat, rc_end, fc, fi, cp_ref_tow, cp_ela_end, cp_ref):
+    rc_end = np.asarray(rc_end, dtype=np.float64)
+    a = np.zeros(rc_end.shape, dtype=CHAN_END_DTYPE)
+    a["satState"] = sat
+    a["codePhaseEnd"], a["codeFrequency"], a["carrierFrequency"] = rc_end, fc, fi
+    a["cpRefTOW"], a["cpElapsedEnd"], a["cpRef"] = cp_ref_tow, cp_ela_end, cp_ref
+    return a
+
+
+def bcm_window_array(x_kk1, enu2ecef, rx_time, doppler_sign=1):
+    rx_time = np.atleast_1d(np.asarray(rx_time, dtype=np.float64))
+    a = np.zeros(rx_time.shape, dtype=BCM_WINDOW_DTYPE)
+    a["xCurrkk1"] = x_kk1
+    a["enu2ecef"] = np.asarray(enu2ecef).reshape(rx_time.shape + (9,))
+    a["rxTime"] = rx_time
+    a["dopplerSign"] = doppler_sign
+    return a
+
+
+class BatchCorrScores:
+    """Module "BatchCorrScores" (batchcorrscores.cu:674-700): Start/Update/Stop + output ports."""
+
+    def __init__(self, SamplingFrequency, SampleLength=None, samples_per_window=None, lag_half_width=8,
+                 bin_half_width=48, max_windows=1, max_channels=8):
+        S = int(samples_per_window) if samples_per_window is not None else int(round(SamplingFrequency * SampleLength))
+        self.S, self.fs = S, float(SamplingFrequency)
+        self.L, self.B = int(lag_half_width), int(bin_half_width)
+        self.max_windows, self.max_channels = int(max_windows), int(max_channels)
+        self._h = C.c_void_p(None)
+        self.Started = False
+
+    def Start(self):
+        if self.Started:
+            return 0
+        cfg = BcsConfig(self.S, self.L, self.B, self.max_windows, self.max_channels, 0, self.fs)
+        _check(lib().dpe_bcs_create(C.byref(cfg), C.byref(self._h)))
+        code, carr = C.c_void_p(), C.c_void_p()
+        nlag, nbin, nfft = C.c_int32(), C.c_int32(), C.c_int64()
+        _check(lib().dpe_bcs_outputs(self._h, C.byref(code), C.byref(carr), C.byref(nlag), C.byref(nbin), C.byref(nfft)))
+        self.CodeScores, self.CarrScores = code.value, carr.value     # device pointers (float2 banks)
+        self.nLag, self.nBin, self.NumFFTPoints = nlag.value, nbin.value, nfft.value
+        self.Started = True
+        self._W = self._K = 0
+        return 0
+
+    def Update(self, Samples, chan, window_stride=None, stream=None):
+        """Samples: device int16 [W, 2*S] (torch tensor or raw pointer); chan: CHAN_START_DTYPE [W,K]."""
+        if not self.Started:
+            raise DpeError("[BatchCorrScores] Error: Update() Failed due to batch correlator not initialized")
+        chan = np.ascontiguousarray(chan)
+        if chan.ndim == 1:
+            chan = chan[None, :]
+        W, K = chan.shape
+        stride = self.S if window_stride is None else int(window_stride)
+        _check(lib().dpe_bcs_update(self._h, _ptr(Samples), C.c_int64(stride), C.c_int32(W), C.c_int32(K),
+                                    chan.ctypes.data_as(C.POINTER(ChanStart)), _stream(stream)))
+        self._W, self._K = W, K
+        return 0
+
+    def Stop(self):
+        if self.Started:
+            _check(lib().dpe_bcs_destroy(self._h))
+            self._h = C.c_void_p(None)
+            self.Started = False
+        return 0
+
+    __del__ = Stop
+
+    # ---- host-side readers (tests / diagnostics)
+    def read_banks(self, stream=None):
+        W, K = self._W, self._K
+        code = d2h(self.CodeScores, self.max_windows * self.max_channels * self.nLag * 8, np.complex64, stream)
+        carr = d2h(self.CarrScores, self.max_windows * self.max_channels * self.nBin * 8, np.complex64, stream)
+        code = code.reshape(self.max_windows, self.max_channels, self.nLag)[:W, :K]
+        carr = carr.reshape(self.max_windows, self.max_channels, self.nBin)[:W, :K]
+        return code, carr
+
+    def read_info(self, stream=None):
+        n = self._W * self._K
+        idx = np.zeros(n, dtype=np.int32)
+        nfl = np.zeros(n, dtype=np.int32)
+        mean = np.zeros(2 * self._W)
+        _check(lib().dpe_bcs_read_info(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       nfl.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       mean.ctypes.data_as(C.POINTER(C.c_double)), _stream(stream)))
+        return (idx.reshape(self._W, self._K), nfl.reshape(self._W, self._K).astype(bool),
+                mean.reshape(self._W, 2).view(np.complex128).ravel())
+
+    def export_dense(self, window, code_dev, carr_dev, stream=None):
+        _check(lib().dpe_bcs_export_dense(self._h, C.c_int32(window), _ptr(code_dev) if code_dev is not None else None,
+                                          _ptr(carr_dev) if carr_dev is not None else None, _stream(stream)))
+
+
+class BatchCorrManifold:
+    """Module "BatchCorrManifold" (batchcorrmanifold.cu:2247-2303): params PosGrid/VelGrid (host
+    [G,4] ENU offsets, i.e. the LoadPosGrid path :2422-2448 generalised to both manifolds), LPower."""
+
+    def __init__(self, SamplingFrequency, samples_per_window, NumFFTPoints, pos_grid, vel_grid, LPower=1,
+                 lag_half_width=8, bin_half_width=48, max_windows=1, max_channels=8, write_scores=True,
+                 pos_index_offset=0, vel_index_offset=0):
+        self.fs, self.S, self.C = float(SamplingFrequency), int(samples_per_window), int(NumFFTPoints)
+        self.pos_grid = np.ascontiguousarray(pos_grid, dtype=np.float64)
+        self.vel_grid = np.ascontiguousarray(vel_grid, dtype=np.float64)
+        self.LPower, self.L, self.B = int(LPower), int(lag_half_width), int(bin_half_width)
+        self.max_windows, self.max_channels = int(max_windows), int(max_channels)
+        self.write_scores = bool(write_scores)
+        self.pos_off, self.vel_off = int(pos_index_offset), int(vel_index_offset)
+        self._h = C.c_void_p(None)
+        self.Started = False
+
+    def Start(self):
+        if self.Started:
+            return 0
+        cfg = BcmConfig(self.S, self.L, self.B, self.LPower, self.max_windows, self.max_channels, self.C, self.fs,
+                        self.pos_grid.ctypes.data_as(C.POINTER(C.c_double)),
+                        self.vel_grid.ctypes.data_as(C.POINTER(C.c_double)),
+                        self.pos_grid.shape[0], self.vel_grid.shape[0], self.pos_off, self.vel_off,
+                        1 if self.write_scores else 0, 0)
+        _check(lib().dpe_bcm_create(C.byref(cfg), C.byref(self._h)))
+        self.PosScores = self.VelScores = None
+        if self.write_scores:
+            ps, vs = C.c_void_p(), C.c_void_p()
+            _check(lib().dpe_bcm_scores(self._h, C.byref(ps), C.byref(vs)))
+            self.PosScores, self.VelScores = ps.value, vs.value
+        keys = C.c_void_p()
+        _check(lib().dpe_bcm_keys(self._h, C.byref(keys)))
+        self.Keys = keys.value
+        self.Started = True
+        self._W = 0
+        return 0
+
+    def Update(self, CodeScores, CarrScores, win, chan, stream=None):
+        """win: BCM_WINDOW_DTYPE [W]; chan: CHAN_END_DTYPE [W,K]; banks: device pointers from BCS."""
+        if not self.Started:
+            raise DpeError("[BatchCorrManifold] Error: Update() Failed due to module not initialized")
+        win = np.ascontiguousarray(np.atleast_1d(win))
+        chan = np.ascontiguousarray(chan)
+        if chan.ndim == 1:
+            chan = chan[None, :]
+        W, K = chan.shape
+        assert win.shape[0] == W
+        _check(lib().dpe_bcm_update(self._h, _ptr(CodeScores), _ptr(CarrScores), C.c_int32(W), C.c_int32(K),
+                                    win.ctypes.data_as(C.POINTER(BcmWindow)),
+                                    chan.ctypes.data_as(C.POINTER(ChanEnd)), _stream(stream)))
+        self._W = W
+        return 0
+
+    def results(self, stream=None):
+        res = (BcmResult * self._W)()
+        _check(lib().dpe_bcm_results(self._h, res, _stream(stream)))
+        return [dict(zVal=np.array(r.zVal), RVal=np.eye(8), posIndex=r.posIndex, velIndex=r.velIndex,
+                     posScore=r.posScore, velScore=r.velScore, posOutOfWindow=r.posOutOfWindow,
+                     velOutOfWindow=r.velOutOfWindow) for r in res]
+
+    def results_from_keys(self, keys_host, pos_grid_global, vel_grid_global):
+        keys_host = np.ascontiguousarray(keys_host, dtype=np.uint64)
+        W = keys_host.shape[0]
+        pg = np.ascontiguousarray(pos_grid_global, dtype=np.float64)
+        vg = np.ascontiguousarray(vel_grid_global, dtype=np.float64)
+        res = (BcmResult * W)()
+        _check(lib().dpe_bcm_results_from_keys(self._h, keys_host.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(W),
+                                               pg.ctypes.data_as(C.POINTER(C.c_double)),
+                                               vg.ctypes.data_as(C.POINTER(C.c_double)), res))
+        return [dict(zVal=np.array(r.zVal), posIndex=r.posIndex, velIndex=r.velIndex, posScore=r.posScore,
+                     velScore=r.velScore) for r in res]
+
+    def read_scores(self, stream=None):
+        Gp, Gv = self.pos_grid.shape[0], self.vel_grid.shape[0]
+        ps = d2h(self.PosScores, self._W * Gp * 4, np.float32, stream).reshape(self._W, Gp)
+        vs = d2h(self.VelScores, self._W * Gv * 4, np.float32, stream).reshape(self._W, Gv)
+        return ps, vs
+
+    def Stop(self):
+        if self.Started:
+            _check(lib().dpe_bcm_destroy(self._h))
+            self._h = C.c_void_p(None)
+            self.Started = False
+        return 0
+
+    __del__ = Stop
+
+
+class HipEventTimer:
+    """HIP events recorded on the stream the kernels are launched on (bench.py roofline leg)."""
+
+    def __init__(self):
+        self.a, self.b = C.c_void_p(), C.c_void_p()
+        _check(lib().dpe_event_create(C.byref(self.a)))
+        _check(lib().dpe_event_create(C.byref(self.b)))
+
+    def start(self, stream=None):
+        _check(lib().dpe_event_record(self.a, _stream(stream)))
+
+    def stop(self, stream=None):
+        _check(lib().dpe_event_record(self.b, _stream(stream)))
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        _check(lib().dpe_event_elapsed_ms(self.a, self.b, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,162 @@
+"""Shared test/bench-checker helpers: build seeded cases, run the oracle (CPU) and the HIP path
+(through the C-ABI) on the same inputs, compare.  Uses oracle/ -- test infrastructure only."""
+import os
+
+import numpy as np
+
+import navlab_dpe_sdr_amd as dpe
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HANDOFF = os.path.join(HERE, "golden", "handoff_params_usrp6.csv")
+
+
+def _oracle():
+    from oracle import oracle as o
+    return o
+
+
+def make_case(seed=0, fs=2.5e6, S=50000, K=8, G=4096, amp=200.0, W=1, grid="rand", vel_G=None,
+              center_offset=None, flips=None):
+    """W consecutive windows on the handoff geometry (static receiver), channel state advanced by
+    the oracle's cuChanMgr restatement; I/Q synthesised from each window's start-referenced params."""
+    o = _oracle()
+    ho = dpe.handoff.read_handoff(HANDOFF)
+    assert K <= 8
+    T = S / fs
+    X = ho["X_ECEF"].copy()
+    sl = slice(0, K)
+    cm = o.ChanMgr(ho["prn_list"][sl], ho["rc"][sl], ho["ri"][sl], ho["fc"][sl], ho["fi"][sl], ho["cp"][sl],
+                   ho["cp_timestamp"][sl], ho["TOW"][sl], ho["eph"][sl], ho["rxTime"], T)
+    if grid == "rand":
+        pos = dpe.synth.rand_grid(seed + 100, G)
+        vel = dpe.synth.rand_grid(seed + 200, vel_G or G, half=(6.0, 6.0, 6.0, 3.0))
+    elif grid == "uniform":
+        dim = int(round(G ** 0.25))
+        pos = dpe.synth.uniform_grid(dim, 1.0)
+        vel = dpe.synth.uniform_grid(dim, 1.0)
+    elif grid == "spread":
+        pos, vel = dpe.synth.spread_grid()
+    else:
+        raise ValueError(grid)
+    tg = np.zeros(1)
+    centre = X.copy()
+    if center_offset is not None:
+        R0 = o.enu2ecef(o.ecef2ll(X)).reshape(3, 3)
+        centre[:3] += R0 @ np.asarray(center_offset[:3], dtype=np.float64)
+        centre[3] += center_offset[3]
+    wins = []
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for w in range(W):
+        batch, R = (cm.start(X, centre, tg) if w == 0 else cm.update(X, centre, tg))
+        start = dict(prn=cm.prns, rc=cm.rcStart.copy(), ri=cm.riStart.copy(), fc=cm.fc.copy(), fi=cm.fi.copy(),
+                     cp=cm.cpElaStart.copy(), cp_ref=cm.cpRef.copy())
+        fl = rng.integers(0, 2, K).astype(bool) if flips is None else np.asarray(flips, dtype=bool)
+        iq = dpe.synth.gen_iq(seed * 1000 + w, fs, S, start, amp=amp, flip=fl)
+        wins.append(dict(iq=iq, start=start, sat=batch[:, 0].copy(), R=R.copy(), rxTime=cm.rxTime,
+                         rcEnd=cm.rcEnd.copy(), cpElaEnd=cm.cpElaEnd.copy(), cpRef=cm.cpRef.copy(),
+                         cpRefTOW=cm.cpRefTOW.copy(), fc=cm.fc.copy(), fi=cm.fi.copy(), centre=centre.copy(),
+                         flip=fl))
+    return dict(fs=fs, S=S, K=K, W=W, C=dpe.engine.carr_fft_len(S), pos=pos, vel=vel, wins=wins,
+                prn=np.asarray(cm.prns))
+
+
+def run_oracle(case, L, B, lpower=1, windows=None):
+    o = _oracle()
+    fs, S, K, C = case["fs"], case["S"], case["K"], case["C"]
+    out = dict(code=[], carr=[], pos=[], vel=[], res=[], info=[])
+    for wi, w in enumerate(case["wins"]):
+        if windows is not None and wi not in windows:
+            continue
+        code, carr, info = [], [], []
+        for k in range(K):
+            s = w["start"]
+            c, f, inf = o.bcs_sv(w["iq"], fs, int(s["prn"][k]), s["rc"][k], s["ri"][k], s["fc"][k], s["fi"][k],
+                                 int(s["cp"][k]), int(s["cp_ref"][k]), -L, L, -B, B, C)
+            code.append(c)
+            carr.append(f)
+            info.append(inf)
+        code, carr = np.stack(code), np.stack(carr)
+        sp, oobp = o.bcm_pos(w["sat"], code, S // 2 - L, w["centre"], case["pos"], w["R"], w["fc"], w["cpRefTOW"],
+                             w["cpElaEnd"], w["cpRef"], w["rcEnd"], w["rxTime"], fs, S, lpower)
+        sv, oobv = o.bcm_vel(w["sat"], carr, C // 2 - B, w["centre"], case["vel"], w["R"], w["fi"], w["rxTime"], fs,
+                             C, 1, lpower)
+        ip, iv = o.argmax_first(sp), o.argmax_first(sv)
+        z, _ = o.make_meas(ip, iv, w["centre"], case["pos"], case["vel"], w["R"])
+        out["code"].append(code)
+        out["carr"].append(carr)
+        out["pos"].append(sp)
+        out["vel"].append(sv)
+        out["info"].append(info)
+        out["res"].append(dict(posIndex=ip, velIndex=iv, zVal=z, posOutOfWindow=oobp, velOutOfWindow=oobv))
+    return out
+
+
+def pack_gpu_inputs(case):
+    """Numpy side of the C-ABI inputs for all windows of a case."""
+    wins = case["wins"]
+    cs = np.stack([dpe.engine.chan_start_array(w["start"]["prn"], w["start"]["rc"], w["start"]["ri"], w["start"]["fc"],
+                                               w["start"]["fi"], w["start"]["cp"], w["start"]["cp_ref"]) for w in wins])
+    ce = np.stack([dpe.engine.chan_end_array(w["sat"], w["rcEnd"], w["fc"], w["fi"], w["cpRefTOW"], w["cpElaEnd"],
+                                             w["cpRef"]) for w in wins])
+    bw = np.concatenate([dpe.engine.bcm_window_array(w["centre"][None, :], w["R"][None, :], [w["rxTime"]]) for w in wins])
+    iq = np.stack([w["iq"] for w in wins])
+    return iq, cs, ce, bw
+
+
+def run_gpu(case, L, B, lpower=1, write_scores=True):
+    import torch
+    iq, cs, ce, bw = pack_gpu_inputs(case)
+    W, K = cs.shape
+    dev = torch.device("cuda:0")
+    iq_d = torch.from_numpy(iq).to(dev)
+    bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=L, bin_half_width=B,
+                              max_windows=W, max_channels=K)
+    bcs.Start()
+    bcm = dpe.BatchCorrManifold(case["fs"], case["S"], bcs.NumFFTPoints, case["pos"], case["vel"], LPower=lpower,
+                                lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K,
+                                write_scores=write_scores)
+    bcm.Start()
+    bcs.Update(iq_d, cs)
+    bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+    res = bcm.results()
+    code, carr = bcs.read_banks()
+    idx_next, no_flip, mean = bcs.read_info()
+    out = dict(code=list(code), carr=list(carr), res=res, idx_next=idx_next, no_flip=no_flip, mean=mean)
+    if write_scores:
+        ps, vs = bcm.read_scores()
+        out["pos"], out["vel"] = list(ps), list(vs)
+    bcm.Stop()
+    bcs.Stop()
+    return out
+
+
+def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
+    """fp32 HIP path vs fp64 oracle.  Tolerances are relative to the peak magnitude / max score."""
+    n = len(ref["res"])
+    worst = dict(code=0.0, carr=0.0, pos=0.0, vel=0.0)
+    for w in range(n):
+        for name in ("code", "carr"):
+            r, g = ref[name][w], gpu[name][w]
+            err = np.abs(g - r).max() / np.abs(r).max()
+            worst[name] = max(worst[name], err)
+            assert err < tol, "%s bank window %d: rel err %.3g" % (name, w, err)
+        for k, inf in enumerate(ref["info"][w]):
+            assert gpu["idx_next"][w, k] == inf["idx_next"]
+            assert bool(gpu["no_flip"][w, k]) == inf["no_flip_larger"]
+        rm = ref["info"][w][0]["mean"]
+        assert gpu["mean"][w] == rm, "DC mean must be bit-exact (integer sums)"
+        if check_scores:
+            for name in ("pos", "vel"):
+                r, g = ref[name][w], gpu[name][w]
+                err = np.abs(g - r).max() / r.max()
+                worst[name] = max(worst[name], err)
+                assert err < tol, "%s scores window %d: rel err %.3g" % (name, w, err)
+        rr, gr = ref["res"][w], gpu["res"][w]
+        for name, key in (("pos", "posIndex"), ("vel", "velIndex")):
+            if gr[key] != rr[key]:   # only acceptable as an fp32 tie
+                r = ref[name][w]
+                assert abs(r[gr[key]] - r[rr[key]]) < tol * r.max(), "%s arg-max differs beyond tolerance" % name
+        if gr["posIndex"] == rr["posIndex"] and gr["velIndex"] == rr["velIndex"]:
+            assert np.abs(gr["zVal"] - rr["zVal"]).max() < 1e-6     # same grid point -> same fix
+        assert gr["posOutOfWindow"] == rr["posOutOfWindow"] and gr["velOutOfWindow"] == rr["velOutOfWindow"]
+    return worst
