@@ -179,6 +179,38 @@ int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWi
                               const double *posGridGlobal, const double *velGridGlobal,
                               dpe_bcm_result *results);
 
+/* ------------------------------------------------------------------ cuChanMgr ------ */
+/* Host-side (fp64) restatement of dsp::cuChanMgr (cuchanmgr.cu:1004-1268): owns the per-SV
+ * channel parameters, start- and end-referenced, the Kepler satellite states and the
+ * Earth-rotation-corrected batch states / ENU->ECEF matrix that feed BCS and BCM.
+ * (Reference: <<<1,64>>> kernels writing device arrays; K <= 37, so this runs on the host.) */
+typedef struct dpe_chanmgr dpe_chanmgr;
+#define DPE_EPH_N 21
+typedef struct dpe_chm_config {
+    int32_t nChan;
+    int32_t dopplerSign;        /* param "DopplerSign" (cuchanmgr.cu:959, dpeflow.cpp:88) */
+    double sampleLength;        /* T, input 11 */
+    double rxTime;              /* InitRXTime, input 9 */
+} dpe_chm_config;
+/* Handoff state of one SV (inputs 1-8, dpeflow.cpp:144-153) + its broadcast ephemeris in the
+ * order sqrt_A,e,i_0,OMEGA_0,omega,M_0,delta_n,OMEGADOT,IDOT,C_rc,C_rs,C_uc,C_us,C_ic,C_is,
+ * t_oe,t_oc,a_f0,a_f1,a_f2,T_GD (handoff_params_usrp6.csv rows 13-40). */
+typedef struct dpe_chm_init_chan {
+    int32_t prn, cpElapsed, cpReference, cpRefTOW;
+    double codePhase, carrierPhase, codeFrequency, carrierFrequency;
+    double eph[DPE_EPH_N];
+} dpe_chm_init_chan;
+int dpe_chm_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans, dpe_chanmgr **out);
+int dpe_chm_destroy(dpe_chanmgr *h);
+/* cuChanMgr::Start :1100-1132 / ::Update :1237-1264.  xk1k1: state the channels are propagated
+ * from (input 10); xkk1: grid centre (input 12); timeGrid: BCM's TimeGrid port (input 13). */
+int dpe_chm_start(dpe_chanmgr *h, const double *xk1k1, const double *xkk1, const double *timeGrid, int32_t dimT);
+int dpe_chm_update(dpe_chanmgr *h, const double *xk1k1, const double *xkk1, const double *timeGrid, int32_t dimT);
+/* Output ports in the form BCS/BCM take (any pointer may be NULL): start[K], end[K] (with the
+ * mid-time batch satellite state), win, and the full SatStates batch [K][dimT][8]. */
+int dpe_chm_outputs(dpe_chanmgr *h, dpe_chan_start *start, dpe_chan_end *end, dpe_bcm_window *win,
+                    double *batchSatStates);
+
 /* Timing helper for bench.py: HIP events on the stream the kernels run on. */
 int dpe_event_create(void **ev);
 int dpe_event_record(void *ev, dpe_stream_t stream);

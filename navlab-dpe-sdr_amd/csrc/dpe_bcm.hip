@@ -255,12 +255,14 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
             const double ue = R[0] * ux + R[3] * uy + R[6] * uz;                        // R^T u
             const double un = R[1] * ux + R[4] * uy + R[7] * uz;
             const double uu = R[2] * ux + R[5] * uy + R[8] * uz;
-            // position manifold, centre index (:1783-1791)
-            const double pr = range - kC * s[3] + c[3];
-            const double txT = win.rxTime - pr / kC;
-            const double cfd = txT - ch.cpRefTOW - ((ch.cpElapsedEnd - ch.cpRef) * kTCA);
-            const double rc0 = cfd * kFCA - ch.codePhaseEnd;
-            const double basePos = (fs / ch.codeFrequency) * (-rc0) + S / 2.0;
+            // position manifold, centre index (:1783-1791).  Carried in long double: the reference's
+            // fp64 "rxTime - pr/C" (rxTime ~4e5 s) rounds at 5.8e-11 s = 1.4e-4 samples PER POINT; the
+            // expansion below is exact about the centre, so the centre itself is kept exact too.
+            const long double pr = (long double)range - (long double)kC * s[3] + c[3];
+            const long double txT = (long double)win.rxTime - pr / (long double)kC;
+            const long double cfd = txT - ch.cpRefTOW - ((long double)(ch.cpElapsedEnd - ch.cpRef) * (long double)kTCA);
+            const long double rc0 = cfd * (long double)kFCA - ch.codePhaseEnd;
+            const double basePos = (double)(((long double)fs / ch.codeFrequency) * (-rc0) + S / 2.0L);
             BcmSvDev &p = h->sv_h[(size_t)(0 * W + w) * maxK + k];
             p.ue = (float)ue; p.un = (float)un; p.uu = (float)uu;
             p.g = (float)(fs * kFCA / (ch.codeFrequency * kC));

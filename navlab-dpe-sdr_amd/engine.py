@@ -21,7 +21,8 @@ EXPORTS = [
     "dpe_bcs_create", "dpe_bcs_destroy", "dpe_bcs_update", "dpe_bcs_outputs", "dpe_bcs_read_info",
     "dpe_bcs_export_dense", "dpe_bcm_create", "dpe_bcm_destroy", "dpe_bcm_update", "dpe_bcm_results",
     "dpe_bcm_scores", "dpe_bcm_keys", "dpe_bcm_results_from_keys", "dpe_event_create", "dpe_event_record",
-    "dpe_event_elapsed_ms", "dpe_event_destroy",
+    "dpe_event_elapsed_ms", "dpe_event_destroy", "dpe_chm_create", "dpe_chm_destroy", "dpe_chm_start",
+    "dpe_chm_update", "dpe_chm_outputs",
 ]
 
 
@@ -329,6 +330,71 @@ class BatchCorrManifold:
             _check(lib().dpe_bcm_destroy(self._h))
             self._h = C.c_void_p(None)
             self.Started = False
+        return 0
+
+    __del__ = Stop
+
+
+class ChmConfig(C.Structure):
+    _fields_ = [("nChan", C.c_int32), ("dopplerSign", C.c_int32), ("sampleLength", C.c_double), ("rxTime", C.c_double)]
+
+
+CHM_INIT_DTYPE = np.dtype([("prn", "<i4"), ("cpElapsed", "<i4"), ("cpReference", "<i4"), ("cpRefTOW", "<i4"),
+                           ("codePhase", "<f8"), ("carrierPhase", "<f8"), ("codeFrequency", "<f8"),
+                           ("carrierFrequency", "<f8"), ("eph", "<f8", (21,))])
+
+
+class ChanMgr:
+    """Module "cuChanMgr" (cuchanmgr.cu:930-1268), host fp64.  Start()/Update() then outputs()
+    returns (chan_start[K], chan_end[K], bcm_window[1]) ready for BatchCorrScores / BatchCorrManifold."""
+
+    def __init__(self, prn, rc, ri, fc, fi, cp, cp_ref, cp_ref_tow, eph, rx_time, T, DopplerSign=1):
+        K = len(prn)
+        init = np.zeros(K, dtype=CHM_INIT_DTYPE)
+        init["prn"], init["cpElapsed"], init["cpReference"], init["cpRefTOW"] = prn, cp, cp_ref, cp_ref_tow
+        init["codePhase"], init["carrierPhase"], init["codeFrequency"], init["carrierFrequency"] = rc, ri, fc, fi
+        init["eph"] = eph
+        self.K = K
+        self._h = C.c_void_p(None)
+        cfg = ChmConfig(K, int(DopplerSign), float(T), float(rx_time))
+        _check(lib().dpe_chm_create(C.byref(cfg), init.ctypes.data_as(C.c_void_p), C.byref(self._h)))
+
+    @classmethod
+    def from_handoff(cls, ho, T, K=None):
+        sl = slice(0, K)
+        return cls(ho["prn_list"][sl], ho["rc"][sl], ho["ri"][sl], ho["fc"][sl], ho["fi"][sl], ho["cp"][sl],
+                   ho["cp_timestamp"][sl], ho["TOW"][sl], ho["eph"][sl], ho["rxTime"], T)
+
+    def _step(self, fn, x_k1k1, x_kk1, time_grid):
+        a = np.ascontiguousarray(x_k1k1, dtype=np.float64)
+        b = np.ascontiguousarray(x_kk1, dtype=np.float64)
+        tg = np.ascontiguousarray(time_grid, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _check(fn(self._h, a.ctypes.data_as(dp), b.ctypes.data_as(dp), tg.ctypes.data_as(dp), C.c_int32(tg.size)))
+        self._dimT = tg.size
+
+    def Start(self, x_k1k1, x_kk1, time_grid=(0.0,)):
+        self._step(lib().dpe_chm_start, x_k1k1, x_kk1, time_grid)
+        return 0
+
+    def Update(self, x_k1k1, x_kk1, time_grid=(0.0,)):
+        self._step(lib().dpe_chm_update, x_k1k1, x_kk1, time_grid)
+        return 0
+
+    def outputs(self, with_batch=False):
+        start = np.zeros(self.K, dtype=CHAN_START_DTYPE)
+        end = np.zeros(self.K, dtype=CHAN_END_DTYPE)
+        win = np.zeros(1, dtype=BCM_WINDOW_DTYPE)
+        batch = np.zeros((self.K, self._dimT, 8)) if with_batch else None
+        _check(lib().dpe_chm_outputs(self._h, start.ctypes.data_as(C.c_void_p), end.ctypes.data_as(C.c_void_p),
+                                     win.ctypes.data_as(C.c_void_p),
+                                     batch.ctypes.data_as(C.c_void_p) if with_batch else None))
+        return (start, end, win, batch) if with_batch else (start, end, win)
+
+    def Stop(self):
+        if self._h:
+            lib().dpe_chm_destroy(self._h)
+            self._h = C.c_void_p(None)
         return 0
 
     __del__ = Stop

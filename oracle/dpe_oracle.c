@@ -148,12 +148,35 @@ int dpo_bcs_sv(const int16_t *iq, int S, double fs, const int8_t *chips,
 }
 
 /* ---------------------------------------------------------------- BCM ------------ */
+/* Index of one (point, SV) pair in extended precision: same formula as :1779-1797, but carried
+ * in long double so that the reference's own fp64 cancellation (rxTime ~4e5 s minus pr/C rounds
+ * at ulp = 5.8e-11 s = 17 mm = 1.4e-4 samples) is removed.  Used only to MEASURE that noise. */
+static long double pos_base_ld(const double *s, const double *g, const double *c, const double *R,
+                               double rxTime, int tow, int dcp, double rcEnd, double fs, double fc,
+                               int numSamps)
+{
+    const long double px = (long double)R[0] * g[0] + (long double)R[1] * g[1] + (long double)R[2] * g[2] + c[0];
+    const long double py = (long double)R[3] * g[0] + (long double)R[4] * g[1] + (long double)R[5] * g[2] + c[1];
+    const long double pz = (long double)R[6] * g[0] + (long double)R[7] * g[1] + (long double)R[8] * g[2] + c[2];
+    const long double pdt = (long double)g[3] + c[3];
+    const long double lx = s[0] - px, ly = s[1] - py, lz = s[2] - pz;
+    const long double range = sqrtl(lx * lx + ly * ly + lz * lz);
+    const long double pr = range - (long double)DPO_C * s[3] + pdt;
+    const long double txT = (long double)rxTime - pr / (long double)DPO_C;
+    const long double cfd = txT - tow - ((long double)dcp * (long double)DPO_T_CA);
+    const long double rc0 = cfd * (long double)DPO_F_CA - rcEnd;
+    return ((long double)fs / fc) * (-rc0) + numSamps / 2.0L;
+}
+
 int dpo_bcm_pos(const double *sat, const double *codeWin, int winLo, int winLen,
                 const double *c, const double *grid, int64_t G, const double *R,
                 const double *codeFreq, const int *cpRefTOW, const int *cpElapsedEnd,
                 const int *cpRef, const double *codePhase, double rxTime, int K, double fs,
                 int numSamps, int LPower, double *scores, int64_t *oob)
 {
+    /* LPower < 0 selects the extended-precision index (|LPower| is the exponent) */
+    const int extended = LPower < 0;
+    if (extended) LPower = -LPower;
     int64_t nOob = 0;
     for (int64_t i = 0; i < G; i++) {
         const double *g = grid + 4 * i;
@@ -172,7 +195,13 @@ int dpo_bcm_pos(const double *sat, const double *codeWin, int winLo, int winLen,
             const double cfd = txT - cpRefTOW[k] - ((cpElapsedEnd[k] - cpRef[k]) * DPO_T_CA);
             const double rcbc = cfd * DPO_F_CA;                               /* :1786 */
             const double rc0 = rcbc - codePhase[k];                           /* :1790 */
-            const double base = (fs / codeFreq[k]) * (-rc0) + numSamps / 2.0; /* :1791 */
+            double base = (fs / codeFreq[k]) * (-rc0) + numSamps / 2.0;       /* :1791 */
+            long double baseLd = base;
+            if (extended) {
+                baseLd = pos_base_ld(s, g, c, R, rxTime, cpRefTOW[k], cpElapsedEnd[k] - cpRef[k],
+                                     codePhase[k], fs, codeFreq[k], numSamps);
+                base = (double)baseLd;
+            }
             if (!(base < numSamps && base > 0)) { nOob++; continue; }         /* :1795 */
             const double idx = base + ((double)numSamps * k);                 /* :1797 */
             const double fi_ = floor(idx), ci_ = floor(idx + 1);              /* :1798-1799 */
@@ -180,7 +209,8 @@ int dpo_bcm_pos(const double *sat, const double *codeWin, int winLo, int winLen,
             const int64_t cin = (int64_t)ci_ - (int64_t)numSamps * k - winLo;
             if (fin < 0 || cin < 0 || fin >= winLen || cin >= winLen) { nOob++; continue; }
             const double *row = codeWin + 2 * (int64_t)winLen * k;
-            const double wc = idx - fi_, wf = ci_ - idx;                      /* :1810-1811 */
+            double wc = idx - fi_, wf = ci_ - idx;                            /* :1810-1811 */
+            if (extended) { wc = (double)(baseLd - floorl(baseLd)); wf = 1.0 - wc; }
             const double vr = row[2 * cin] * wc + row[2 * fin] * wf;
             const double vi = row[2 * cin + 1] * wc + row[2 * fin + 1] * wf;
             score += pow(hypot(vr, vi), (double)LPower);                      /* :1816 */

@@ -76,6 +76,8 @@ int dpo_bcs_sv(const int16_t *iq, int S, double fs, const int8_t *chips,
  * codeScores[k*S ...]; an access outside the window (or outside (0,S), which the
  * reference leaves undefined, :1795-1804) contributes 0 and bumps *oob.
  * grid: G x 4 doubles (x,y,z,delta_t ENU offsets).  satStates: K x 8 (mid-time state).
+ * LPower < 0: evaluate the index in long double (exponent |LPower|) -- not the reference's
+ * arithmetic, only used to measure the reference's own fp64 cancellation noise.
  */
 int dpo_bcm_pos(const double *satStates, const double *codeWin, int winLo, int winLen,
                 const double *centerPt, const double *grid, int64_t G,

@@ -137,8 +137,11 @@ def bcs_sv_fft(iq, fs, prn, rc, ri, fc, fi, cp_ela, cp_ref, C_fft=None):
 
 
 def bcm_pos(sat, code_win, win_lo, center, grid, R, fc, cp_ref_tow, cp_ela_end, cp_ref, rc_end,
-            rx_time, fs, num_samps, lpower=1):
-    """BCM_PosMeasML.  sat: K x 8 mid-time states; code_win: K x winLen complex."""
+            rx_time, fs, num_samps, lpower=1, extended=False):
+    """BCM_PosMeasML.  sat: K x 8 mid-time states; code_win: K x winLen complex.
+    extended=True evaluates the index in long double (measures the reference's fp64 noise)."""
+    if extended:
+        lpower = -int(lpower)
     sat = np.ascontiguousarray(sat, dtype=np.float64)
     K = sat.shape[0]
     cw = np.ascontiguousarray(code_win, dtype=np.complex128)

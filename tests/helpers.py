@@ -63,7 +63,7 @@ def make_case(seed=0, fs=2.5e6, S=50000, K=8, G=4096, amp=200.0, W=1, grid="rand
 def run_oracle(case, L, B, lpower=1, windows=None):
     o = _oracle()
     fs, S, K, C = case["fs"], case["S"], case["K"], case["C"]
-    out = dict(code=[], carr=[], pos=[], vel=[], res=[], info=[])
+    out = dict(code=[], carr=[], pos=[], pos_x=[], vel=[], res=[], info=[])
     for wi, w in enumerate(case["wins"]):
         if windows is not None and wi not in windows:
             continue
@@ -78,6 +78,8 @@ def run_oracle(case, L, B, lpower=1, windows=None):
         code, carr = np.stack(code), np.stack(carr)
         sp, oobp = o.bcm_pos(w["sat"], code, S // 2 - L, w["centre"], case["pos"], w["R"], w["fc"], w["cpRefTOW"],
                              w["cpElaEnd"], w["cpRef"], w["rcEnd"], w["rxTime"], fs, S, lpower)
+        spx, _ = o.bcm_pos(w["sat"], code, S // 2 - L, w["centre"], case["pos"], w["R"], w["fc"], w["cpRefTOW"],
+                           w["cpElaEnd"], w["cpRef"], w["rcEnd"], w["rxTime"], fs, S, lpower, extended=True)
         sv, oobv = o.bcm_vel(w["sat"], carr, C // 2 - B, w["centre"], case["vel"], w["R"], w["fi"], w["rxTime"], fs,
                              C, 1, lpower)
         ip, iv = o.argmax_first(sp), o.argmax_first(sv)
@@ -85,6 +87,7 @@ def run_oracle(case, L, B, lpower=1, windows=None):
         out["code"].append(code)
         out["carr"].append(carr)
         out["pos"].append(sp)
+        out["pos_x"].append(spx)
         out["vel"].append(sv)
         out["info"].append(info)
         out["res"].append(dict(posIndex=ip, velIndex=iv, zVal=z, posOutOfWindow=oobp, velOutOfWindow=oobv))
@@ -130,8 +133,16 @@ def run_gpu(case, L, B, lpower=1, write_scores=True):
     return out
 
 
+POS_REF_NOISE = 1e-4
+
+
 def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
-    """fp32 HIP path vs fp64 oracle.  Tolerances are relative to the peak magnitude / max score."""
+    """fp32 HIP path vs fp64 oracle.  Tolerances are relative to the peak magnitude / max score.
+
+    Position-manifold scores are held to `tol` against the oracle's extended-precision index
+    (pos_x) and to POS_REF_NOISE against the faithful fp64 restatement: the reference's own
+    `rxTime - pr/C` (batchcorrmanifold.cu:1784, rxTime ~4e5 s) rounds at 5.8e-11 s = 17 mm =
+    1.4e-4 samples per (point, SV), i.e. ~3e-5 of the score -- measured, see DESIGN.md."""
     n = len(ref["res"])
     worst = dict(code=0.0, carr=0.0, pos=0.0, vel=0.0)
     for w in range(n):
@@ -146,16 +157,17 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
         rm = ref["info"][w][0]["mean"]
         assert gpu["mean"][w] == rm, "DC mean must be bit-exact (integer sums)"
         if check_scores:
-            for name in ("pos", "vel"):
-                r, g = ref[name][w], gpu[name][w]
+            for name, rname, lim in (("pos", "pos_x", tol), ("pos", "pos", POS_REF_NOISE), ("vel", "vel", tol)):
+                r, g = ref[rname][w], gpu[name][w]
                 err = np.abs(g - r).max() / r.max()
-                worst[name] = max(worst[name], err)
-                assert err < tol, "%s scores window %d: rel err %.3g" % (name, w, err)
+                worst[rname] = max(worst.get(rname, 0.0), err)
+                assert err < lim, "%s scores vs %s window %d: rel err %.3g" % (name, rname, w, err)
         rr, gr = ref["res"][w], gpu["res"][w]
         for name, key in (("pos", "posIndex"), ("vel", "velIndex")):
             if gr[key] != rr[key]:   # only acceptable as an fp32 tie
                 r = ref[name][w]
-                assert abs(r[gr[key]] - r[rr[key]]) < tol * r.max(), "%s arg-max differs beyond tolerance" % name
+                lim = POS_REF_NOISE if name == "pos" else tol
+                assert abs(r[gr[key]] - r[rr[key]]) < lim * r.max(), "%s arg-max differs beyond tolerance" % name
         if gr["posIndex"] == rr["posIndex"] and gr["velIndex"] == rr["velIndex"]:
             assert np.abs(gr["zVal"] - rr["zVal"]).max() < 1e-6     # same grid point -> same fix
         assert gr["posOutOfWindow"] == rr["posOutOfWindow"] and gr["velOutOfWindow"] == rr["velOutOfWindow"]

@@ -49,3 +49,34 @@ def test_no_cpu_fallback(built):
         bcs.Start()          # hipMalloc fails -> error, never a CPU path
     with pytest.raises(dpe.DpeError):
         bcs.Update(0, dpe.engine.chan_start_array([2], [0.0], [0.0], [1.023e6], [0.0], [0], [0]))
+
+
+def test_chanmgr_matches_oracle(built, oracle):
+    """Product cuChanMgr (host C++ in libdpe_hip.so) vs the oracle's independent restatement:
+    Start + 3 Updates on the handoff state, spread time grid."""
+    from tests import helpers
+    ho = dpe.handoff.read_handoff(helpers.HANDOFF)
+    T = 0.02
+    X = ho["X_ECEF"]
+    pos, _ = dpe.synth.spread_grid()
+    tg = np.unique(pos[:, 3])
+    cm = dpe.ChanMgr.from_handoff(ho, T)
+    om = oracle.ChanMgr(ho["prn_list"], ho["rc"], ho["ri"], ho["fc"], ho["fi"], ho["cp"], ho["cp_timestamp"],
+                        ho["TOW"], ho["eph"], ho["rxTime"], T)
+    for it in range(4):
+        xk = X + np.array([0.3, -0.2, 0.1, 0.5, 0.01, 0.0, -0.02, 0.003]) * it   # a moving fix
+        if it == 0:
+            cm.Start(xk, xk, tg)
+            ob, oR = om.start(xk, xk, tg)
+        else:
+            cm.Update(xk, xk, tg)
+            ob, oR = om.update(xk, xk, tg)
+        s, e, w, batch = cm.outputs(with_batch=True)
+        assert np.array_equal(s["codePhaseStart"], om.rcStart) and np.array_equal(s["cpElapsedStart"], om.cpElaStart)
+        assert np.abs(e["codePhaseEnd"] - om.rcEnd).max() < 1e-9 and np.array_equal(e["cpElapsedEnd"], om.cpElaEnd)
+        assert np.abs(s["carrierPhaseStart"] - om.riStart).max() < 1e-12
+        assert np.abs(s["codeFrequency"] - om.fc).max() < 1e-6 and np.abs(s["carrierFrequency"] - om.fi).max() < 1e-6
+        assert w["rxTime"][0] == om.rxTime
+        assert np.abs(batch - ob).max() < 1e-6 and np.abs(w["enu2ecef"][0] - oR).max() < 1e-14
+        assert np.abs(e["satState"] - ob[:, tg.size // 2]).max() < 1e-6
+    cm.Stop()
