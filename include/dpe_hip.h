@@ -211,6 +211,12 @@ int dpe_chm_update(dpe_chanmgr *h, const double *xk1k1, const double *xkk1, cons
 int dpe_chm_outputs(dpe_chanmgr *h, dpe_chan_start *start, dpe_chan_end *end, dpe_bcm_window *win,
                     double *batchSatStates);
 
+/* Per-kernel timing (HIP events recorded on the launch stream around each kernel).  Returns and
+ * resets the totals accumulated since the previous call, then sets the enable flag.
+ * BCS slots: 0 DC-sum, 1 bank, 2 finalize (ms[3], count[3]); BCM slots: 0 pos scan, 1 vel scan. */
+int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count);
+int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count);
+
 /* Timing helper for bench.py: HIP events on the stream the kernels run on. */
 int dpe_event_create(void **ev);
 int dpe_event_record(void *ev, dpe_stream_t stream);

@@ -128,6 +128,7 @@ struct dpe_bcm {
     unsigned long long *keys_d = nullptr, *oob_d = nullptr;  // [W][2]
     std::vector<dpe_bcm_window> win_h;
     int lastW = 0;
+    dpe::KernelProfiler prof;  // slots: 0 pos scan, 1 vel scan
 };
 
 static int upload_grid(const double *src, int64_t G, std::vector<double> &keep, float4 **dst)
@@ -293,17 +294,21 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         const long long G = h->cfg.posGridSize;
         const dim3 grid((unsigned)((G + kPtsPerBlock - 1) / kPtsPerBlock), nWindows);
         const size_t lds = (size_t)nChan * nLag * sizeof(float4) + (size_t)nChan * sizeof(BcmSvDev);
+        h->prof.begin(0, stream);
         launch_scan<true>(h->cfg.lPower, grid, lds, stream, h->posGrid_d, G, nChan, nLag, maxK, h->sv_d,
                           reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, h->keys_d, h->oob_d,
                           h->cfg.posGridIndexOffset, 0);
+        h->prof.end(0, stream);
     }
     {
         const long long G = h->cfg.velGridSize;
         const dim3 grid((unsigned)((G + kPtsPerBlock - 1) / kPtsPerBlock), nWindows);
         const size_t lds = (size_t)nChan * nBin * sizeof(float4) + (size_t)nChan * sizeof(BcmSvDev);
+        h->prof.begin(1, stream);
         launch_scan<false>(h->cfg.lPower, grid, lds, stream, h->velGrid_d, G, nChan, nBin, maxK,
                            h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev), h->velScores_d,
                            h->keys_d, h->oob_d, h->cfg.velGridIndexOffset, 1);
+        h->prof.end(1, stream);
     }
     DPE_CHECK_HIP(hipGetLastError());
     return 0;
@@ -348,6 +353,20 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
                     "[BatchCorrManifold] results: arg-max index outside the local shard");
         make_meas(h->win_h[w], h->posGrid_h.data() + 4 * pl, h->velGrid_h.data() + 4 * vl, r.zVal);
     }
+    return 0;
+}
+
+int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count)
+{
+    DPE_REQUIRE(h, "[BatchCorrManifold] profile: null handle");
+    float m[dpe::KernelProfiler::kSlots];
+    int c[dpe::KernelProfiler::kSlots];
+    h->prof.collect(m, c);
+    for (int i = 0; i < 2; ++i) {
+        if (ms) ms[i] = m[i];
+        if (count) count[i] = c[i];
+    }
+    h->prof.enabled = enable != 0;
     return 0;
 }
 

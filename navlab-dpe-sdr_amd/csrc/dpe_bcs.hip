@@ -323,6 +323,7 @@ struct dpe_bcs {
     int *info_d = nullptr;
     int lastW = 0, lastK = 0;
     std::vector<int32_t> idxNext_h;
+    dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
 };
 
 static long long next_pow2(long long x)
@@ -439,14 +440,17 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
     DPE_CHECK_HIP(hipMemsetAsync(h->sums_d, 0, sizeof(long long) * 2 * nWindows, stream));
     const int sumBlocks = (S / 256 / 8 > 0) ? (S / 256 / 8 > 64 ? 64 : S / 256 / 8) : 1;
+    h->prof.begin(0, stream);
     hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
                        (long long)windowStrideSamples, S, h->sums_d);
+    h->prof.end(0, stream);
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     const dim3 grid(h->nBlk, nChan, nWindows), block(256);
 #define DPE_LAUNCH_BANK(LHV)                                                                                     \
     hipLaunchKernelGGL(bcs_bank_kernel<LHV>, grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, h->tilesPerBlock, h->nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, \
                        h->part_d, h->mom_d)
+    h->prof.begin(1, stream);
     switch (h->LH) {
         case 4: DPE_LAUNCH_BANK(4); break;
         case 8: DPE_LAUNCH_BANK(8); break;
@@ -454,10 +458,13 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         default: DPE_LAUNCH_BANK(32); break;
     }
 #undef DPE_LAUNCH_BANK
+    h->prof.end(1, stream);
+    h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 63) / 64;
     hipLaunchKernelGGL(bcs_finalize_kernel, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
                        h->nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
                        h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
+    h->prof.end(2, stream);
     DPE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -471,6 +478,20 @@ int dpe_bcs_outputs(dpe_bcs *h, const float **codeBank_dev, const float **carrBa
     if (nLag) *nLag = 2 * h->cfg.lagHalfWidth + 1;
     if (nBin) *nBin = 2 * h->cfg.binHalfWidth + 1;
     if (numFFTPoints) *numFFTPoints = h->C;
+    return 0;
+}
+
+int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count)
+{
+    DPE_REQUIRE(h, "[BatchCorrScores] profile: null handle");
+    float m[dpe::KernelProfiler::kSlots];
+    int c[dpe::KernelProfiler::kSlots];
+    h->prof.collect(m, c);
+    for (int i = 0; i < 3; ++i) {
+        if (ms) ms[i] = m[i];
+        if (count) count[i] = c[i];
+    }
+    h->prof.enabled = enable != 0;
     return 0;
 }
 

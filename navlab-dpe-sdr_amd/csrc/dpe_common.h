@@ -53,6 +53,43 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
+struct KernelProfiler {
+    bool enabled = false;
+    static constexpr int kSlots = 8;
+    std::vector<hipEvent_t> ev[kSlots];   // pairs: start, stop
+    void begin(int slot, hipStream_t st)
+    {
+        if (!enabled) return;
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        ev[slot].push_back(a);
+        ev[slot].push_back(b);
+        (void)hipEventRecord(a, st);
+    }
+    void end(int slot, hipStream_t st)
+    {
+        if (!enabled || ev[slot].empty()) return;
+        (void)hipEventRecord(ev[slot].back(), st);
+    }
+    // total milliseconds and launch count per slot since the last call; frees the events
+    void collect(float *ms, int *count)
+    {
+        for (int s = 0; s < kSlots; ++s) {
+            ms[s] = 0.f;
+            count[s] = (int)ev[s].size() / 2;
+            for (size_t i = 0; i + 1 < ev[s].size(); i += 2) {
+                float t = 0.f;
+                (void)hipEventSynchronize(ev[s][i + 1]);
+                if (hipEventElapsedTime(&t, ev[s][i], ev[s][i + 1]) == hipSuccess) ms[s] += t;
+                (void)hipEventDestroy(ev[s][i]);
+                (void)hipEventDestroy(ev[s][i + 1]);
+            }
+            ev[s].clear();
+        }
+    }
+};
+
 template <typename T>
 static inline T *dev_alloc(size_t n)
 {

@@ -22,7 +22,7 @@ EXPORTS = [
     "dpe_bcs_export_dense", "dpe_bcm_create", "dpe_bcm_destroy", "dpe_bcm_update", "dpe_bcm_results",
     "dpe_bcm_scores", "dpe_bcm_keys", "dpe_bcm_results_from_keys", "dpe_event_create", "dpe_event_record",
     "dpe_event_elapsed_ms", "dpe_event_destroy", "dpe_chm_create", "dpe_chm_destroy", "dpe_chm_start",
-    "dpe_chm_update", "dpe_chm_outputs",
+    "dpe_chm_update", "dpe_chm_outputs", "dpe_bcs_profile", "dpe_bcm_profile",
 ]
 
 
@@ -212,6 +212,12 @@ class BatchCorrScores:
         self._W, self._K = W, K
         return 0
 
+    def profile(self, enable=True):
+        """-> {kernel: (total_ms, launches)} since the previous call; sets the enable flag."""
+        ms, cnt = (C.c_float * 3)(), (C.c_int32 * 3)()
+        _check(lib().dpe_bcs_profile(self._h, C.c_int32(1 if enable else 0), ms, cnt))
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(("bcs_sum", "bcs_bank", "bcs_finalize"))}
+
     def Stop(self):
         if self.Started:
             _check(lib().dpe_bcs_destroy(self._h))
@@ -324,6 +330,11 @@ class BatchCorrManifold:
         ps = d2h(self.PosScores, self._W * Gp * 4, np.float32, stream).reshape(self._W, Gp)
         vs = d2h(self.VelScores, self._W * Gv * 4, np.float32, stream).reshape(self._W, Gv)
         return ps, vs
+
+    def profile(self, enable=True):
+        ms, cnt = (C.c_float * 2)(), (C.c_int32 * 2)()
+        _check(lib().dpe_bcm_profile(self._h, C.c_int32(1 if enable else 0), ms, cnt))
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(("bcm_scan_pos", "bcm_scan_vel"))}
 
     def Stop(self):
         if self.Started:

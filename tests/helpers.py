@@ -7,7 +7,7 @@ import numpy as np
 import navlab_dpe_sdr_amd as dpe
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HANDOFF = os.path.join(HERE, "golden", "handoff_params_usrp6.csv")
+HANDOFF = dpe.workload.HANDOFF_CSV
 
 
 def _oracle():

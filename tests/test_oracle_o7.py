@@ -9,7 +9,7 @@ import numpy as np
 
 import navlab_dpe_sdr_amd as dpe
 
-HANDOFF = os.path.join(os.path.dirname(__file__), "golden", "handoff_params_usrp6.csv")
+HANDOFF = dpe.workload.HANDOFF_CSV
 
 
 def test_o7_dp_iteration(golden, oracle):
