@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--windows", type=int, default=64, help="windows per step (batch resident in HBM)")
+    ap.add_argument("--windows", type=int, default=256, help="windows per step (batch resident in HBM)")
     ap.add_argument("--exchange", choices=["keys", "scores"], default="keys",
                     help="multi-GPU exchange: packed arg-max keys (8 B/window/manifold) or the north-star-literal "
                          "all-reduce(SUM) of the zero-initialised full score vectors")
@@ -166,6 +166,8 @@ def main():
     else:
         res = bcm.results()
     assert all(np.isfinite(r["zVal"]).all() for r in res)
+    if world == 1:   # the banks must cover every index the grids reach
+        assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res), "bank window too narrow"
 
     if rank == 0:
         units = float(args.steps) * W * 2.0 * G * K * world       # (gridpoint, SV) pairs, both manifolds, all ranks

@@ -8,8 +8,8 @@
 // to a fractional index into the SV's score row.  Here the geometry is expanded about the grid
 // centre on the HOST in fp64 (per window, per SV: unit line of sight in ENU, index at the centre,
 // index-per-metre scale, 1/(2 range)); the kernel then needs only fp32 DIFFERENCES:
-//   pos:  d_rho = |d - R delta| - |d| = -a + (q - a^2) h (1 + 2 a h) + O(|delta|^4 / range^3),
-//         a = u_enu . delta, q = |delta|^2, h = 1/(2 range)       (error < 1e-6 m for |delta| < 10 km)
+//   pos:  d_rho = |d - R delta| - |d| = -a + (q - a^2) h + O(|delta|^3 / range^2),
+//         a = u_enu . delta, q = |delta|^2, h = 1/(2 range)       (error < 1.3e-5 m for |delta| < 3 km)
 //         idx  = idx0 + g (delta_t + d_rho)                         (g = fs F_CA / (fc C), :1783-1791)
 //   vel:  idx  = idx0 + g_v (u_enu . delta_v - delta_tdot)          (exactly linear, :1917-1936)
 // followed by the reference's floor / floor(+1) linear interpolation (:1798-1812) and |.|^L.
@@ -28,6 +28,8 @@ struct BcmSvDev {
     float pad0, pad1;
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 constexpr int kPtsPerThread = 4;
 constexpr int kPtsPerBlock = 256 * kPtsPerThread;
 
@@ -41,59 +43,125 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float4 *sBank = reinterpret_cast<float4 *>(smem);                       // [K][nEnt] {c.re,c.im,d.re,d.im}
-    BcmSvDev *sSv = reinterpret_cast<BcmSvDev *>(smem + sizeof(float4) * (size_t)K * nEnt);
     __shared__ unsigned long long sKey[4];
     __shared__ unsigned int sOob[4];
 
     const int w = blockIdx.y, tid = threadIdx.x;
+    // first tile's grid points: issued before the bank fill so both latencies overlap
+    float4 nxt[kPtsPerThread];
+    {
+        const long long b0 = (long long)blockIdx.x * kPtsPerBlock + tid;
+#pragma unroll
+        for (int it = 0; it < kPtsPerThread; ++it)
+            nxt[it] = (b0 + it * 256 < G) ? grid[b0 + it * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float2 *bw = bank + (size_t)w * maxK * nEnt;
     for (int i = tid; i < K * nEnt; i += 256) {
         const int k = i / nEnt, j = i - k * nEnt;
-        const float2 c0 = bw[(size_t)k * nEnt + j];
-        const float2 c1 = (j + 1 < nEnt) ? bw[(size_t)k * nEnt + j + 1] : c0;
-        sBank[i] = make_float4(c0.x, c0.y, c1.x - c0.x, c1.y - c0.y);
+        // entry nEnt-1 can never be a valid lower neighbour: it is the all-zero slot that
+        // out-of-window indices are clamped to (contribution exactly 0, no select in the loop)
+        if (j + 1 < nEnt) {
+            const float2 c0 = bw[(size_t)k * nEnt + j], c1 = bw[(size_t)k * nEnt + j + 1];
+            sBank[i] = make_float4(c0.x, c0.y, c1.x - c0.x, c1.y - c0.y);
+        } else {
+            sBank[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-    for (int i = tid; i < K; i += 256) sSv[i] = sv[(size_t)w * maxK + i];
     __syncthreads();
 
+    // Persistent over point tiles: block (x, w) scores tiles x, x+gridDim.x, ... of window w, so the bank
+    // fill above is paid once per block and the next tile's grid points are prefetched under the
+    // current tile's arithmetic.  gridDim.x is a multiple of 8: blocks are dealt to the 8 XCDs round
+    // robin, so each XCD's L2 keeps re-serving the same 1/8 of the grid for every window.
+    // A thread's points: tile*1024 + tid + 256*it (each load instruction: 64 lanes x 16 B contiguous),
+    // held as PAIRS so that the geometry runs on packed fp32 (v_pk_fma_f32: two points per instruction).
+    constexpr int kPairs = kPtsPerThread / 2;
+    const unsigned last = (unsigned)(nEnt - 1);
+    const BcmSvDev *svw = sv + (size_t)w * maxK;   // wave-uniform address -> scalar loads
+    const long long nTiles = (G + kPtsPerBlock - 1) / kPtsPerBlock;
     unsigned long long best = 0ull;
     unsigned int nOob = 0;
-    const long long base = (long long)blockIdx.x * kPtsPerBlock;
+    for (long long tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const long long base = tile * kPtsPerBlock + tid;
+        f2 dx[kPairs], dy[kPairs], dz[kPairs], dw[kPairs], q[kPairs], score[kPairs];
 #pragma unroll
-    for (int it = 0; it < kPtsPerThread; ++it) {
-        const long long i = base + it * 256 + tid;
-        if (i < G) {
-            const float4 d = grid[i];
-            const float q = d.x * d.x + d.y * d.y + d.z * d.z;
-            float score = 0.f;
-            for (int k = 0; k < K; ++k) {
-                const BcmSvDev s = sSv[k];
-                const float a = fmaf(s.uu, d.z, fmaf(s.un, d.y, s.ue * d.x));
-                float x = d.w - a;
+        for (int p = 0; p < kPairs; ++p) {
+            const float4 d0 = nxt[2 * p], d1 = nxt[2 * p + 1];
+            dx[p] = f2{d0.x, d1.x}; dy[p] = f2{d0.y, d1.y}; dz[p] = f2{d0.z, d1.z}; dw[p] = f2{d0.w, d1.w};
+            q[p] = dx[p] * dx[p] + dy[p] * dy[p] + dz[p] * dz[p];
+            score[p] = f2{0.f, 0.f};
+        }
+        {   // prefetch the next tile of this block
+            const long long b1 = base + (long long)gridDim.x * kPtsPerBlock;
+#pragma unroll
+            for (int it = 0; it < kPtsPerThread; ++it)
+                nxt[it] = (b1 + it * 256 < G) ? grid[b1 + it * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        unsigned emax = 0;
+#pragma unroll 2
+        for (int k = 0; k < K; ++k) {
+            const BcmSvDev s = svw[k];
+            const float4 *bk = sBank + k * nEnt;
+#pragma unroll
+            for (int p = 0; p < kPairs; ++p) {
+                f2 a = dx[p] * s.ue;
+                a = __builtin_elementwise_fma(dy[p], f2{s.un, s.un}, a);
+                a = __builtin_elementwise_fma(dz[p], f2{s.uu, s.uu}, a);
+                f2 x = dw[p] - a;
                 if (SECOND) {
-                    const float t = fmaf(-a, a, q);
-                    const float ah = a * s.h;
-                    x = fmaf(t * s.h, fmaf(2.f, ah, 1.f), x);
+                    const f2 t = __builtin_elementwise_fma(-a, a, q[p]);          // q - a^2
+                    x = __builtin_elementwise_fma(t, f2{s.h, s.h}, x);             // + (q - a^2) / (2 range)
                 }
-                const float idx = fmaf(s.g, x, s.idx0);
-                const float fl = floorf(idx);
-                const float wgt = idx - fl;
-                const int e = (int)fl;
-                const bool ok = (unsigned)e < (unsigned)(nEnt - 1);
-                const float4 b = sBank[k * nEnt + (ok ? e : 0)];
-                const float vr = fmaf(wgt, b.z, b.x), vi = fmaf(wgt, b.w, b.y);
-                const float m2 = vr * vr + vi * vi;
-                float c;
-                if (LP == 1) c = sqrtf(m2);
-                else if (LP == 2) c = m2;
-                else c = powf(sqrtf(m2), (float)lpower);
-                score += ok ? c : 0.f;
-                nOob += ok ? 0u : 1u;
+                const f2 idx = __builtin_elementwise_fma(x, f2{s.g, s.g}, f2{s.idx0, s.idx0});
+                float c[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float id = idx[j];
+                    const float wgt = __builtin_amdgcn_fractf(id);                 // id - floor(id)
+                    int ei;
+                    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ei) : "v"(id));          // (int)floor(id), saturating
+                    const unsigned e = min((unsigned)ei, last);                    // negative -> huge -> zero slot
+                    emax = max(emax, e);
+                    const float4 b = bk[e];
+                    const f2 v = __builtin_elementwise_fma(f2{wgt, wgt}, f2{b.z, b.w}, f2{b.x, b.y});
+                    const f2 vv = v * v;
+                    const float m2 = vv.x + vv.y;
+                    if (LP == 1) c[j] = __builtin_amdgcn_sqrtf(m2);                // raw v_sqrt_f32 (1 ulp)
+                    else if (LP == 2) c[j] = m2;
+                    else c[j] = powf(__builtin_amdgcn_sqrtf(m2), (float)lpower);
+                }
+                score[p] += f2{c[0], c[1]};
             }
-            if (scores) scores[(size_t)w * G + i] = score;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) |
-                                           (unsigned long long)(0xFFFFFFFFu - (unsigned int)(i + indexOffset));
-            best = key > best ? key : best;
+        }
+        // out-of-window bookkeeping off the fast path: recount only if this thread ever hit the zero
+        // slot (or owns padding beyond G)
+        if (emax == last || base + (kPtsPerThread - 1) * 256 >= G) {
+            for (int it = 0; it < kPtsPerThread; ++it) {
+                if (base + it * 256 >= G) continue;
+                const float px = dx[it >> 1][it & 1], py = dy[it >> 1][it & 1], pz = dz[it >> 1][it & 1];
+                const float pw = dw[it >> 1][it & 1], pq = q[it >> 1][it & 1];
+                for (int k = 0; k < K; ++k) {
+                    const BcmSvDev s = svw[k];
+                    const float a = fmaf(pz, s.uu, fmaf(py, s.un, px * s.ue));
+                    float x = pw - a;
+                    if (SECOND) x = fmaf(fmaf(-a, a, pq), s.h, x);
+                    const float id = fmaf(x, s.g, s.idx0);
+                    int ei;
+                    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ei) : "v"(id));
+                    nOob += (min((unsigned)ei, last) == last) ? 1u : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kPtsPerThread; ++it) {
+            const long long i = base + it * 256;
+            if (i < G) {
+                const float sc = score[it >> 1][it & 1];
+                if (scores) scores[(size_t)w * G + i] = sc;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(sc) << 32) |
+                                               (unsigned long long)(0xFFFFFFFFu - (unsigned int)(i + indexOffset));
+                best = key > best ? key : best;
+            }
         }
     }
     // block arg-max: larger score wins, ties -> smaller global index (thrust::max_element, :2589)
@@ -144,6 +212,18 @@ static int upload_grid(const double *src, int64_t G, std::vector<double> &keep, 
     return 0;
 }
 
+// Blocks along x per window: ~4096 blocks in flight overall, a multiple of 8 (XCD round robin, see the
+// kernel) and never more than the number of 1024-point tiles.
+static unsigned scan_split(long long G, int nWindows)
+{
+    const long long nTiles = (G + dpe::kPtsPerBlock - 1) / dpe::kPtsPerBlock;
+    long long s = 4096 / nWindows;
+    if (s < 8) s = 8;
+    s = (s + 7) / 8 * 8;
+    if (s > nTiles) s = nTiles;
+    return (unsigned)s;
+}
+
 template <bool SECOND>
 static void launch_scan(int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
                         int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores, unsigned long long *keys,
@@ -185,7 +265,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
         const double r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
         if (r2 > maxR2) maxR2 = r2;
     }
-    DPE_REQUIRE(maxR2 < 2.0e4 * 2.0e4, "[BatchCorrManifold] create: position grid extends beyond 20 km from its centre");
+    DPE_REQUIRE(maxR2 < 3.0e3 * 3.0e3, "[BatchCorrManifold] create: position grid extends beyond 3 km from its centre");
     dpe_bcm *h = new dpe_bcm();
     h->cfg = *cfg;
     h->cfg.posGrid = h->cfg.velGrid = nullptr;
@@ -292,8 +372,8 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     const int nLag = 2 * L + 1, nBin = 2 * B + 1;
     {
         const long long G = h->cfg.posGridSize;
-        const dim3 grid((unsigned)((G + kPtsPerBlock - 1) / kPtsPerBlock), nWindows);
-        const size_t lds = (size_t)nChan * nLag * sizeof(float4) + (size_t)nChan * sizeof(BcmSvDev);
+        const dim3 grid(scan_split(G, nWindows), nWindows);
+        const size_t lds = (size_t)nChan * nLag * sizeof(float4);
         h->prof.begin(0, stream);
         launch_scan<true>(h->cfg.lPower, grid, lds, stream, h->posGrid_d, G, nChan, nLag, maxK, h->sv_d,
                           reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, h->keys_d, h->oob_d,
@@ -302,8 +382,8 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     }
     {
         const long long G = h->cfg.velGridSize;
-        const dim3 grid((unsigned)((G + kPtsPerBlock - 1) / kPtsPerBlock), nWindows);
-        const size_t lds = (size_t)nChan * nBin * sizeof(float4) + (size_t)nChan * sizeof(BcmSvDev);
+        const dim3 grid(scan_split(G, nWindows), nWindows);
+        const size_t lds = (size_t)nChan * nBin * sizeof(float4);
         h->prof.begin(1, stream);
         launch_scan<false>(h->cfg.lPower, grid, lds, stream, h->velGrid_d, G, nChan, nBin, maxK,
                            h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev), h->velScores_d,

@@ -24,6 +24,7 @@ namespace dpe {
 
 constexpr int kSub = 256;   // samples per wave sub-tile (4 per lane) == moment block
 constexpr int kNMom = 6;    // power moments 0..5
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct BcsChanDev {
     double rc;        // code phase at sample 0 (chips)
@@ -44,11 +45,27 @@ __global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict_
 {
     const int w = blockIdx.y;
     const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);
-    int sI = 0, sQ = 0;  // <= ~S/gridDim.x/256 samples per thread: no int32 overflow below 65k each
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < S; n += gridDim.x * blockDim.x) {
-        const int v = x[n];
-        sI += (short)(v & 0xFFFF);
-        sQ += v >> 16;
+    int sI = 0, sQ = 0;  // each thread sums < 64k samples: no int32 overflow
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    if (((reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
+        const int4 *x4 = reinterpret_cast<const int4 *>(x);
+        const int n4 = S >> 2;
+        for (int n = gtid; n < n4; n += gsz) {
+            const int4 v = x4[n];
+            sI += (short)(v.x & 0xFFFF) + (short)(v.y & 0xFFFF) + (short)(v.z & 0xFFFF) + (short)(v.w & 0xFFFF);
+            sQ += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
+        }
+        for (int n = (n4 << 2) + gtid; n < S; n += gsz) {
+            const int v = x[n];
+            sI += (short)(v & 0xFFFF);
+            sQ += v >> 16;
+        }
+    } else {
+        for (int n = gtid; n < S; n += gsz) {
+            const int v = x[n];
+            sI += (short)(v & 0xFFFF);
+            sQ += v >> 16;
+        }
     }
     long long tI = sI, tQ = sQ;
 #pragma unroll
@@ -92,9 +109,9 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
     __syncthreads();
 
     for (int side = 0; side < 2; ++side) {
-        float2 acc[NL];
+        f2 acc[NL];   // (re, im) pairs: packed fp32 FMAs against the real replica
 #pragma unroll
-        for (int j = 0; j < NL; ++j) acc[j] = make_float2(0.f, 0.f);
+        for (int j = 0; j < NL; ++j) acc[j] = f2{0.f, 0.f};
 
         for (int t = 0; t < tilesPerBlock; ++t) {
             const int sub = (blk * tilesPerBlock + t) * 4 + wave;
@@ -117,10 +134,10 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
                     sRep[wave][e] = (sd == side) ? (float)sChips[ci] : 0.f;
                 }
             }
-            __syncthreads();
-            float2 M[kNMom];
+            // no barrier: sRep[wave] is private to this wave and a wave's DS operations complete in order
+            f2 M[kNMom];
 #pragma unroll
-            for (int p = 0; p < kNMom; ++p) M[p] = make_float2(0.f, 0.f);
+            for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
             if (active) {
                 const int n0 = sub0 + 4 * lane;
                 float re[4], im[4];
@@ -157,21 +174,21 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
                     const float br = re[i] * wr - im[i] * wi;
                     const float bi = re[i] * wi + im[i] * wr;
                     // sample n, lag l = j-LH uses replica index n-l -> rr[i - j + 2 LH]
+                    const f2 bb = f2{br, bi};
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        acc[j].x = fmaf(br, rr[i + 2 * LH - j], acc[j].x);
-                        acc[j].y = fmaf(bi, rr[i + 2 * LH - j], acc[j].y);
+                        const float r = rr[i + 2 * LH - j];
+                        acc[j] = __builtin_elementwise_fma(bb, f2{r, r}, acc[j]);
                     }
                     // carrier path: (raw - mean) * wipe * replica (:480, :440-448)
                     const float r0 = (n0 + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
                     const float cr = (br - (mRe * wr - mIm * wi)) * r0;
                     const float cim = (bi - (mRe * wi + mIm * wr)) * r0;
-                    float pw = 1.f;
+                    f2 cp = f2{cr, cim};   // x^p * c, built up by one packed multiply per order
 #pragma unroll
                     for (int p = 0; p < kNMom; ++p) {
-                        M[p].x = fmaf(pw, cr, M[p].x);
-                        M[p].y = fmaf(pw, cim, M[p].y);
-                        pw *= xp[i];
+                        M[p] += cp;
+                        cp *= xp[i];
                     }
                     const float nr = wr * ch.rotRe - wi * ch.rotIm;
                     wi = wr * ch.rotIm + wi * ch.rotRe;
@@ -179,24 +196,31 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
                 }
             }
             if (sub < nSub) {
+                float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
+                if (active) {
+                    float mm[2 * kNMom];
 #pragma unroll
-                for (int p = 0; p < kNMom; ++p) {
-                    M[p].x = wave_sum(M[p].x);
-                    M[p].y = wave_sum(M[p].y);
-                }
-                if (lane == 0) {
-                    float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
+                    for (int p = 0; p < kNMom; ++p) { mm[2 * p] = M[p].x; mm[2 * p + 1] = M[p].y; }
+                    dpp_sum_lane63(mm);
+                    if (lane == 63) {
 #pragma unroll
-                    for (int p = 0; p < kNMom; ++p) o[p] = M[p];
+                        for (int p = 0; p < kNMom; ++p) o[p] = make_float2(mm[2 * p], mm[2 * p + 1]);
+                    }
+                } else if (lane < kNMom) {
+                    o[lane] = make_float2(0.f, 0.f);
                 }
             }
-            __syncthreads();
         }
         // block partial of the lag sums, fixed reduction order
+        {
+            float aa[2 * NL];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const float sx = wave_sum(acc[j].x), sy = wave_sum(acc[j].y);
-            if (lane == 0) sAcc[wave][j] = make_float2(sx, sy);
+            for (int j = 0; j < NL; ++j) { aa[2 * j] = acc[j].x; aa[2 * j + 1] = acc[j].y; }
+            dpp_sum_lane63(aa);
+            if (lane == 63) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) sAcc[wave][j] = make_float2(aa[2 * j], aa[2 * j + 1]);
+            }
         }
         __syncthreads();
         for (int j = tid; j < NL; j += 256) {
@@ -262,7 +286,17 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSu
         const float2 *m0 = mom + (((size_t)w * K + k) * 2) * nSub * kNMom;
         const float2 *m1 = m0 + (size_t)nSub * kNMom;
         const float invC = 1.0f / (float)C;  // C is a power of two: exact
-        for (int sub = grp; sub < nSub; sub += 4) {
+        // centre twiddle exp(-j 2 pi n_c b / C), n_c = 256 sub + 127.5: exact (integer-reduced phase +
+        // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 1024 b / C) between
+        float stepS, stepC;
+        {
+            long long ts = ((long long)2048 * (long long)b) % (2 * C);   // 2 * 1024 b  (phase unit: pi / C)
+            if (ts < 0) ts += 2 * C;
+            sincospif((float)ts * invC, &stepS, &stepC);
+        }
+        float sn = 0.f, cs = 1.f;
+        int it = 0;
+        for (int sub = grp; sub < nSub; sub += 4, ++it) {
             const float2 *a0 = m0 + (size_t)sub * kNMom, *a1 = m1 + (size_t)sub * kNMom;
             float ar = a0[kNMom - 1].x + sgn * a1[kNMom - 1].x;
             float ai = a0[kNMom - 1].y + sgn * a1[kNMom - 1].y;
@@ -274,11 +308,15 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSu
                 ai = fmaf(-s, ar, mi);
                 ar = nr;
             }
-            // block centre n_c = 256 sub + 127.5 -> phase = -(512 sub + 255) b / (2C) revolutions
-            long long tt = ((long long)(512 * sub + 255) * (long long)b) % (2 * C);
-            if (tt < 0) tt += 2 * C;
-            float sn, cs;
-            sincospif((float)tt * invC, &sn, &cs);  // angle = pi * tt / C
+            if ((it & 7) == 0) {
+                long long tt = ((long long)(512 * sub + 255) * (long long)b) % (2 * C);
+                if (tt < 0) tt += 2 * C;
+                sincospif((float)tt * invC, &sn, &cs);  // angle = pi * tt / C
+            } else {
+                const float nc = cs * stepC - sn * stepS;
+                sn = sn * stepC + cs * stepS;
+                cs = nc;
+            }
             // (cs - j sn) * (ar + j ai)
             F.x += cs * ar + sn * ai;
             F.y += cs * ai - sn * ar;
@@ -367,7 +405,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->LH = cfg->lagHalfWidth <= 4 ? 4 : cfg->lagHalfWidth <= 8 ? 8 : cfg->lagHalfWidth <= 16 ? 16 : 32;
     h->nSub = (S + kSub - 1) / kSub;
     const int nTiles = (h->nSub + 3) / 4;
-    h->tilesPerBlock = (nTiles + 63) / 64;
+    h->tilesPerBlock = (nTiles + 63) / 64;   // fewest tiles per block ever used -> sizes the partial buffer
     h->nBlk = (nTiles + h->tilesPerBlock - 1) / h->tilesPerBlock;
     const size_t W = cfg->maxWindows, K = cfg->maxChannels;
     std::vector<int8_t> table(37 * 1024, 0);
@@ -439,16 +477,22 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->lastK = nChan;
     DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
     DPE_CHECK_HIP(hipMemsetAsync(h->sums_d, 0, sizeof(long long) * 2 * nWindows, stream));
-    const int sumBlocks = (S / 256 / 8 > 0) ? (S / 256 / 8 > 64 ? 64 : S / 256 / 8) : 1;
+    const int sumBlocks = (S / 1024 / 8 > 0) ? (S / 1024 / 8 > 64 ? 64 : S / 1024 / 8) : 1;
     h->prof.begin(0, stream);
     hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
                        (long long)windowStrideSamples, S, h->sums_d);
     h->prof.end(0, stream);
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
-    const dim3 grid(h->nBlk, nChan, nWindows), block(256);
+    // tiles per block: amortise the end-of-block lag reduction while keeping >= ~4096 blocks in flight
+    const int nTiles = (h->nSub + 3) / 4;
+    int tpb = (int)(((long long)nTiles * nChan * nWindows) / 4096);
+    if (tpb < h->tilesPerBlock) tpb = h->tilesPerBlock;
+    if (tpb > 16) tpb = 16;
+    const int nBlk = (nTiles + tpb - 1) / tpb;
+    const dim3 grid(nBlk, nChan, nWindows), block(256);
 #define DPE_LAUNCH_BANK(LHV)                                                                                     \
     hipLaunchKernelGGL(bcs_bank_kernel<LHV>, grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
-                       S, nChan, h->nSub, h->tilesPerBlock, h->nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, \
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, \
                        h->part_d, h->mom_d)
     h->prof.begin(1, stream);
     switch (h->LH) {
@@ -462,7 +506,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 63) / 64;
     hipLaunchKernelGGL(bcs_finalize_kernel, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
-                       h->nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
+                       nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
                        h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);
     DPE_CHECK_HIP(hipGetLastError());

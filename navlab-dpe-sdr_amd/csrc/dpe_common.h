@@ -53,6 +53,33 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// 64-lane sums on the VALU (DPP, no LDS traffic): quad swaps, half-row and row mirrors, then the two
+// row broadcasts; lane 63 ends up with the total.  N independent values are reduced step-major so
+// that the VALU->DPP read hazard of one chain is covered by the other chains (no s_nop padding).
+template <int N>
+__device__ __forceinline__ void dpp_sum_lane63(float (&v)[N])
+{
+    static_assert(N >= 3, "the step-major interleave must cover the 2 wait states of a VALU->DPP hazard");
+    // in-place v_add_f32 with a DPP source: one instruction per value per step; rows masked off by
+    // row_mask keep their value.  (Written as asm: the compiler's own lowering of update_dpp costs
+    // three instructions per step and pairs the adds into v_pk_add, which cannot take DPP.)
+#define DPE_DPP_STEP(mod) \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) asm volatile("v_add_f32_dpp %0, %0, %0 " mod : "+v"(v[i]));
+    DPE_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+    DPE_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+    DPE_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+    DPE_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+    DPE_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    DPE_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef DPE_DPP_STEP
+}
+
+// wave-uniform total of v (read back from lane 63)
+__device__ __forceinline__ float lane63(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
 struct KernelProfiler {
     bool enabled = false;

@@ -13,7 +13,7 @@ from . import engine, handoff, synth
 HANDOFF_CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "handoff_params_usrp6.csv")
 
 CONFIG_R = dict(name="R: demofiles twin, 2.5 Msps x 20 ms, 8 SVs, rngrid3-format 25^4-point grids",
-                fs=2.5e6, S=50000, K=8, G=390625, L=8, B=48, amp=48.0)
+                fs=2.5e6, S=50000, K=8, G=390625, L=4, B=20, amp=48.0)
 
 
 def build_windows(W, fs, S, K, seed=0, amp=48.0):
