@@ -1,0 +1,185 @@
+// dpe_flow -- batch driver that loads the DPE flow exactly as DPEFlow::LoadFlow does
+// (cudarecv/dsp/src/dpeflow.cpp:26-222: 7 modules, SetModParam table, ConnectPort table) on top of
+// libdpe_hip.so, runs it for N windows and writes the X-file (xCurrk1k1 per window, CSV).
+// Replaces the interactive console (NEWFlow / LOADFlow / STARTFlow) for this path.
+//
+//   dpe_flow --samples f.dat --handoff handoff.csv --out X.csv [--fs 2.5e6] [--T 0.02] [--iters 3000]
+//            [--grid-dim 25] [--spacing 1.0] [--grid-type 0|2] [--load-grid rngrid.csv] [--lpower 1]
+//            [--init-delta dx dy dz dt]
+//   dpe_flow --dump-grid <type> <dim> <spacing> <out.bin>        (grid builders only, no GPU)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "modules.hpp"
+
+#define CHECK(x)                                                              \
+    do {                                                                      \
+        if ((x) != 0) {                                                       \
+            std::fprintf(stderr, "[DPEFlow] failed: %s\n", #x);               \
+            return 1;                                                         \
+        }                                                                     \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    std::string samples, handoff, out = "XFile.csv", loadGrid;
+    double fs = 2.5e6, T = 0.02;
+    int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
+    float spacing = 1.0f, delta[4] = {0, 0, 0, 0};
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&](int n = 1) { if (i + n >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[i + 1]; };
+        if (a == "--dump-grid") {
+            if (i + 4 >= argc) return 2;
+            const int type = std::atoi(argv[i + 1]), dim = std::atoi(argv[i + 2]);
+            const double sp = std::atof(argv[i + 3]);
+            const int d[4] = {dim, dim, dim, dim};
+            const double s[4] = {sp, sp, sp, sp};
+            std::vector<double> g, tg;
+            dsp::utils::build_grid((dsp::utils::ManifoldGridTypes)type, d, s, g, &tg, false);
+            FILE *f = std::fopen(argv[i + 4], "wb");
+            if (!f) return 1;
+            std::fwrite(g.data(), sizeof(double), g.size(), f);
+            std::fwrite(tg.data(), sizeof(double), tg.size(), f);
+            std::fclose(f);
+            return 0;
+        } else if (a == "--samples") { samples = next(); ++i; }
+        else if (a == "--handoff") { handoff = next(); ++i; }
+        else if (a == "--out") { out = next(); ++i; }
+        else if (a == "--load-grid") { loadGrid = next(); ++i; }
+        else if (a == "--fs") { fs = std::atof(next()); ++i; }
+        else if (a == "--T") { T = std::atof(next()); ++i; }
+        else if (a == "--iters") { iters = std::atoi(next()); ++i; }
+        else if (a == "--grid-dim") { gridDim = std::atoi(next()); ++i; }
+        else if (a == "--grid-type") { gridType = std::atoi(next()); ++i; }
+        else if (a == "--spacing") { spacing = (float)std::atof(next()); ++i; }
+        else if (a == "--lpower") { lpower = std::atoi(next()); ++i; }
+        else if (a == "--init-delta") { next(4); for (int j = 0; j < 4; ++j) delta[j] = (float)std::atof(argv[i + 1 + j]); i += 4; }
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (samples.empty() || handoff.empty()) { std::fprintf(stderr, "usage: see the header of dpe_flow_main.cpp\n"); return 2; }
+
+    // bank widths from the grids this run will use
+    int L = 8, B = 48;
+    {
+        const int d[4] = {gridDim, gridDim, gridDim, gridDim};
+        const double s[4] = {spacing, spacing, spacing, spacing};
+        std::vector<double> pg, vg;
+        dsp::utils::build_grid((dsp::utils::ManifoldGridTypes)gridType, d, s, pg, nullptr, false);
+        dsp::utils::build_grid((dsp::utils::ManifoldGridTypes)gridType, d, s, vg, nullptr, true);
+        if (!loadGrid.empty() && dsp::utils::load_grid_csv(loadGrid, (long long)pg.size() / 4, pg)) {
+            std::fprintf(stderr, "[DPEFlow] cannot load %s (needs %d^4 rows)\n", loadGrid.c_str(), gridDim);
+            return 1;
+        }
+        long long nfft = 8;
+        while (nfft / 8 < (long long)(fs * T + 0.5)) nfft <<= 1;
+        dsp::utils::bank_half_widths(pg, vg, fs, nfft, &L, &B);
+        if (L > 32) { std::fprintf(stderr, "[DPEFlow] grid needs +-%d code lags (> 32)\n", L); return 1; }
+    }
+
+    dsp::Flow flow;                                             // dpeflow.cpp:55-62
+    flow.Add(new dsp::DPInit);
+    flow.Add(new dsp::SampleBlock);
+    flow.Add(new dsp::BatchCorrScores);
+    flow.Add(new dsp::BatchCorrManifold);
+    flow.Add(new dsp::cuEKF);
+    flow.Add(new dsp::cuChanMgr);
+    flow.Add(new dsp::DataLogger("XECEFLogger"));
+
+    CHECK(flow.SetModParam("SampleBlock", "SamplingFrequency", fs));          // dpeflow.cpp:67-90
+    CHECK(flow.SetModParam("SampleBlock", "RunLive", false));
+    CHECK(flow.SetModParam("SampleBlock", "Filename", samples.c_str()));
+    CHECK(flow.SetModParam("DPInit", "HandoffFilename", handoff.c_str()));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaX", delta[0]));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaY", delta[1]));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaZ", delta[2]));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaT", delta[3]));
+    CHECK(flow.SetModParam("DPInit", "MaxIterations", iters + 1));
+    CHECK(flow.SetModParam("SampleBlock", "SampleLength", T));
+    CHECK(flow.SetModParam("cuEKF", "SampleLength", T));
+    CHECK(flow.SetModParam("BatchCorrManifold", "PosGridDimSize", gridDim));
+    CHECK(flow.SetModParam("BatchCorrManifold", "VelGridDimSize", gridDim));
+    CHECK(flow.SetModParam("BatchCorrManifold", "GridDimSpacing", spacing));
+    CHECK(flow.SetModParam("BatchCorrManifold", "GridType", gridType));
+    CHECK(flow.SetModParam("BatchCorrManifold", "LPower", lpower));
+    CHECK(flow.SetModParam("cuChanMgr", "DopplerSign", 1));
+    CHECK(flow.SetModParam("cuEKF", "EnableEKF", false));
+    CHECK(flow.SetModParam("XECEFLogger", "Filename", out.c_str()));
+    CHECK(flow.SetModParam("XECEFLogger", "CSV", true));
+    if (!loadGrid.empty()) {
+        CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGrid", true));
+        CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGridFilename", loadGrid.c_str()));
+    }
+    CHECK(flow.SetModParam("BatchCorrScores", "LagHalfWidth", L));
+    CHECK(flow.SetModParam("BatchCorrScores", "BinHalfWidth", B));
+
+    // port table, dpeflow.cpp:140-213 (InitP / InitK belong to the disabled EKF and are dropped)
+    static const char *wires[][4] = {
+        {"DPInit", "StartByte", "SampleBlock", "StartByte"},
+        {"DPInit", "InitX", "cuEKF", "InitX"},
+        {"DPInit", "InitEph", "cuChanMgr", "InitEph"},
+        {"DPInit", "InitPRN", "cuChanMgr", "InitPRN"},
+        {"DPInit", "InitCodePhase", "cuChanMgr", "InitCodePhase"},
+        {"DPInit", "InitCarrierPhase", "cuChanMgr", "InitCarrierPhase"},
+        {"DPInit", "InitCodeFrequency", "cuChanMgr", "InitCodeFrequency"},
+        {"DPInit", "InitCarrierFrequency", "cuChanMgr", "InitCarrierFrequency"},
+        {"DPInit", "InitElapsedCodePeriods", "cuChanMgr", "InitElapsedCodePeriods"},
+        {"DPInit", "InitReferenceCodePeriods", "cuChanMgr", "InitReferenceCodePeriods"},
+        {"DPInit", "InitCPRefTOW", "cuChanMgr", "InitCPRefTOW"},
+        {"DPInit", "InitRXTime", "cuChanMgr", "InitRXTime"},
+        {"SampleBlock", "Samples", "BatchCorrScores", "Samples"},
+        {"SampleBlock", "SamplingFrequency", "BatchCorrScores", "SamplingFrequency"},
+        {"SampleBlock", "SampleLength", "BatchCorrScores", "SampleLength"},
+        {"SampleBlock", "SamplingFrequency", "BatchCorrManifold", "SamplingFrequency"},
+        {"SampleBlock", "SampleLength", "BatchCorrManifold", "SampleLength"},
+        {"SampleBlock", "SampleLength", "cuChanMgr", "SampleLength"},
+        {"BatchCorrScores", "CodeScores", "BatchCorrManifold", "CodeScores"},
+        {"BatchCorrScores", "CarrScores", "BatchCorrManifold", "CarrScores"},
+        {"BatchCorrScores", "NumFFTPoints", "BatchCorrManifold", "NumFFTPoints"},
+        {"cuChanMgr", "CodePhaseStart", "BatchCorrScores", "CodePhaseStart"},
+        {"cuChanMgr", "CodeFrequency", "BatchCorrScores", "CodeFrequency"},
+        {"cuChanMgr", "CarrierPhaseStart", "BatchCorrScores", "CarrierPhaseStart"},
+        {"cuChanMgr", "CarrierFrequency", "BatchCorrScores", "CarrierFrequency"},
+        {"cuChanMgr", "cpReference", "BatchCorrScores", "cpReference"},
+        {"cuChanMgr", "cpElapsedStart", "BatchCorrScores", "cpElapsedStart"},
+        {"cuChanMgr", "DopplerSign", "BatchCorrScores", "DopplerSign"},
+        {"cuChanMgr", "ValidPRNs", "BatchCorrScores", "ValidPRNs"},
+        {"cuChanMgr", "CodeFrequency", "BatchCorrManifold", "CodeFrequency"},
+        {"cuChanMgr", "CarrierFrequency", "BatchCorrManifold", "CarrierFrequency"},
+        {"cuChanMgr", "rxTime", "BatchCorrManifold", "rxTime"},
+        {"cuChanMgr", "txTime", "BatchCorrManifold", "txTime"},
+        {"cuChanMgr", "DopplerSign", "BatchCorrManifold", "DopplerSign"},
+        {"cuChanMgr", "SatStates", "BatchCorrManifold", "SatStates"},
+        {"cuChanMgr", "ENU2ECEFMat", "BatchCorrManifold", "ENU2ECEFMat"},
+        {"cuChanMgr", "SatStatesOld", "BatchCorrManifold", "SatStatesOld"},
+        {"cuChanMgr", "CodePhaseEnd", "BatchCorrManifold", "CodePhase"},
+        {"cuChanMgr", "CarrierPhaseEnd", "BatchCorrManifold", "CarrierPhase"},
+        {"cuChanMgr", "cpRefTOW", "BatchCorrManifold", "cpRefTOW"},
+        {"cuChanMgr", "cpRef", "BatchCorrManifold", "cpRef"},
+        {"cuChanMgr", "cpElapsedEnd", "BatchCorrManifold", "cpElapsedEnd"},
+        {"BatchCorrManifold", "zVal", "cuEKF", "zVal"},
+        {"BatchCorrManifold", "RVal", "cuEKF", "RVal"},
+        {"BatchCorrManifold", "TimeGrid", "cuChanMgr", "TimeGrid"},
+        {"cuEKF", "xCurrk1k1", "cuChanMgr", "xCurrk1k1"},
+        {"cuEKF", "xCurrkk1", "cuChanMgr", "xCurrkk1"},
+        {"cuEKF", "xCurrkk1", "BatchCorrManifold", "xCurrkk1"},
+        {"cuEKF", "xCurrk1k1", "XECEFLogger", "Data"},
+    };
+    for (auto &w : wires) CHECK(flow.ConnectPort(w[0], w[1], w[2], w[3]));
+    std::clog << "[DPEFlow] Completed LoadFlow. (L=" << L << ", B=" << B << ")" << std::endl;
+
+    dpe_stream_t stream = nullptr;
+    CHECK(dpe_stream_create(&stream));
+    CHECK(flow.Start(stream));
+    int n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (n < iters && flow.Step() == 0) ++n;                  // FlowThread loop, flow.cu:122-137
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    flow.Stop();
+    dpe_stream_destroy(stream);
+    std::clog << "[DPEFlow] " << n << " iterations, " << (n ? dt / n * 1e6 : 0.0) << " us per iteration ("
+              << (n ? n * T / dt : 0.0) << " x real time, closed loop, one window per Update)" << std::endl;
+    return n > 0 ? 0 : 1;
+}

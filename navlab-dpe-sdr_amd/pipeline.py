@@ -1,0 +1,51 @@
+"""Closed-loop DPE iteration on top of the C-ABI -- the Python twin of host/dpe_flow_main.cpp and of
+Flow::FlowThread's module order (cudarecv/dsp/src/flow.cu:122-137; dpeflow.cpp:55-62):
+SampleBlock -> BatchCorrScores -> BatchCorrManifold -> cuEKF(pass-through) -> cuChanMgr."""
+import numpy as np
+
+from . import engine
+
+
+def bank_half_widths(pos_grid, vel_grid, fs, nfft):
+    """INTEGRATION.md section 3 (same rule as host/grids.hpp::bank_half_widths)."""
+    ep = (np.linalg.norm(pos_grid[:, :3], axis=1) + np.abs(pos_grid[:, 3])).max()
+    ev = (np.linalg.norm(vel_grid[:, :3], axis=1) + np.abs(vel_grid[:, 3])).max()
+    L = int(np.ceil(ep * fs / 299792458.0)) + 2
+    B = int(np.ceil(ev * (nfft / fs) * 1.57542e9 / 299792458.0)) + 3
+    return L, B
+
+
+def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), init_delta=(0, 0, 0, 0), K=None,
+                    lpower=1):
+    """iq_windows: int16 [W, 2S] (host).  Returns fixes [W, 8] (= xCurrk1k1 per window) and the raw
+    per-window result dicts.  One window per Update, fix fed back to the channel manager."""
+    import torch
+    iq_windows = np.ascontiguousarray(iq_windows)
+    W, S2 = iq_windows.shape
+    S = S2 // 2
+    K = len(ho["prn_list"]) if K is None else K
+    nfft = engine.carr_fft_len(S)
+    L, B = bank_half_widths(pos_grid, vel_grid, fs, nfft)
+    bcs = engine.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_channels=K)
+    bcs.Start()
+    bcm = engine.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos_grid, vel_grid, LPower=lpower, lag_half_width=L,
+                                   bin_half_width=B, max_channels=K)
+    bcm.Start()
+    cm = engine.ChanMgr.from_handoff(ho, S / fs, K)
+    x = np.array(ho["X_ECEF"], dtype=np.float64).copy()
+    x[:4] += np.asarray(init_delta, dtype=np.float64)
+    iq_d = torch.from_numpy(iq_windows).to("cuda:0")
+    fixes, results = np.zeros((W, 8)), []
+    for w in range(W):
+        (cm.Start if w == 0 else cm.Update)(x, x, time_grid)
+        cs, ce, bw = cm.outputs()
+        bcs.Update(iq_d[w], cs)
+        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+        r = bcm.results()[0]
+        x = r["zVal"].copy()            # EKF_PassMeas: the ML point is the new state
+        fixes[w] = x
+        results.append(r)
+    cm.Stop()
+    bcm.Stop()
+    bcs.Stop()
+    return fixes, results

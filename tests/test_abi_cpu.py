@@ -80,3 +80,17 @@ def test_chanmgr_matches_oracle(built, oracle):
         assert np.abs(batch - ob).max() < 1e-6 and np.abs(w["enu2ecef"][0] - oR).max() < 1e-14
         assert np.abs(e["satState"] - ob[:, tg.size // 2]).max() < 1e-6
     cm.Stop()
+
+
+@pytest.mark.parametrize("gtype,dim,sp", [(0, 5, 1.0), (0, 6, 0.5), (2, 9, 1.5), (2, 25, 1.0)])
+def test_host_grid_builders_match_oracle(built, oracle, tmp_path, gtype, dim, sp):
+    """C++ host (host/grids.hpp via `dpe_flow --dump-grid`) vs the oracle's BCM_InitPosGrid restatement."""
+    import subprocess
+    out = str(tmp_path / "g.bin")
+    subprocess.check_call([os.path.join(ROOT, "navlab-dpe-sdr_amd", "dpe_flow"), "--dump-grid", str(gtype), str(dim), str(sp), out])
+    raw = np.fromfile(out)
+    G = dim ** 4
+    og, otg = oracle.init_grid(gtype, [dim] * 4, [sp] * 4)
+    assert np.array_equal(raw[:4 * G].reshape(G, 4), og) and np.array_equal(raw[4 * G:], otg)
+    if gtype == 0:
+        assert np.array_equal(og, dpe.synth.uniform_grid(dim, sp))

@@ -139,3 +139,67 @@ def test_dense_export_matches_reference_layout(golden):
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_sharded_grid_equals_full_grid():
+    """Two BatchCorrManifold instances on the two halves of a grid (index offsets as in the multi-GPU
+    path) + integer max of their packed keys == one instance on the whole grid."""
+    import torch
+    case = helpers.make_case(seed=9, S=12500, K=4, G=5001, amp=200.0, W=2)
+    iq, cs, ce, bw = helpers.pack_gpu_inputs(case)
+    L, B = 8, 32
+    bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=L, bin_half_width=B, max_windows=2, max_channels=4)
+    bcs.Start()
+    bcs.Update(torch.from_numpy(iq).to("cuda:0"), cs)
+
+    def run(pos, vel, po, vo):
+        m = dpe.BatchCorrManifold(case["fs"], case["S"], bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B,
+                                  max_windows=2, max_channels=4, pos_index_offset=po, vel_index_offset=vo)
+        m.Start()
+        m.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+        torch.cuda.synchronize()
+        keys = dpe.engine.d2h(m.Keys, 2 * 2 * 8, np.uint64).reshape(2, 2)
+        return m, keys
+
+    full, kf = run(case["pos"], case["vel"], 0, 0)
+    rf = full.results()
+    b0, e0 = dpe.sharding.shard_range(5001, 0, 2)
+    b1, e1 = dpe.sharding.shard_range(5001, 1, 2)
+    m0, k0 = run(case["pos"][b0:e0], case["vel"][b0:e0], b0, b0)
+    m1, k1 = run(case["pos"][b1:e1], case["vel"][b1:e1], b1, b1)
+    merged = np.maximum(k0, k1)
+    assert np.array_equal(merged, kf)
+    rm = m0.results_from_keys(merged, case["pos"], case["vel"])
+    for w in range(2):
+        assert rm[w]["posIndex"] == rf[w]["posIndex"] and rm[w]["velIndex"] == rf[w]["velIndex"]
+        assert np.array_equal(rm[w]["zVal"], rf[w]["zVal"])
+    for m in (full, m0, m1):
+        m.Stop()
+    bcs.Stop()
+
+
+def test_cpp_flow_matches_python_closed_loop(tmp_path):
+    """host/dpe_flow (C++ modules wired as DPEFlow::LoadFlow) on a synthetic sample file == the Python
+    closed loop on the same library; and the fix stays on the true position (static receiver)."""
+    import os
+    import subprocess
+    W, fs, S, K = 6, 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=5, amp=200.0)
+    dat = str(tmp_path / "synthetic_2500kHz.dat")
+    iq.tofile(dat)
+    ho_path = str(tmp_path / "handoff.csv")
+    with open(dpe.workload.HANDOFF_CSV) as f, open(ho_path, "w") as g:
+        for line in f:
+            g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
+    out = str(tmp_path / "X.csv")
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
+    subprocess.check_call([exe, "--samples", dat, "--handoff", ho_path, "--out", out, "--iters", str(W), "--grid-dim", "9",
+                           "--spacing", "1.0"])
+    rows = np.loadtxt(out, delimiter=",")
+    assert rows.shape == (W, 8)
+    ho = dpe.handoff.read_handoff(ho_path)
+    g9 = dpe.synth.uniform_grid(9, 1.0)
+    fixes, res = dpe.pipeline.run_closed_loop(iq, ho, fs, g9, g9, time_grid=np.unique(g9[:, 3]))
+    assert np.abs(rows - fixes).max() < 1e-6                       # %f rows vs doubles
+    assert np.abs(fixes[:, :3] - ho["X_ECEF"][:3]).max() < 1.0     # position fix within 1 m of truth
+    assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res)
