@@ -30,6 +30,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
+def pmc_traffic(windows):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json; FETCH_SIZE doubled as the microarch guide prescribes), or None when
+    the batch size differs from the profiled one."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        d = json.load(open(f))
+        if d.get("windows_per_step") == windows:
+            return d["kernels"]["bcm_scan_kernel<pos>"]["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """Oracle (fp64 port of the reference algorithm: FFT BatchCorrScores in numpy + C grid scan)
     timed single-threaded on the host, on whole windows of the same workload."""
@@ -87,13 +99,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("DPE_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL self-test
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
 
     cfg = dict(dpe.workload.CONFIG_R)
     fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
@@ -110,7 +125,7 @@ def main():
     bcm.Start()
     stream = torch.cuda.current_stream()
     keys_t = None
-    if world > 1:
+    if use_dist:
         # torch view of the handle's packed keys (int64: scores are >= 0 so the sign bit is clear)
         class _Cai:
             __cuda_array_interface__ = {"shape": (W, 2), "typestr": "<i8", "data": (bcm.Keys, False), "version": 2}
@@ -128,9 +143,9 @@ def main():
     def step():
         bcs.Update(iq_d, cs, stream=stream)
         bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce, stream=stream)
-        if world > 1:
+        if use_dist:
             if args.exchange == "keys":
-                dist.all_reduce(keys_t, op=dist.ReduceOp.MAX)
+                dpe.sharding.allreduce_argmax(keys_t, dist)
             else:
                 glob_p.zero_(); glob_v.zero_()
                 glob_p[:, off:off + G].copy_(loc_p); glob_v[:, off:off + G].copy_(loc_v)
@@ -139,7 +154,7 @@ def main():
                 torch.argmax(glob_p, dim=1); torch.argmax(glob_v, dim=1)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,15 +169,20 @@ def main():
     dt = time.perf_counter() - t0
     kern = {}
     kern.update(bcs.profile(False)); kern.update(bcm.profile(False))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # result sanity on rank 0: the synthetic windows put the truth at the grid centre -> the ML point must be
     # the grid point with the smallest geometric offset pattern; just check the fix is finite and in-grid.
-    if world > 1:
+    if use_dist:
         res = bcm.results_from_keys(keys_t.cpu().numpy().view(np.uint64), pos_g, vel_g)
+        if world == 1:   # self-test: the exchanged keys decode to what the handle itself reports
+            ref = bcm.results()
+            assert all(a["posIndex"] == b["posIndex"] and a["velIndex"] == b["velIndex"] and
+                       np.array_equal(a["zVal"], b["zVal"]) for a, b in zip(res, ref))
+            res = ref
     else:
         res = bcm.results()
     assert all(np.isfinite(r["zVal"]).all() for r in res)
@@ -182,10 +202,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "samples_per_window": S, "svs": K, "grid_points_per_manifold_per_gpu": G,
                        "manifolds": 2, "windows_per_step": W, "lag_half_width": L, "bin_half_width": B,
-                       "exchange": args.exchange if world > 1 else "none", "scores_written": write_scores},
+                       "exchange": args.exchange if use_dist else "none", "scores_written": write_scores},
             "x_realtime": windows_per_s / 50.0, "windows_per_s": windows_per_s,
             "roofline": {"bound": "hbm", "kernel": "bcm_scan_kernel<pos>", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(W) if world == 1 else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": ms_scan / n_scan if n_scan else None},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()},
@@ -194,7 +214,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
     bcm.Stop(); bcs.Stop()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
