@@ -84,7 +84,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--windows", type=int, default=256, help="windows per step (batch resident in HBM)")
+    ap.add_argument("--windows", type=int, default=None, help="windows per step (batch resident in HBM); default 256 (R) / 32 (H)")
+    ap.add_argument("--config", choices=["R", "H"], default="R",
+                    help="R = BASELINE.json configs[1] (the metric's configuration); H = configs[2] (25 Msps, 12 SVs, 1e5-point grids)")
     ap.add_argument("--exchange", choices=["keys", "scores"], default="keys",
                     help="multi-GPU exchange: packed arg-max keys (8 B/window/manifold) or the north-star-literal "
                          "all-reduce(SUM) of the zero-initialised full score vectors")
@@ -110,9 +112,9 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if use_dist else 0)
 
-    cfg = dict(dpe.workload.CONFIG_R)
+    cfg = dict(dpe.workload.CONFIG_R if args.config == "R" else dpe.workload.CONFIG_H)
     fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
-    W = args.windows
+    W = args.windows if args.windows else (256 if args.config == "R" else 32)
     iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=0, amp=cfg["amp"])
     pos_g, vel_g, pos, vel, off = dpe.workload.build_grids(G, rank, world)
     write_scores = (not args.no_scores) or args.exchange == "scores"

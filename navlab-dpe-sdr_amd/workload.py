@@ -16,9 +16,80 @@ CONFIG_R = dict(name="R: demofiles twin, 2.5 Msps x 20 ms, 8 SVs, rngrid3-format
                 fs=2.5e6, S=50000, K=8, G=390625, L=4, B=20, amp=48.0)
 
 
+CONFIG_H = dict(name="H: synthetic 25 Msps x 20 ms, 12 SVs, 1e5-point rngrid3-format grids",
+                fs=25e6, S=500000, K=12, G=100000, L=31, B=16, amp=15.2)
+
+_C = 299792458.0
+_FCA = 1.023e6
+_FL1 = 1.57542e9
+_OE = 7.2921151467e-5
+
+
+def extend_handoff(ho, K_total, elev_min_deg=10.0):
+    """Handoff state with K_total SVs: the file's 8 plus synthetic ones (SURVEY.md 8d, K=12 uses PRNs
+    1,5,10,25).  A synthetic SV clones a real ephemeris with shifted OMEGA_0 / M_0; its code phase,
+    reference code period and Doppler are then derived from the geometry with the product's own
+    cuChanMgr restatement so that the extended state is self-consistent at rxTime."""
+    K0 = len(ho["prn_list"])
+    if K_total <= K0:
+        return ho
+    out = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in ho.items()}
+    X = ho["X_ECEF"]
+    R = None
+    have = set(int(q) for q in ho["prn_list"])
+    extra_prns = [p for p in synth.PRNS_H if p not in have]
+    extra_prns += [p for p in range(1, 38) if p not in have and p not in extra_prns]
+    add = dict(prn=[], rc=[], ri=[], fc=[], fi=[], cp=[], cpr=[], tow=[], eph=[])
+    j = 0
+    for trial in range(1, 2000):
+        if len(add["prn"]) == K_total - K0:
+            break
+        eph = ho["eph"][trial % K0].copy()
+        eph[3] += 0.9 * trial      # OMEGA_0
+        eph[5] += 1.7 * trial      # M_0
+        tow = int(ho["TOW"][0])
+        cp, rc, cpr, fc, fi = 1000, 0.0, 1000, _FCA, 0.0
+        ok = True
+        for it in range(4):        # fixed point: transmit time <-> satellite position <-> pseudorange
+            cm = engine.ChanMgr([1], [rc], [0.0], [fc], [fi], [cp], [cpr], [tow], eph[None, :], ho["rxTime"], 0.02)
+            cm.Start(X, X, (0.0,))
+            cm.Update(X, X, (0.0,))
+            s, e, w, batch = cm.outputs(with_batch=True)
+            cm.Stop()
+            sat = e["satState"][0]
+            if R is None:
+                R = w["enu2ecef"][0].reshape(3, 3)
+            los = sat[:3] - X[:3]
+            rng = np.linalg.norm(los)
+            elev = np.degrees(np.arcsin((R.T @ (los / rng))[2]))
+            if elev < elev_min_deg:
+                ok = False
+                break
+            tx = ho["rxTime"] - (rng - _C * sat[3] + X[3]) / _C      # consistent transmit time at rxTime
+            whole = np.floor((tx - tow) * 1000.0)
+            cpr = int(cp - whole)
+            rc = float((tx - tow - whole * 1e-3) * _FCA)
+            fc, fi = float(s["codeFrequency"][0]), float(s["carrierFrequency"][0])   # measurement-updated by Update()
+        if not ok or not (0.0 <= rc < 1023.0):
+            continue
+        add["prn"].append(extra_prns[j]); j += 1
+        add["rc"].append(rc); add["ri"].append(0.25 * trial % 1.0); add["fc"].append(fc); add["fi"].append(fi)
+        add["cp"].append(cp); add["cpr"].append(cpr); add["tow"].append(tow); add["eph"].append(eph)
+    if len(add["prn"]) != K_total - K0:
+        raise RuntimeError("could not place %d synthetic SVs above the horizon" % (K_total - K0))
+    out["prn_list"] = np.concatenate([ho["prn_list"], np.array(add["prn"], dtype=np.int32)])
+    for k, a in (("rc", "rc"), ("ri", "ri"), ("fc", "fc"), ("fi", "fi")):
+        out[k] = np.concatenate([ho[k], np.array(add[a])])
+    out["cp"] = np.concatenate([ho["cp"], np.array(add["cp"], dtype=np.int32)])
+    out["cp_timestamp"] = np.concatenate([ho["cp_timestamp"], np.array(add["cpr"], dtype=np.int32)])
+    out["TOW"] = np.concatenate([ho["TOW"], np.array(add["tow"], dtype=np.int32)])
+    out["eph"] = np.vstack([ho["eph"], np.array(add["eph"])])
+    return out
+
+
 def build_windows(W, fs, S, K, seed=0, amp=48.0):
     """-> iq int16 [W, 2S], chan_start [W,K], chan_end [W,K], bcm_window [W]."""
-    ho = handoff.read_handoff(HANDOFF_CSV)
+    ho = extend_handoff(handoff.read_handoff(HANDOFF_CSV), K)
     cm = engine.ChanMgr.from_handoff(ho, S / fs, K)
     X = ho["X_ECEF"]
     iq = np.empty((W, 2 * S), dtype=np.int16)

@@ -20,8 +20,7 @@ def make_case(seed=0, fs=2.5e6, S=50000, K=8, G=4096, amp=200.0, W=1, grid="rand
     """W consecutive windows on the handoff geometry (static receiver), channel state advanced by
     the oracle's cuChanMgr restatement; I/Q synthesised from each window's start-referenced params."""
     o = _oracle()
-    ho = dpe.handoff.read_handoff(HANDOFF)
-    assert K <= 8
+    ho = dpe.workload.extend_handoff(dpe.handoff.read_handoff(HANDOFF), K)   # K > 8: synthetic extra SVs
     T = S / fs
     X = ho["X_ECEF"].copy()
     sl = slice(0, K)

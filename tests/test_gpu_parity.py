@@ -97,6 +97,19 @@ def test_path_vs_oracle(kw, L, B):
     print("worst rel err", worst)
 
 
+def test_config_h_25msps_12sv():
+    """BASELINE.json configs[2]: 25 Msps x 20 ms (S = 500000, beyond the reference's unsigned-short
+    lengths), 12 SVs, 1e5-point random ENU-dt grid -> +-31 lags, +-16 bins of the 4194304-point FFT."""
+    cfg = dpe.workload.CONFIG_H
+    case = helpers.make_case(seed=21, fs=cfg["fs"], S=cfg["S"], K=cfg["K"], G=cfg["G"], amp=60.0)
+    assert case["C"] == 4194304
+    out = helpers.run_gpu(case, cfg["L"], cfg["B"])
+    ref = helpers.run_oracle(case, cfg["L"], cfg["B"])
+    worst = helpers.assert_parity(out, ref, tol=TOL)
+    assert ref["res"][0]["posOutOfWindow"] == 0 and ref["res"][0]["velOutOfWindow"] == 0
+    print("config H worst rel err", worst)
+
+
 def test_lpower2():
     case = helpers.make_case(seed=7, S=12500, K=4, G=3000, amp=200.0)
     out = helpers.run_gpu(case, 8, 32, lpower=2)
@@ -203,3 +216,80 @@ def test_cpp_flow_matches_python_closed_loop(tmp_path):
     assert np.abs(rows - fixes).max() < 1e-6                       # %f rows vs doubles
     assert np.abs(fixes[:, :3] - ho["X_ECEF"][:3]).max() < 1.0     # position fix within 1 m of truth
     assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res)
+
+
+@pytest.mark.parametrize("kw,L,B", [
+    (dict(seed=31, S=12502, K=3, G=1, amp=200.0), 4, 24),        # one grid point; S not a multiple of 4 (scalar loads)
+    (dict(seed=32, S=12500, K=2, G=1023, amp=200.0), 4, 24),     # one short of a 1024-point tile
+    (dict(seed=33, S=12500, K=2, G=1025, amp=200.0, W=2), 4, 24),  # one over
+    (dict(seed=34, S=10240, K=5, G=2048, amp=100.0, W=2), 16, 24),  # S = 40 exact sub-tiles, LH=16 kernel
+])
+def test_ragged_sizes(kw, L, B):
+    case = helpers.make_case(**kw)
+    out = helpers.run_gpu(case, L, B)
+    ref = helpers.run_oracle(case, L, B)
+    helpers.assert_parity(out, ref, tol=TOL)
+
+
+def test_max_channels_37():
+    """CONST_PRN_MAX = 37 tracked SVs (the reference's allocation stride; PRN 37 itself is generated
+    here although BCS_GenCACode never writes it, batchcorrscores.cu:127)."""
+    case = helpers.make_case(seed=35, S=12500, K=37, G=700, amp=60.0)
+    assert sorted(case["prn"])[-1] == 37
+    out = helpers.run_gpu(case, 8, 24)
+    ref = helpers.run_oracle(case, 8, 24)
+    helpers.assert_parity(out, ref, tol=TOL)
+
+
+def test_window_stride_and_unaligned_base():
+    """Windows separated by padding (stride > S) and a sample pointer that is only 4-byte aligned."""
+    import torch
+    case = helpers.make_case(seed=36, S=12500, K=4, G=600, amp=200.0, W=2)
+    iq, cs, ce, bw = helpers.pack_gpu_inputs(case)
+    S, stride = case["S"], case["S"] + 37
+    buf = np.zeros(1 + 2 * 2 * stride, dtype=np.int16)        # +1 int16 pair offset -> base % 16 == 4
+    base = 2
+    for w in range(2):
+        buf[base + 2 * stride * w: base + 2 * stride * w + 2 * S] = iq[w]
+    d = torch.from_numpy(buf).to("cuda:0")
+    bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=S, lag_half_width=8, bin_half_width=32, max_windows=2, max_channels=4)
+    bcs.Start()
+    bcs.Update(d.data_ptr() + 2 * base, cs, window_stride=stride)
+    code, carr = bcs.read_banks()
+    ref = helpers.run_oracle(case, 8, 32)
+    for w in range(2):
+        assert np.abs(code[w] - ref["code"][w]).max() < TOL * np.abs(ref["code"][w]).max()
+        assert np.abs(carr[w] - ref["carr"][w]).max() < TOL * np.abs(ref["carr"][w]).max()
+    bcs.Stop()
+
+
+def test_argument_errors_are_reported():
+    """0 / -1 status with a [Module]-tagged message; nothing is computed on bad input."""
+    import torch
+    e = dpe.engine
+    with pytest.raises(dpe.DpeError, match="lagHalfWidth"):
+        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, lag_half_width=40).Start()
+    with pytest.raises(dpe.DpeError, match="non-integer-ns"):
+        dpe.BatchCorrScores(2.048e6 * 1.0000001, samples_per_window=40960).Start()
+    with pytest.raises(dpe.DpeError, match="too wide"):
+        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, bin_half_width=400).Start()
+    bcs = dpe.BatchCorrScores(2.5e6, samples_per_window=50000, max_channels=4)
+    bcs.Start()
+    iq = torch.zeros(100000, dtype=torch.int16, device="cuda:0")
+    good = e.chan_start_array([2], [1.0], [0.0], [1.023e6], [0.0], [0], [0])
+    with pytest.raises(dpe.DpeError, match="nChan"):
+        bcs.Update(iq, np.repeat(good, 5))
+    bad = good.copy(); bad["prn"] = 38
+    with pytest.raises(dpe.DpeError, match="PRN"):
+        bcs.Update(iq, bad)
+    bcs.Update(iq, good)          # all-zero samples: finite, zero banks
+    code, carr = bcs.read_banks()
+    assert np.all(code == 0) and np.all(carr == 0)
+    g = dpe.synth.rand_grid(1, 100)
+    with pytest.raises(dpe.DpeError, match="3 km"):
+        dpe.BatchCorrManifold(2.5e6, 50000, bcs.NumFFTPoints, g * 100.0, g).Start()
+    with pytest.raises(dpe.DpeError, match="even"):
+        dpe.BatchCorrManifold(2.5e6, 49999, bcs.NumFFTPoints, g, g).Start()
+    bcs.Stop()
+    with pytest.raises(dpe.DpeError, match="not initialized"):
+        bcs.Update(iq, good)
