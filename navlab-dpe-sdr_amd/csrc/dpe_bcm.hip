@@ -30,10 +30,16 @@ struct BcmSvDev {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kPtsPerThread = 4;
+#ifndef DPE_PTS_PER_THREAD
+#define DPE_PTS_PER_THREAD 4
+#endif
+#ifndef DPE_SV_UNROLL
+#define DPE_SV_UNROLL 2
+#endif
+constexpr int kPtsPerThread = DPE_PTS_PER_THREAD;
 constexpr int kPtsPerBlock = 256 * kPtsPerThread;
 
-template <int LP, bool SECOND>
+template <int LP, bool SECOND, bool CLAMP>
 __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict__ grid, long long G, int K, int nEnt,
                                                        int maxK, int lpower, const BcmSvDev *__restrict__ sv,
                                                        const float2 *__restrict__ bank, float *__restrict__ scores,
@@ -42,7 +48,11 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
                                                        int keyStride, int keySlot)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float4 *sBank = reinterpret_cast<float4 *>(smem);                       // [K][nEnt] {c.re,c.im,d.re,d.im}
+    // |lerp|^2 = A + w (B + w C) per bank entry, split as {A,B} (ds_read_b64) + {C} (ds_read_b32): 4 LDS cycles per
+    // wave access and conflict-free over 32 consecutive entries (a 12/16-byte ds_read_b96/b128 costs 8/4 and
+    // collides every 16 entries)
+    float2 *sAB = reinterpret_cast<float2 *>(smem);                         // [K][nEnt]
+    float *sC = reinterpret_cast<float *>(smem + sizeof(float2) * (size_t)K * nEnt);   // [K][nEnt]
     __shared__ unsigned long long sKey[4];
     __shared__ unsigned int sOob[4];
 
@@ -58,13 +68,17 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
     const float2 *bw = bank + (size_t)w * maxK * nEnt;
     for (int i = tid; i < K * nEnt; i += 256) {
         const int k = i / nEnt, j = i - k * nEnt;
-        // entry nEnt-1 can never be a valid lower neighbour: it is the all-zero slot that
-        // out-of-window indices are clamped to (contribution exactly 0, no select in the loop)
+        // |c0 + w (c1 - c0)|^2 = A + w (B + w C): the interpolated magnitude needs two FMAs per pair.
+        // Entry nEnt-1 can never be a valid lower neighbour: it is the all-zero slot that out-of-window
+        // indices are clamped to (contribution exactly 0).
         if (j + 1 < nEnt) {
             const float2 c0 = bw[(size_t)k * nEnt + j], c1 = bw[(size_t)k * nEnt + j + 1];
-            sBank[i] = make_float4(c0.x, c0.y, c1.x - c0.x, c1.y - c0.y);
+            const float dr = c1.x - c0.x, di = c1.y - c0.y;
+            sAB[i] = make_float2(c0.x * c0.x + c0.y * c0.y, 2.f * (c0.x * dr + c0.y * di));
+            sC[i] = dr * dr + di * di;
         } else {
-            sBank[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sAB[i] = make_float2(0.f, 0.f);
+            sC[i] = 0.f;
         }
     }
     __syncthreads();
@@ -98,10 +112,11 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
                 nxt[it] = (b1 + it * 256 < G) ? grid[b1 + it * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         unsigned emax = 0;
-#pragma unroll 2
+#pragma unroll DPE_SV_UNROLL
         for (int k = 0; k < K; ++k) {
             const BcmSvDev s = svw[k];
-            const float4 *bk = sBank + k * nEnt;
+            const float2 *bkAB = sAB + k * nEnt;
+            const float *bkC = sC + k * nEnt;
 #pragma unroll
             for (int p = 0; p < kPairs; ++p) {
                 f2 a = dx[p] * s.ue;
@@ -120,22 +135,23 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
                     const float wgt = __builtin_amdgcn_fractf(id);                 // id - floor(id)
                     int ei;
                     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ei) : "v"(id));          // (int)floor(id), saturating
-                    const unsigned e = min((unsigned)ei, last);                    // negative -> huge -> zero slot
-                    emax = max(emax, e);
-                    const float4 b = bk[e];
-                    const f2 v = __builtin_elementwise_fma(f2{wgt, wgt}, f2{b.z, b.w}, f2{b.x, b.y});
-                    const f2 vv = v * v;
-                    const float m2 = vv.x + vv.y;
-                    if (LP == 1) c[j] = __builtin_amdgcn_sqrtf(m2);                // raw v_sqrt_f32 (1 ulp)
+                    unsigned e = (unsigned)ei;
+                    if (CLAMP) {                                                   // negative -> huge -> zero slot
+                        e = min(e, last);
+                        emax = max(emax, e);
+                    }
+                    const float2 ab = bkAB[e];
+                    const float m2 = fmaf(wgt, fmaf(wgt, bkC[e], ab.y), ab.x);
+                    if (LP == 1) c[j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(m2));    // raw v_sqrt_f32 (1 ulp)
                     else if (LP == 2) c[j] = m2;
-                    else c[j] = powf(__builtin_amdgcn_sqrtf(m2), (float)lpower);
+                    else c[j] = powf(__builtin_amdgcn_sqrtf(__builtin_fabsf(m2)), (float)lpower);
                 }
                 score[p] += f2{c[0], c[1]};
             }
         }
         // out-of-window bookkeeping off the fast path: recount only if this thread ever hit the zero
         // slot (or owns padding beyond G)
-        if (emax == last || base + (kPtsPerThread - 1) * 256 >= G) {
+        if (CLAMP && (emax == last || base + (kPtsPerThread - 1) * 256 >= G)) {
             for (int it = 0; it < kPtsPerThread; ++it) {
                 if (base + it * 256 >= G) continue;
                 const float px = dx[it >> 1][it & 1], py = dy[it >> 1][it & 1], pz = dz[it >> 1][it & 1];
@@ -196,6 +212,7 @@ struct dpe_bcm {
     unsigned long long *keys_d = nullptr, *oob_d = nullptr;  // [W][2]
     std::vector<dpe_bcm_window> win_h;
     int lastW = 0;
+    double posExtent = 0, velExtent = 0;
     dpe::KernelProfiler prof;  // slots: 0 pos scan, 1 vel scan
 };
 
@@ -224,18 +241,35 @@ static unsigned scan_split(long long G, int nWindows)
     return (unsigned)s;
 }
 
-template <bool SECOND>
-static void launch_scan(int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
-                        int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores, unsigned long long *keys,
-                        unsigned long long *oob, long long off, int slot)
+template <bool SECOND, bool CLAMP>
+static void launch_scan2(int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
+                         int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores, unsigned long long *keys,
+                         unsigned long long *oob, long long off, int slot)
 {
     using namespace dpe;
     if (lp == 1)
-        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND, CLAMP>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
     else if (lp == 2)
-        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND, CLAMP>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
     else
-        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND, CLAMP>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+}
+
+// clamp = false only when the host has proved that every index of every (point, SV) pair stays inside
+// the bank (then the kernel drops the range clamp and the out-of-window bookkeeping)
+template <bool SECOND>
+static void launch_scan(bool clamp, int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K,
+                        int nEnt, int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores,
+                        unsigned long long *keys, unsigned long long *oob, long long off, int slot)
+{
+    if (clamp) launch_scan2<SECOND, true>(lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot);
+    else launch_scan2<SECOND, false>(lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot);
+}
+
+template <int LP, bool SECOND, bool CLAMP>
+static void allow_big_lds()
+{
+    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, SECOND, CLAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
 }
 
 extern "C" {
@@ -259,16 +293,25 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
                            ((size_t)(2 * (cfg->lagHalfWidth > cfg->binHalfWidth ? cfg->lagHalfWidth : cfg->binHalfWidth) + 1) * 16 + 32);
     DPE_REQUIRE(ldsNeed <= 150 * 1024, "[BatchCorrManifold] create: score banks (%zu B) exceed the 160 KB LDS", ldsNeed);
     // validity of the range expansion (file header): |delta| must stay far below the SV range
-    double maxR2 = 0;
+    double maxR2 = 0, posExt = 0, velExt = 0;   // extents: max(|delta_xyz| + |delta_t|), bounds |delta_t - u.delta|
     for (int64_t i = 0; i < cfg->posGridSize; ++i) {
         const double *p = cfg->posGrid + 4 * i;
         const double r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
         if (r2 > maxR2) maxR2 = r2;
+        const double e = std::sqrt(r2) + std::fabs(p[3]);
+        if (e > posExt) posExt = e;
+    }
+    for (int64_t i = 0; i < cfg->velGridSize; ++i) {
+        const double *p = cfg->velGrid + 4 * i;
+        const double e = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + std::fabs(p[3]);
+        if (e > velExt) velExt = e;
     }
     DPE_REQUIRE(maxR2 < 3.0e3 * 3.0e3, "[BatchCorrManifold] create: position grid extends beyond 3 km from its centre");
     dpe_bcm *h = new dpe_bcm();
     h->cfg = *cfg;
     h->cfg.posGrid = h->cfg.velGrid = nullptr;
+    h->posExtent = posExt * 1.000001 + maxR2 / 2.0e7 + 1e-3;   // + second-order term bound (range > 2e7 m) + fp32 slack
+    h->velExtent = velExt * 1.000001 + 1e-6;
     const size_t W = cfg->maxWindows, K = cfg->maxChannels;
     if (upload_grid(cfg->posGrid, cfg->posGridSize, h->posGrid_h, &h->posGrid_d) ||
         upload_grid(cfg->velGrid, cfg->velGridSize, h->velGrid_h, &h->velGrid_d)) {
@@ -289,13 +332,10 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
         return -1;
     }
     // dynamic LDS above 64 KB needs the opt-in attribute
-    const int maxLds = 155 * 1024;
-    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-    (void)hipFuncSetAttribute((const void *)bcm_scan_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+    allow_big_lds<0, true, true>();  allow_big_lds<1, true, true>();  allow_big_lds<2, true, true>();
+    allow_big_lds<0, false, true>(); allow_big_lds<1, false, true>(); allow_big_lds<2, false, true>();
+    allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
+    allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
     h->win_h.resize(W);
     *out = h;
     return 0;
@@ -322,6 +362,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     const int S = h->cfg.samplesPerWindow, L = h->cfg.lagHalfWidth, B = h->cfg.binHalfWidth;
     const int maxK = h->cfg.maxChannels, W = h->cfg.maxWindows;
     const double fs = h->cfg.samplingFrequency, Cf = (double)h->cfg.numFFTPoints;
+    bool posInside = true, velInside = true;   // every index provably inside the banks?
     for (int w = 0; w < nWindows; ++w) {
         const dpe_bcm_window &win = win_host[w];
         DPE_REQUIRE(win.dopplerSign == 1 || win.dopplerSign == -1, "[BatchCorrManifold] Update: dopplerSign must be +/-1");
@@ -350,6 +391,10 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
             p.h = (float)(0.5 / range);
             p.idx0 = (float)(basePos - (double)(S / 2 - L));
             p.pad0 = p.pad1 = 0.f;
+            {
+                const double reach = std::fabs((double)p.g) * h->posExtent + 1e-3;
+                if (!((double)p.idx0 - reach >= 0.0 && (double)p.idx0 + reach < (double)(2 * L))) posInside = false;
+            }
             // velocity manifold, centre index (:1917-1936)
             const double ex = c[4] - kOEDot * c[1], ey = c[5] + kOEDot * c[0], ez = c[6];
             const double lrr = ux * (ex - s[4]) + uy * (ey - s[5]) + uz * (ez - s[6]);
@@ -362,6 +407,10 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
             v.h = 0.f;
             v.idx0 = (float)(baseVel - (double)(h->cfg.numFFTPoints / 2 - B));
             v.pad0 = v.pad1 = 0.f;
+            {
+                const double reach = std::fabs(gv) * h->velExtent + 1e-3;
+                if (!((double)v.idx0 - reach >= 0.0 && (double)v.idx0 + reach < (double)(2 * B))) velInside = false;
+            }
         }
     }
     h->lastW = nWindows;
@@ -373,9 +422,9 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     {
         const long long G = h->cfg.posGridSize;
         const dim3 grid(scan_split(G, nWindows), nWindows);
-        const size_t lds = (size_t)nChan * nLag * sizeof(float4);
+        const size_t lds = (size_t)nChan * nLag * 12;
         h->prof.begin(0, stream);
-        launch_scan<true>(h->cfg.lPower, grid, lds, stream, h->posGrid_d, G, nChan, nLag, maxK, h->sv_d,
+        launch_scan<true>(!posInside, h->cfg.lPower, grid, lds, stream, h->posGrid_d, G, nChan, nLag, maxK, h->sv_d,
                           reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, h->keys_d, h->oob_d,
                           h->cfg.posGridIndexOffset, 0);
         h->prof.end(0, stream);
@@ -383,9 +432,9 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     {
         const long long G = h->cfg.velGridSize;
         const dim3 grid(scan_split(G, nWindows), nWindows);
-        const size_t lds = (size_t)nChan * nBin * sizeof(float4);
+        const size_t lds = (size_t)nChan * nBin * 12;
         h->prof.begin(1, stream);
-        launch_scan<false>(h->cfg.lPower, grid, lds, stream, h->velGrid_d, G, nChan, nBin, maxK,
+        launch_scan<false>(!velInside, h->cfg.lPower, grid, lds, stream, h->velGrid_d, G, nChan, nBin, maxK,
                            h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev), h->velScores_d,
                            h->keys_d, h->oob_d, h->cfg.velGridIndexOffset, 1);
         h->prof.end(1, stream);
