@@ -23,7 +23,7 @@
 namespace dpe {
 
 constexpr int kSub = 256;   // samples per wave sub-tile (4 per lane) == moment block
-constexpr int kNMom = 6;    // power moments 0..5
+constexpr int kNMomMax = 6;  // power moments 0..5 at most; 4 when the bin window is narrow (chosen at create)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct BcsChanDev {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-template <int LH>
+template <int LH, int kNMom>
 __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
                                                        int K, int nSub, int tilesPerBlock, int nBlk, int vecOK,
                                                        const BcsChanDev *__restrict__ chan,
@@ -91,14 +91,15 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
     constexpr int NL = 2 * LH + 1;      // lags
     constexpr int NREP = kSub + 2 * LH;  // replica entries per sub-tile (with halo)
     constexpr int NRR = 4 + 2 * LH;      // entries one lane touches
-    __shared__ int8_t sChips[1024];
+    __shared__ float sChips[2048];   // chips as +/-1.0f, periodically extended: sChips[i] = chip[i mod 1023]
     __shared__ __align__(16) float sRep[4][NREP + 4];
     __shared__ float2 sAcc[4][NL];
 
     const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const BcsChanDev ch = chan[w * K + k];
-    for (int i = tid; i < 1024; i += 256) sChips[i] = chipTable[(ch.prn - 1) * 1024 + i];
+    for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
+    const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;   // chip span of one sub-tile fits the extended table
     // DC mean = sum / (float)S in fp64 (batchcorrscores.cu:1065-1066,1210-1216), then fp32
     const float mRe = (float)((double)sums[2 * w] / (double)(float)S);
     const float mIm = (float)((double)sums[2 * w + 1] / (double)(float)S);
@@ -122,25 +123,10 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
                 if (!ch.hasFlip) active = (side == 0);
                 else if (lo >= 0 && hi < S) active = (side == 0) ? (lo < ch.idxNext) : (hi >= ch.idxNext);
             }
+            // samples first: the global-load latency is covered by the replica build below
+            const int n0 = sub0 + 4 * lane;
+            float re[4], im[4];
             if (active) {
-                // replica r[m] = chip[floor(t_m fc + rc) mod 1023] (BCS_ComputeCodeReplica :347-349),
-                // masked to this side of the nav-bit boundary (:352-367), m wrapped circularly.
-                for (int e = lane; e < NREP; e += 64) {
-                    int m = lo + e;
-                    if (m < 0) m += S; else if (m >= S) m -= S;
-                    const double cph = fma((double)m, ch.codeStep, ch.rc);
-                    const int ci = ((int)floor(cph)) % kLCA;
-                    const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
-                    sRep[wave][e] = (sd == side) ? (float)sChips[ci] : 0.f;
-                }
-            }
-            // no barrier: sRep[wave] is private to this wave and a wave's DS operations complete in order
-            f2 M[kNMom];
-#pragma unroll
-            for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
-            if (active) {
-                const int n0 = sub0 + 4 * lane;
-                float re[4], im[4];
                 if (vecOK && n0 + 3 < S) {
                     const int4 v = *reinterpret_cast<const int4 *>(x + 2 * (size_t)n0);
                     re[0] = (float)(short)(v.x & 0xFFFF); im[0] = (float)(v.x >> 16);
@@ -156,6 +142,39 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
                         im[i] = (float)(v >> 16);
                     }
                 }
+            }
+            if (active) {
+                // replica r[m] = chip[floor(t_m fc + rc) mod 1023] (BCS_ComputeCodeReplica :347-349),
+                // masked to this side of the nav-bit boundary (:352-367), m wrapped circularly.
+                if (fastIdx && lo >= 0 && hi < S) {
+                    // common case (no circular wrap inside the sub-tile): the chip index relative to the
+                    // sub-tile's first entry indexes the periodically extended table -- no modulo, no branch
+                    const int ci0 = (int)floor(fma((double)lo, ch.codeStep, ch.rc));
+                    const int shift = (ci0 % kLCA) - ci0;
+                    const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
+                    for (int e = lane; e < NREP; e += 64) {
+                        const int m = lo + e;
+                        const int ci = (int)floor(fma((double)m, ch.codeStep, ch.rc)) + shift;
+                        float r = sChips[ci];
+                        if (straddle) r = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
+                        sRep[wave][e] = r;
+                    }
+                } else {
+                    for (int e = lane; e < NREP; e += 64) {
+                        int m = lo + e;
+                        if (m < 0) m += S; else if (m >= S) m -= S;
+                        const double cph = fma((double)m, ch.codeStep, ch.rc);
+                        const int ci = ((int)floor(cph)) % kLCA;
+                        const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
+                        sRep[wave][e] = (sd == side) ? sChips[ci] : 0.f;
+                    }
+                }
+            }
+            // no barrier: sRep[wave] is private to this wave and a wave's DS operations complete in order
+            f2 M[kNMom];
+#pragma unroll
+            for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
+            if (active) {
                 // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300):
                 // fp64 phase seed per lane, hardware sin/cos in revolutions, 3 fp32 rotations.
                 double ph = fma((double)n0, ch.carrStep, ch.ri);
@@ -236,6 +255,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
 
 // ------------------------------------------------------------------------------------------
 // blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
+template <int kNMom>
 __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSub, int nBlk, int LH, int L, int B,
                                                            long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
@@ -351,7 +371,7 @@ __global__ void bcs_export_kernel(const float2 *__restrict__ bank, int n, long l
 struct dpe_bcs {
     dpe_bcs_config cfg;
     int LH;             // internal lag half width (4,8,16,32)
-    int nSub, nBlk, tilesPerBlock;
+    int nSub, nBlk, tilesPerBlock, nMom;
     long long C;
     int8_t *chipTable_d = nullptr;
     long long *sums_d = nullptr;
@@ -388,6 +408,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     const long long C = 8 * next_pow2(S);  // batchcorrscores.cu:761
     // Taylor remainder of the moment expansion must stay below fp32 rounding (see file header)
     const double th = 6.283185307179586 * 127.5 * cfg->binHalfWidth / (double)C;
+    const int nMom = (std::pow(th, 4) / 24.0 < 1e-7) ? 4 : 6;   // Taylor order of the moment expansion
     DPE_REQUIRE(std::pow(th, 6) / 720.0 < 2e-7,
                 "[BatchCorrScores] create: binHalfWidth %d too wide for the moment expansion at C=%lld",
                 cfg->binHalfWidth, C);
@@ -402,6 +423,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     dpe_bcs *h = new dpe_bcs();
     h->cfg = *cfg;
     h->C = C;
+    h->nMom = nMom;
     h->LH = cfg->lagHalfWidth <= 4 ? 4 : cfg->lagHalfWidth <= 8 ? 8 : cfg->lagHalfWidth <= 16 ? 16 : 32;
     h->nSub = (S + kSub - 1) / kSub;
     const int nTiles = (h->nSub + 3) / 4;
@@ -414,7 +436,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->sums_d = dev_alloc<long long>(2 * W);
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     h->part_d = dev_alloc<float2>(W * K * h->nBlk * 2 * (2 * h->LH + 1));
-    h->mom_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMom);
+    h->mom_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMomMax);
     h->codeBank_d = dev_alloc<float2>(W * K * (2 * cfg->lagHalfWidth + 1));
     h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
     h->info_d = dev_alloc<int>(W * K);
@@ -490,11 +512,16 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     if (tpb > 16) tpb = 16;
     const int nBlk = (nTiles + tpb - 1) / tpb;
     const dim3 grid(nBlk, nChan, nWindows), block(256);
-#define DPE_LAUNCH_BANK(LHV)                                                                                     \
-    hipLaunchKernelGGL(bcs_bank_kernel<LHV>, grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
+#define DPE_LAUNCH_BANK2(LHV, NM)                                                                                       \
+    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, \
                        h->part_d, h->mom_d)
     h->prof.begin(1, stream);
+#define DPE_LAUNCH_BANK(LHV)            \
+    do {                                \
+        if (h->nMom == 4) DPE_LAUNCH_BANK2(LHV, 4); \
+        else DPE_LAUNCH_BANK2(LHV, 6);  \
+    } while (0)
     switch (h->LH) {
         case 4: DPE_LAUNCH_BANK(4); break;
         case 8: DPE_LAUNCH_BANK(8); break;
@@ -502,12 +529,18 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         default: DPE_LAUNCH_BANK(32); break;
     }
 #undef DPE_LAUNCH_BANK
+#undef DPE_LAUNCH_BANK2
     h->prof.end(1, stream);
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 63) / 64;
-    hipLaunchKernelGGL(bcs_finalize_kernel, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
-                       nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
-                       h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
+    if (h->nMom == 4)
+        hipLaunchKernelGGL(bcs_finalize_kernel<4>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
+                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
+                           h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
+    else
+        hipLaunchKernelGGL(bcs_finalize_kernel<6>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
+                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
+                           h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);
     DPE_CHECK_HIP(hipGetLastError());
     return 0;
