@@ -125,7 +125,7 @@ typedef struct dpe_bcm_config {
     int64_t posGridIndexOffset;
     int64_t velGridIndexOffset;
     int32_t writeScores;        /* 1: keep per-point fp32 scores (PosScores port), 0: arg-max only */
-    int32_t reserved;
+    int32_t weightedMean;       /* 1: also accumulate the "Method 1" score-weighted mean (see dpe_bcm_result) */
 } dpe_bcm_config;
 
 /* Per-window inputs of BatchCorrManifold::Update (batchcorrmanifold.cu:2261-2279,2512-2540). */
@@ -157,6 +157,12 @@ typedef struct dpe_bcm_result {
     float velScore;
     int64_t posOutOfWindow;     /* (point,SV) pairs whose index left the bank (reference: UB) */
     int64_t velOutOfWindow;
+    /* "Method 1" of BatchCorrManifold::Update (:2546-2567, kernels :816-1056,1365-1510; what PyGNSS'
+     * folded dp_measurement_estimation does, receiver.py:317-318): score-weighted mean state.
+     * weightedSums[m] = {sum s, sum s*x, sum s*y, sum s*z, sum s*t} over the local shard of manifold m
+     * (ENU offsets; all-reduce(SUM) them across shards), zValMean = the resulting ECEF state. */
+    double zValMean[8];
+    double weightedSums[2][5];
 } dpe_bcm_result;
 
 int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out);     /* BatchCorrManifold::Start :2315-2463 */

@@ -39,13 +39,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPtsPerThread = DPE_PTS_PER_THREAD;
 constexpr int kPtsPerBlock = 256 * kPtsPerThread;
 
-template <int LP, bool SECOND, bool CLAMP>
+template <int LP, bool SECOND, bool CLAMP, bool WMEAN>
 __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict__ grid, long long G, int K, int nEnt,
                                                        int maxK, int lpower, const BcmSvDev *__restrict__ sv,
                                                        const float2 *__restrict__ bank, float *__restrict__ scores,
                                                        unsigned long long *__restrict__ keys,
                                                        unsigned long long *__restrict__ oob, long long indexOffset,
-                                                       int keyStride, int keySlot)
+                                                       int keyStride, int keySlot, double *__restrict__ wsum)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // |lerp|^2 = A + w (B + w C) per bank entry, split as {A,B} (ds_read_b64) + {C} (ds_read_b32): 4 LDS cycles per
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
     float *sC = reinterpret_cast<float *>(smem + sizeof(float2) * (size_t)K * nEnt);   // [K][nEnt]
     __shared__ unsigned long long sKey[4];
     __shared__ unsigned int sOob[4];
+    __shared__ double sW[4][5];
 
     const int w = blockIdx.y, tid = threadIdx.x;
     // first tile's grid points: issued before the bank fill so both latencies overlap
@@ -95,6 +96,8 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
     const long long nTiles = (G + kPtsPerBlock - 1) / kPtsPerBlock;
     unsigned long long best = 0ull;
     unsigned int nOob = 0;
+    // "Method 1" weighted-mean estimator (optional: wsum != nullptr): sum s, sum s*{x,y,z,t}, pair-packed fp32
+    f2 w0 = f2{0.f, 0.f}, w1 = w0, w2 = w0, w3 = w0, w4 = w0;
     for (long long tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
         const long long base = tile * kPtsPerBlock + tid;
         f2 dx[kPairs], dy[kPairs], dz[kPairs], dw[kPairs], q[kPairs], score[kPairs];
@@ -168,6 +171,21 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
                 }
             }
         }
+        if (WMEAN) {
+#pragma unroll
+            for (int p = 0; p < kPairs; ++p) {
+                f2 sc = score[p];
+                if (base + (kPtsPerThread - 1) * 256 >= G) {   // ragged last tile: padded points must not count
+                    if (base + (2 * p) * 256 >= G) sc.x = 0.f;
+                    if (base + (2 * p + 1) * 256 >= G) sc.y = 0.f;
+                }
+                w0 += sc;
+                w1 = __builtin_elementwise_fma(sc, dx[p], w1);
+                w2 = __builtin_elementwise_fma(sc, dy[p], w2);
+                w3 = __builtin_elementwise_fma(sc, dz[p], w3);
+                w4 = __builtin_elementwise_fma(sc, dw[p], w4);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < kPtsPerThread; ++it) {
             const long long i = base + it * 256;
@@ -187,7 +205,22 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
         best = o > best ? o : best;
         nOob += __shfl_xor(nOob, off, 64);
     }
-    if ((tid & 63) == 0) { sKey[tid >> 6] = best; sOob[tid >> 6] = nOob; }
+    double ws[5] = {(double)w0.x + (double)w0.y, (double)w1.x + (double)w1.y, (double)w2.x + (double)w2.y,
+                    (double)w3.x + (double)w3.y, (double)w4.x + (double)w4.y};
+    if (WMEAN) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ws[j] += __shfl_xor(ws[j], off, 64);
+        }
+    }
+    if ((tid & 63) == 0) {
+        sKey[tid >> 6] = best; sOob[tid >> 6] = nOob;
+        if (WMEAN) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) sW[tid >> 6][j] = ws[j];
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         unsigned long long b = sKey[0];
@@ -195,6 +228,12 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
         b = sKey[2] > b ? sKey[2] : b;
         b = sKey[3] > b ? sKey[3] : b;
         atomicMax(&keys[(size_t)w * keyStride + keySlot], b);  // integer max: order-independent
+        // per-block partial of the weighted sums, reduced on the host in block order (deterministic)
+        if (WMEAN) {
+            double *o = wsum + ((size_t)w * gridDim.x + blockIdx.x) * 5;   // wsum already points at this manifold's half
+#pragma unroll
+            for (int j = 0; j < 5; ++j) o[j] = ((sW[0][j] + sW[1][j]) + sW[2][j]) + sW[3][j];
+        }
         const unsigned int n = sOob[0] + sOob[1] + sOob[2] + sOob[3];
         if (n) atomicAdd(&oob[(size_t)w * keyStride + keySlot], (unsigned long long)n);
     }
@@ -210,6 +249,10 @@ struct dpe_bcm {
     float *posScores_d = nullptr, *velScores_d = nullptr;
     dpe::BcmSvDev *sv_d = nullptr, *sv_h = nullptr;  // [2][W][maxK]  (manifold-major)
     unsigned long long *keys_d = nullptr, *oob_d = nullptr;  // [W][2]
+    double *wsum_d = nullptr;   // [W][2][split][5] per-block weighted sums
+    unsigned lastSplit[2] = {0, 0};
+    static constexpr unsigned kMaxSplit = 4096;
+    size_t wsumHalf = 0;
     std::vector<dpe_bcm_window> win_h;
     int lastW = 0;
     double posExtent = 0, velExtent = 0;
@@ -241,35 +284,39 @@ static unsigned scan_split(long long G, int nWindows)
     return (unsigned)s;
 }
 
-template <bool SECOND, bool CLAMP>
-static void launch_scan2(int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
+template <bool SECOND, bool CLAMP, bool WMEAN>
+static void launch_scan3(int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
                          int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores, unsigned long long *keys,
-                         unsigned long long *oob, long long off, int slot)
+                         unsigned long long *oob, long long off, int slot, double *wsum)
 {
     using namespace dpe;
     if (lp == 1)
-        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND, CLAMP>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
     else if (lp == 2)
-        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND, CLAMP>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
     else
-        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND, CLAMP>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot);
+        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
 }
 
 // clamp = false only when the host has proved that every index of every (point, SV) pair stays inside
-// the bank (then the kernel drops the range clamp and the out-of-window bookkeeping)
+// the bank (then the kernel drops the range clamp and the out-of-window bookkeeping); wsum != nullptr
+// selects the variant that also accumulates the weighted-mean sums
 template <bool SECOND>
 static void launch_scan(bool clamp, int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K,
                         int nEnt, int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores,
-                        unsigned long long *keys, unsigned long long *oob, long long off, int slot)
+                        unsigned long long *keys, unsigned long long *oob, long long off, int slot, double *wsum)
 {
-    if (clamp) launch_scan2<SECOND, true>(lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot);
-    else launch_scan2<SECOND, false>(lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot);
+#define DPE_SCAN_ARGS lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot, wsum
+    if (clamp) { if (wsum) launch_scan3<SECOND, true, true>(DPE_SCAN_ARGS); else launch_scan3<SECOND, true, false>(DPE_SCAN_ARGS); }
+    else { if (wsum) launch_scan3<SECOND, false, true>(DPE_SCAN_ARGS); else launch_scan3<SECOND, false, false>(DPE_SCAN_ARGS); }
+#undef DPE_SCAN_ARGS
 }
 
 template <int LP, bool SECOND, bool CLAMP>
 static void allow_big_lds()
 {
-    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, SECOND, CLAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, SECOND, CLAMP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, SECOND, CLAMP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
 }
 
 extern "C" {
@@ -325,7 +372,9 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->sv_d = dev_alloc<BcmSvDev>(2 * W * K);
     h->keys_d = dev_alloc<unsigned long long>(2 * W);
     h->oob_d = dev_alloc<unsigned long long>(2 * W);
-    if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->oob_d ||
+    h->wsumHalf = (size_t)(dpe_bcm::kMaxSplit + 8 * W) * 5;   // >= nWindows * blocks-per-window of any launch
+    h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
+    if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->oob_d || !h->wsum_d ||
         hipHostMalloc((void **)&h->sv_h, 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
         dpe_bcm_destroy(h);
@@ -344,7 +393,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
 int dpe_bcm_destroy(dpe_bcm *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->oob_d};
+    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->oob_d, h->wsum_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->sv_h) (void)hipHostFree(h->sv_h);
     delete h;
@@ -422,21 +471,24 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     {
         const long long G = h->cfg.posGridSize;
         const dim3 grid(scan_split(G, nWindows), nWindows);
+        h->lastSplit[0] = grid.x;
         const size_t lds = (size_t)nChan * nLag * 12;
         h->prof.begin(0, stream);
         launch_scan<true>(!posInside, h->cfg.lPower, grid, lds, stream, h->posGrid_d, G, nChan, nLag, maxK, h->sv_d,
                           reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, h->keys_d, h->oob_d,
-                          h->cfg.posGridIndexOffset, 0);
+                          h->cfg.posGridIndexOffset, 0, h->cfg.weightedMean ? h->wsum_d : nullptr);
         h->prof.end(0, stream);
     }
     {
         const long long G = h->cfg.velGridSize;
         const dim3 grid(scan_split(G, nWindows), nWindows);
+        h->lastSplit[1] = grid.x;
         const size_t lds = (size_t)nChan * nBin * 12;
         h->prof.begin(1, stream);
         launch_scan<false>(!velInside, h->cfg.lPower, grid, lds, stream, h->velGrid_d, G, nChan, nBin, maxK,
                            h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev), h->velScores_d,
-                           h->keys_d, h->oob_d, h->cfg.velGridIndexOffset, 1);
+                           h->keys_d, h->oob_d, h->cfg.velGridIndexOffset, 1,
+                           h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr);
         h->prof.end(1, stream);
     }
     DPE_CHECK_HIP(hipGetLastError());
@@ -471,8 +523,28 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
     std::vector<unsigned long long> keys(2 * W), oob(2 * W);
     DPE_CHECK_HIP(hipMemcpy(keys.data(), h->keys_d, sizeof(unsigned long long) * 2 * W, hipMemcpyDeviceToHost));
     DPE_CHECK_HIP(hipMemcpy(oob.data(), h->oob_d, sizeof(unsigned long long) * 2 * W, hipMemcpyDeviceToHost));
+    std::vector<double> ws(2 * h->wsumHalf, 0.0);
+    if (h->cfg.weightedMean)
+        DPE_CHECK_HIP(hipMemcpy(ws.data(), h->wsum_d, sizeof(double) * 2 * h->wsumHalf, hipMemcpyDeviceToHost));
     for (int w = 0; w < W; ++w) {
         dpe_bcm_result &r = results[w];
+        // "Method 1" score-weighted mean of the manifold (BCM_PosMeasReduction / BCM_ReduceAndPosMeas,
+        // batchcorrmanifold.cu:816-1056,1365-1510; PyGNSS receiver.py:317-318): LOCAL shard only
+        double m[2][5];
+        for (int slot = 0; slot < 2; ++slot) {
+            for (int j = 0; j < 5; ++j) m[slot][j] = 0.0;
+            const double *base = ws.data() + slot * h->wsumHalf + (size_t)w * h->lastSplit[slot] * 5;
+            for (unsigned b = 0; b < h->lastSplit[slot]; ++b)
+                for (int j = 0; j < 5; ++j) m[slot][j] += base[(size_t)b * 5 + j];
+            for (int j = 0; j < 5; ++j) r.weightedSums[slot][j] = m[slot][j];
+        }
+        if (!h->cfg.weightedMean) {
+            for (int j = 0; j < 8; ++j) r.zValMean[j] = 0.0;
+        } else {
+            const double pm[4] = {m[0][1] / m[0][0], m[0][2] / m[0][0], m[0][3] / m[0][0], m[0][4] / m[0][0]};
+            const double vm[4] = {m[1][1] / m[1][0], m[1][2] / m[1][0], m[1][3] / m[1][0], m[1][4] / m[1][0]};
+            make_meas(h->win_h[w], pm, vm, r.zValMean);
+        }
         decode_key(keys[2 * w], &r.posScore, &r.posIndex);
         decode_key(keys[2 * w + 1], &r.velScore, &r.velIndex);
         r.posOutOfWindow = (int64_t)oob[2 * w];
@@ -525,6 +597,8 @@ int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWi
         decode_key(keys_host[2 * w], &r.posScore, &r.posIndex);
         decode_key(keys_host[2 * w + 1], &r.velScore, &r.velIndex);
         r.posOutOfWindow = r.velOutOfWindow = -1;
+        for (int j = 0; j < 8; ++j) r.zValMean[j] = 0.0;   // needs the all-reduced weightedSums; see sharding.py
+        for (int j = 0; j < 10; ++j) (&r.weightedSums[0][0])[j] = 0.0;
         make_meas(h->win_h[w], posGridGlobal + 4 * r.posIndex, velGridGlobal + 4 * r.velIndex, r.zVal);
     }
     return 0;

@@ -49,7 +49,7 @@ class BcmConfig(C.Structure):
                 ("posGrid", C.POINTER(C.c_double)), ("velGrid", C.POINTER(C.c_double)),
                 ("posGridSize", C.c_int64), ("velGridSize", C.c_int64),
                 ("posGridIndexOffset", C.c_int64), ("velGridIndexOffset", C.c_int64),
-                ("writeScores", C.c_int32), ("reserved", C.c_int32)]
+                ("writeScores", C.c_int32), ("weightedMean", C.c_int32)]
 
 
 class BcmWindow(C.Structure):
@@ -66,7 +66,7 @@ class ChanEnd(C.Structure):
 class BcmResult(C.Structure):
     _fields_ = [("zVal", C.c_double * 8), ("posIndex", C.c_int64), ("velIndex", C.c_int64),
                 ("posScore", C.c_float), ("velScore", C.c_float), ("posOutOfWindow", C.c_int64),
-                ("velOutOfWindow", C.c_int64)]
+                ("velOutOfWindow", C.c_int64), ("zValMean", C.c_double * 8), ("weightedSums", (C.c_double * 5) * 2)]
 
 
 CHAN_START_DTYPE = np.dtype([("codePhaseStart", "<f8"), ("carrierPhaseStart", "<f8"), ("codeFrequency", "<f8"),
@@ -258,13 +258,14 @@ class BatchCorrManifold:
 
     def __init__(self, SamplingFrequency, samples_per_window, NumFFTPoints, pos_grid, vel_grid, LPower=1,
                  lag_half_width=8, bin_half_width=48, max_windows=1, max_channels=8, write_scores=True,
-                 pos_index_offset=0, vel_index_offset=0):
+                 pos_index_offset=0, vel_index_offset=0, weighted_mean=False):
         self.fs, self.S, self.C = float(SamplingFrequency), int(samples_per_window), int(NumFFTPoints)
         self.pos_grid = np.ascontiguousarray(pos_grid, dtype=np.float64)
         self.vel_grid = np.ascontiguousarray(vel_grid, dtype=np.float64)
         self.LPower, self.L, self.B = int(LPower), int(lag_half_width), int(bin_half_width)
         self.max_windows, self.max_channels = int(max_windows), int(max_channels)
         self.write_scores = bool(write_scores)
+        self.weighted_mean = bool(weighted_mean)
         self.pos_off, self.vel_off = int(pos_index_offset), int(vel_index_offset)
         self._h = C.c_void_p(None)
         self.Started = False
@@ -276,7 +277,7 @@ class BatchCorrManifold:
                         self.pos_grid.ctypes.data_as(C.POINTER(C.c_double)),
                         self.vel_grid.ctypes.data_as(C.POINTER(C.c_double)),
                         self.pos_grid.shape[0], self.vel_grid.shape[0], self.pos_off, self.vel_off,
-                        1 if self.write_scores else 0, 0)
+                        1 if self.write_scores else 0, 1 if self.weighted_mean else 0)
         _check(lib().dpe_bcm_create(C.byref(cfg), C.byref(self._h)))
         self.PosScores = self.VelScores = None
         if self.write_scores:
@@ -311,7 +312,8 @@ class BatchCorrManifold:
         _check(lib().dpe_bcm_results(self._h, res, _stream(stream)))
         return [dict(zVal=np.array(r.zVal), RVal=np.eye(8), posIndex=r.posIndex, velIndex=r.velIndex,
                      posScore=r.posScore, velScore=r.velScore, posOutOfWindow=r.posOutOfWindow,
-                     velOutOfWindow=r.velOutOfWindow) for r in res]
+                     velOutOfWindow=r.velOutOfWindow, zValMean=np.array(r.zValMean),
+                     weightedSums=np.array([list(r.weightedSums[0]), list(r.weightedSums[1])])) for r in res]
 
     def results_from_keys(self, keys_host, pos_grid_global, vel_grid_global):
         keys_host = np.ascontiguousarray(keys_host, dtype=np.uint64)

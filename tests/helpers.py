@@ -90,6 +90,9 @@ def run_oracle(case, L, B, lpower=1, windows=None):
         out["vel"].append(sv)
         out["info"].append(info)
         out["res"].append(dict(posIndex=ip, velIndex=iv, zVal=z, posOutOfWindow=oobp, velOutOfWindow=oobv))
+        out.setdefault("R", []).append(w["R"])
+        out.setdefault("centre", []).append(w["centre"])
+    out["pos_grid"], out["vel_grid"] = case["pos"], case["vel"]
     return out
 
 
@@ -105,7 +108,7 @@ def pack_gpu_inputs(case):
     return iq, cs, ce, bw
 
 
-def run_gpu(case, L, B, lpower=1, write_scores=True):
+def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True):
     import torch
     iq, cs, ce, bw = pack_gpu_inputs(case)
     W, K = cs.shape
@@ -116,7 +119,7 @@ def run_gpu(case, L, B, lpower=1, write_scores=True):
     bcs.Start()
     bcm = dpe.BatchCorrManifold(case["fs"], case["S"], bcs.NumFFTPoints, case["pos"], case["vel"], LPower=lpower,
                                 lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K,
-                                write_scores=write_scores)
+                                write_scores=write_scores, weighted_mean=weighted_mean)
     bcm.Start()
     bcs.Update(iq_d, cs)
     bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
@@ -170,4 +173,11 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
         if gr["posIndex"] == rr["posIndex"] and gr["velIndex"] == rr["velIndex"]:
             assert np.abs(gr["zVal"] - rr["zVal"]).max() < 1e-6     # same grid point -> same fix
         assert gr["posOutOfWindow"] == rr["posOutOfWindow"] and gr["velOutOfWindow"] == rr["velOutOfWindow"]
+        if "zValMean" in gr and "pos_grid" in ref and np.any(gr["zValMean"] != 0):   # "Method 1" weighted-mean estimator vs fp64 sums of the oracle scores
+            zp = (ref["pos_x"][w][:, None] * ref["pos_grid"]).sum(0) / ref["pos_x"][w].sum()
+            zv = (ref["vel"][w][:, None] * ref["vel_grid"]).sum(0) / ref["vel"][w].sum()
+            R = ref["R"][w].reshape(3, 3)
+            c = ref["centre"][w]
+            zm = np.concatenate([R @ zp[:3] + c[:3], [zp[3] + c[3]], R @ zv[:3] + c[4:7], [zv[3] + c[7]]])
+            assert np.abs(gr["zValMean"][:4] - zm[:4]).max() < 1e-3 and np.abs(gr["zValMean"][4:] - zm[4:]).max() < 1e-4
     return worst
