@@ -217,6 +217,39 @@ int dpe_chm_update(dpe_chanmgr *h, const double *xk1k1, const double *xkk1, cons
 int dpe_chm_outputs(dpe_chanmgr *h, dpe_chan_start *start, dpe_chan_end *end, dpe_bcm_window *win,
                     double *batchSatStates);
 
+/* ------------------------------------------------------------------ Acquisition ---- */
+/* Cold-start coarse acquisition.  Only the reference's Python twin implements it:
+ * Correlator.coarse_acquisition, pygnss/pythonreceiver/scalar/correlator.py:53-103 (CUDARecv only
+ * forward-declares the classes, cudarecv/dsp/inc/dsp.h:207-209).  Full code-delay x Doppler search
+ * with batched FFTs (rocFFT through hipFFT). */
+typedef struct dpe_acq dpe_acq;
+typedef struct dpe_acq_config {
+    int32_t samplesPerWindow;   /* S = round(T fs), e.g. 25000 for 10 ms at 2.5 Msps (rawfile.py:162) */
+    int32_t nCodePeriods;       /* N = round(T / 1 ms) (rawfile.py:161); S % N must be 0 */
+    int32_t nBins;              /* Doppler bins: binStartHz + i binStepHz (correlator.py:13-14) */
+    int32_t nPrn;
+    int32_t mode;               /* 0: reference coherent=True; 1: reference coherent=False (sum |.| over the N
+                                 * lag aliases of one S-long correlation); 2: textbook 1 ms coherent x N
+                                 * non-coherent (BASELINE.json wording; not a reference algorithm) */
+    int32_t prnChunk;           /* PRNs per inverse-FFT batch (0 -> 8) */
+    double samplingFrequency;
+    double binStartHz;
+    double binStepHz;
+    double dopplerSign;         /* rawfile.ds; fcaid = ds F_CA / F_L1 (rawfile.py:95) */
+    int32_t prn[DPE_MAX_CHAN];
+    int32_t reserved;
+} dpe_acq_config;
+typedef struct dpe_acq_result {  /* return values of coarse_acquisition, correlator.py:86-103 */
+    int32_t prn, found, maxCodeIdx, maxDoppIdx;
+    double rc, fc, fi, cppr, cppm, peak;
+} dpe_acq_result;
+int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out);
+int dpe_acq_destroy(dpe_acq *h);
+int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream);   /* one window, asynchronous */
+int dpe_acq_results(dpe_acq *h, dpe_acq_result *results /* [nPrn] */, dpe_stream_t stream);   /* synchronises */
+/* |coarse_result_matrix| as float [nPrn][nBins][S/N] and its per-lag maximum over bins [nPrn][S/N] */
+int dpe_acq_surface(dpe_acq *h, const float **surface_dev, const float **maxPerCode_dev);
+
 /* Per-kernel timing (HIP events recorded on the launch stream around each kernel).  Returns and
  * resets the totals accumulated since the previous call, then sets the enable flag.
  * BCS slots: 0 DC-sum, 1 bank, 2 finalize (ms[3], count[3]); BCM slots: 0 pos scan, 1 vel scan. */

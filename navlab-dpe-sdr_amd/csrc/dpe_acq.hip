@@ -1,0 +1,270 @@
+// dpe_acq.hip -- cold-start coarse acquisition (BASELINE.json configs[4]).
+//
+// The reference has acquisition only in its Python twin: Correlator.coarse_acquisition
+// (pygnss/pythonreceiver/scalar/correlator.py:53-103) -- per Doppler bin: wipe-off, FFT, multiply by the
+// conjugate FFT of the nominal-rate replica, IFFT (all S lags), fold the N code periods of the window
+// (complex sum = "coherent", sum of magnitudes = "non-coherent"), then peak statistics
+// (cppr, cppm = peak / 10 %-trimmed mean, found <=> cppm > 2).
+//
+// Here: the bin loop becomes one batched FFT (rocFFT through hipFFT -- an FFT is intrinsic to a
+// full code-delay search), the replica spectra (conj, 1/S folded in) are precomputed once per PRN at
+// create, and three small HIP kernels do wipe-off, spectrum multiply and fold + per-lag max over bins.
+// mode 0 / 1 = the reference's coherent / non-coherent semantics (pinned by fixture O8);
+// mode 2 = the textbook "1 ms coherent x N non-coherent" of BASELINE.json (NOT in the reference: parity
+// unpinned, checked against the oracle's own restatement only).
+#include <hipfft/hipfft.h>
+
+#include <algorithm>
+
+#include "dpe_common.h"
+
+namespace dpe {
+
+// X[b][n] = raw[n] * exp(-j 2 pi f_b n / fs)   (correlator.py:63)
+__global__ __launch_bounds__(256) void acq_wipe_kernel(const int16_t *__restrict__ iq, int S, int B, double binStart,
+                                                       double binStep, double invFs, float2 *__restrict__ X)
+{
+    const int b = blockIdx.y;
+    const double cyclesPerSample = (binStart + binStep * b) * invFs;
+    const int *x = reinterpret_cast<const int *>(iq);
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < S; n += gridDim.x * blockDim.x) {
+        const int v = x[n];
+        const float re = (float)(short)(v & 0xFFFF), im = (float)(v >> 16);
+        double ph = cyclesPerSample * (double)n;
+        ph -= floor(ph);
+        const float f = (float)ph;
+        const float c = __builtin_amdgcn_cosf(f), s = -__builtin_amdgcn_sinf(f);
+        X[(size_t)b * S + n] = make_float2(re * c - im * s, re * s + im * c);
+    }
+}
+
+// Rc = conj(FFT(replica)) / len   (correlator.py:67; the 1/len is numpy's ifft normalisation)
+__global__ void acq_conj_scale_kernel(float2 *__restrict__ R, long long n, float scale)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = R[i];
+        R[i] = make_float2(v.x * scale, -v.y * scale);
+    }
+}
+
+// Y[p][b][i] = X[b][i] * Rc[p][i mod len]   (correlator.py:75)
+__global__ __launch_bounds__(256) void acq_mul_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc, int S,
+                                                      int len, int B, float2 *__restrict__ Y)
+{
+    const int b = blockIdx.y, p = blockIdx.z;
+    const float2 *xr = X + (size_t)b * S, *rr = Rc + (size_t)p * len;
+    float2 *yr = Y + ((size_t)p * B + b) * S;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+        const float2 a = xr[i], r = rr[i % len];
+        yr[i] = make_float2(a.x * r.x - a.y * r.y, a.x * r.y + a.y * r.x);
+    }
+}
+
+// surface[p][b][j] = | sum_n Y[j + n M] |  (coherent)  or  sum_n |Y[j + n M]|   (correlator.py:77-84)
+__global__ __launch_bounds__(256) void acq_fold_kernel(const float2 *__restrict__ Y, int S, int M, int N, int coherent,
+                                                       float *__restrict__ surf)
+{
+    const size_t row = (size_t)blockIdx.z * gridDim.y + blockIdx.y;   // (p, b)
+    const float2 *y = Y + row * S;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+        float ar = 0.f, ai = 0.f, am = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float2 v = y[j + n * M];
+            ar += v.x; ai += v.y;
+            am += sqrtf(v.x * v.x + v.y * v.y);
+        }
+        surf[row * M + j] = coherent ? sqrtf(ar * ar + ai * ai) : am;
+    }
+}
+
+// max_percode[p][j] = max_b surface[p][b][j]   (correlator.py:87)
+__global__ __launch_bounds__(256) void acq_colmax_kernel(const float *__restrict__ surf, int B, int M, float *__restrict__ mp)
+{
+    const int p = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+        float m = 0.f;
+        for (int b = 0; b < B; ++b) m = fmaxf(m, surf[((size_t)p * B + b) * M + j]);
+        mp[(size_t)p * M + j] = m;
+    }
+}
+
+}  // namespace dpe
+
+struct dpe_acq {
+    dpe_acq_config cfg;
+    int S, N, M, B, P, len, chunk;   // len = FFT length (S, or M in mode 2)
+    hipfftHandle planFwd = 0, planInv = 0;
+    bool haveFwd = false, haveInv = false;
+    float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
+    float *surf_d = nullptr, *mp_d = nullptr;
+    bool searched = false;
+};
+
+#define DPE_CHECK_FFT(expr)                                                                  \
+    do {                                                                                     \
+        hipfftResult r_ = (expr);                                                            \
+        if (r_ != HIPFFT_SUCCESS) {                                                          \
+            dpe::set_error("%s:%d: %s -> hipfft error %d", __FILE__, __LINE__, #expr, (int)r_); \
+            return -1;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+extern "C" {
+
+int dpe_acq_destroy(dpe_acq *h)
+{
+    if (!h) return 0;
+    if (h->haveFwd) hipfftDestroy(h->planFwd);
+    if (h->haveInv) hipfftDestroy(h->planInv);
+    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d};
+    for (void *b : bufs) (void)hipFree(b);
+    delete h;
+    return 0;
+}
+
+int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
+{
+    using namespace dpe;
+    DPE_REQUIRE(cfg && out, "[Acquisition] create: null argument");
+    DPE_REQUIRE(cfg->samplesPerWindow > 0 && cfg->nCodePeriods >= 1 && cfg->samplesPerWindow % cfg->nCodePeriods == 0,
+                "[Acquisition] create: samplesPerWindow must be a positive multiple of nCodePeriods");
+    DPE_REQUIRE(cfg->nBins >= 1 && cfg->nPrn >= 1 && cfg->nPrn <= DPE_MAX_CHAN, "[Acquisition] create: nBins / nPrn out of range");
+    DPE_REQUIRE(cfg->mode >= 0 && cfg->mode <= 2, "[Acquisition] create: mode must be 0, 1 or 2");
+    DPE_REQUIRE(cfg->samplingFrequency > 0, "[Acquisition] create: bad samplingFrequency");
+    for (int i = 0; i < cfg->nPrn; ++i)
+        DPE_REQUIRE(cfg->prn[i] >= 1 && cfg->prn[i] <= kPrnMax, "[Acquisition] create: PRN %d out of range", cfg->prn[i]);
+    dpe_acq *h = new dpe_acq();
+    h->cfg = *cfg;
+    h->S = cfg->samplesPerWindow; h->N = cfg->nCodePeriods; h->M = h->S / h->N; h->B = cfg->nBins; h->P = cfg->nPrn;
+    h->len = (cfg->mode == 2) ? h->M : h->S;
+    h->chunk = cfg->prnChunk > 0 ? std::min(cfg->prnChunk, h->P) : std::min(8, h->P);
+    const size_t S = h->S, B = h->B, P = h->P;
+    h->X_d = dev_alloc<float2>(B * S);
+    h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
+    h->Y_d = dev_alloc<float2>((size_t)h->chunk * B * S);
+    h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
+    h->mp_d = dev_alloc<float>(P * (size_t)h->M);
+    if (!h->X_d || !h->Rc_d || !h->Y_d || !h->surf_d || !h->mp_d) {
+        set_error("[Acquisition] create: device allocation failed");
+        dpe_acq_destroy(h);
+        return -1;
+    }
+    int n[1] = {h->len};
+    const int batchFwd = (int)(B * (S / h->len)), batchInv = (int)(h->chunk * B * (S / h->len));
+    if (hipfftPlanMany(&h->planFwd, 1, n, nullptr, 1, h->len, nullptr, 1, h->len, HIPFFT_C2C, batchFwd) != HIPFFT_SUCCESS) {
+        set_error("[Acquisition] create: hipfftPlanMany(forward, n=%d, batch=%d) failed", h->len, batchFwd);
+        dpe_acq_destroy(h);
+        return -1;
+    }
+    h->haveFwd = true;
+    if (hipfftPlanMany(&h->planInv, 1, n, nullptr, 1, h->len, nullptr, 1, h->len, HIPFFT_C2C, batchInv) != HIPFFT_SUCCESS) {
+        set_error("[Acquisition] create: hipfftPlanMany(inverse, n=%d, batch=%d) failed", h->len, batchInv);
+        dpe_acq_destroy(h);
+        return -1;
+    }
+    h->haveInv = true;
+    // nominal-rate replica: chips[floor(n / fs * F_CA) mod 1023] (correlator.py:66, rawfile.py:164-166), fp64 on the host
+    std::vector<float2> rep(P * (size_t)h->len);
+    int8_t chips[kLCA];
+    for (size_t p = 0; p < P; ++p) {
+        gen_ca_code_host(cfg->prn[p], chips);
+        for (int i = 0; i < h->len; ++i) {
+            const double t = (double)i / cfg->samplingFrequency;
+            const long long ci = (long long)std::floor(t * kFCA);
+            rep[p * h->len + i] = make_float2((float)chips[ci % kLCA], 0.f);
+        }
+    }
+    DPE_CHECK_HIP(hipMemcpy(h->Rc_d, rep.data(), sizeof(float2) * rep.size(), hipMemcpyHostToDevice));
+    {
+        hipfftHandle pr;
+        DPE_CHECK_FFT(hipfftPlanMany(&pr, 1, n, nullptr, 1, h->len, nullptr, 1, h->len, HIPFFT_C2C, (int)P));
+        DPE_CHECK_FFT(hipfftExecC2C(pr, (hipfftComplex *)h->Rc_d, (hipfftComplex *)h->Rc_d, HIPFFT_FORWARD));
+        hipLaunchKernelGGL(acq_conj_scale_kernel, dim3(256), dim3(256), 0, 0, h->Rc_d, (long long)(P * h->len), 1.0f / (float)h->len);
+        DPE_CHECK_HIP(hipDeviceSynchronize());
+        hipfftDestroy(pr);
+    }
+    *out = h;
+    return 0;
+}
+
+int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && samples_dev, "[Acquisition] search: null argument");
+    hipStream_t st = (hipStream_t)stream_;
+    DPE_CHECK_FFT(hipfftSetStream(h->planFwd, st));
+    DPE_CHECK_FFT(hipfftSetStream(h->planInv, st));
+    const int S = h->S, B = h->B, P = h->P, M = h->M;
+    hipLaunchKernelGGL(acq_wipe_kernel, dim3((S + 1023) / 1024, B), dim3(256), 0, st, samples_dev, S, B, h->cfg.binStartHz,
+                       h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d);
+    DPE_CHECK_FFT(hipfftExecC2C(h->planFwd, (hipfftComplex *)h->X_d, (hipfftComplex *)h->X_d, HIPFFT_FORWARD));
+    for (int p0 = 0; p0 < P; p0 += h->chunk) {
+        const int pc = std::min(h->chunk, P - p0);
+        hipLaunchKernelGGL(acq_mul_kernel, dim3((S + 1023) / 1024, B, pc), dim3(256), 0, st, h->X_d,
+                           h->Rc_d + (size_t)p0 * h->len, S, h->len, B, h->Y_d);
+        // a short last chunk still runs the full-batch plan over stale rows; they are never read
+        DPE_CHECK_FFT(hipfftExecC2C(h->planInv, (hipfftComplex *)h->Y_d, (hipfftComplex *)h->Y_d, HIPFFT_BACKWARD));
+        hipLaunchKernelGGL(acq_fold_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->Y_d, S, M, h->N,
+                           h->cfg.mode == 0 ? 1 : 0, h->surf_d + (size_t)p0 * B * M);
+    }
+    hipLaunchKernelGGL(acq_colmax_kernel, dim3((M + 255) / 256, P), dim3(256), 0, st, h->surf_d, B, M, h->mp_d);
+    DPE_CHECK_HIP(hipGetLastError());
+    h->searched = true;
+    return 0;
+}
+
+static double percentile_sorted(const std::vector<float> &a, double q)   // numpy/scipy linear interpolation
+{
+    const double pos = (a.size() - 1) * q / 100.0;
+    const size_t i = (size_t)std::floor(pos);
+    const double f = pos - (double)i;
+    return (i + 1 < a.size()) ? a[i] + (a[i + 1] - a[i]) * f : a[i];
+}
+
+int dpe_acq_results(dpe_acq *h, dpe_acq_result *out, dpe_stream_t stream)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && out && h->searched, "[Acquisition] results: no search yet");
+    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    const int M = h->M, B = h->B, P = h->P;
+    std::vector<float> mp((size_t)P * M), col(B);
+    DPE_CHECK_HIP(hipMemcpy(mp.data(), h->mp_d, sizeof(float) * mp.size(), hipMemcpyDeviceToHost));
+    const double fs = h->cfg.samplingFrequency;
+    for (int p = 0; p < P; ++p) {
+        float *m = mp.data() + (size_t)p * M;
+        const int ci = (int)(std::max_element(m, m + M) - m);                      // first maximum, correlator.py:88
+        for (int b = 0; b < B; ++b)
+            DPE_CHECK_HIP(hipMemcpy(&col[b], h->surf_d + ((size_t)p * B + b) * M + ci, sizeof(float), hipMemcpyDeviceToHost));
+        const int di = (int)(std::max_element(col.begin(), col.end()) - col.begin());   // :89
+        dpe_acq_result &r = out[p];
+        r.prn = h->cfg.prn[p];
+        r.maxCodeIdx = ci; r.maxDoppIdx = di;
+        r.rc = (double)kLCA - ((double)ci / fs) * kFCA;                            // :90
+        r.fi = h->cfg.binStartHz + h->cfg.binStepHz * di;                          // :91
+        r.fc = kFCA + (h->cfg.dopplerSign * kFCA / kFL1) * r.fi;                   // :92
+        r.peak = m[ci];
+        const int maskS = (int)std::ceil(fs / kFCA);                               // :96-99 (indices wrap)
+        std::vector<float> a(m, m + M);
+        for (int d = -maskS; d <= maskS; ++d) a[((ci + d) % M + M) % M] = 0.f;
+        r.cppr = r.peak / *std::max_element(a.begin(), a.end());                   // :100
+        std::sort(a.begin(), a.end());
+        const double lo = percentile_sorted(a, 5.0), hi = percentile_sorted(a, 95.0);   // _trim_mean :546-564
+        double sum = 0;
+        long long cnt = 0;
+        for (float v : a)
+            if (v > lo && v < hi) { sum += v; ++cnt; }
+        r.cppm = cnt ? r.peak / (sum / cnt) : 0.0;
+        r.found = r.cppm > 2.0 ? 1 : 0;                                            // :103
+    }
+    return 0;
+}
+
+int dpe_acq_surface(dpe_acq *h, const float **surface_dev, const float **maxPerCode_dev)
+{
+    DPE_REQUIRE(h, "[Acquisition] surface: null handle");
+    if (surface_dev) *surface_dev = h->surf_d;
+    if (maxPerCode_dev) *maxPerCode_dev = h->mp_d;
+    return 0;
+}
+
+}  // extern "C"

@@ -22,7 +22,8 @@ EXPORTS = [
     "dpe_bcs_export_dense", "dpe_bcm_create", "dpe_bcm_destroy", "dpe_bcm_update", "dpe_bcm_results",
     "dpe_bcm_scores", "dpe_bcm_keys", "dpe_bcm_results_from_keys", "dpe_event_create", "dpe_event_record",
     "dpe_event_elapsed_ms", "dpe_event_destroy", "dpe_chm_create", "dpe_chm_destroy", "dpe_chm_start",
-    "dpe_chm_update", "dpe_chm_outputs", "dpe_bcs_profile", "dpe_bcm_profile",
+    "dpe_chm_update", "dpe_chm_outputs", "dpe_bcs_profile", "dpe_bcm_profile", "dpe_acq_create", "dpe_acq_destroy",
+    "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface",
 ]
 
 
@@ -411,6 +412,62 @@ class ChanMgr:
         return 0
 
     __del__ = Stop
+
+
+class AcqConfig(C.Structure):
+    _fields_ = [("samplesPerWindow", C.c_int32), ("nCodePeriods", C.c_int32), ("nBins", C.c_int32), ("nPrn", C.c_int32),
+                ("mode", C.c_int32), ("prnChunk", C.c_int32), ("samplingFrequency", C.c_double),
+                ("binStartHz", C.c_double), ("binStepHz", C.c_double), ("dopplerSign", C.c_double),
+                ("prn", C.c_int32 * 37), ("reserved", C.c_int32)]
+
+
+class AcqResult(C.Structure):
+    _fields_ = [("prn", C.c_int32), ("found", C.c_int32), ("maxCodeIdx", C.c_int32), ("maxDoppIdx", C.c_int32),
+                ("rc", C.c_double), ("fc", C.c_double), ("fi", C.c_double), ("cppr", C.c_double), ("cppm", C.c_double),
+                ("peak", C.c_double)]
+
+
+class Acquisition:
+    """Coarse acquisition over `prns` x Doppler bins x all code delays of one window.
+    mode: "coherent" / "noncoherent" = Correlator.coarse_acquisition(coherent=True/False)
+    (correlator.py:53-103); "textbook" = 1 ms coherent x N non-coherent (not in the reference)."""
+    MODES = {"coherent": 0, "noncoherent": 1, "textbook": 2}
+
+    def __init__(self, SamplingFrequency, samples_per_window, prns, bins_hz, mode="coherent", prn_chunk=0, ds=1.0):
+        bins_hz = np.asarray(bins_hz, dtype=np.float64)
+        step = float(bins_hz[1] - bins_hz[0]) if bins_hz.size > 1 else 0.0
+        assert bins_hz.size == 1 or np.allclose(np.diff(bins_hz), step), "bins must be equally spaced"
+        self.S, self.fs = int(samples_per_window), float(SamplingFrequency)
+        self.N = int(round(self.S / self.fs / 1e-3))
+        self.M = self.S // self.N
+        self.prns, self.bins = [int(p) for p in prns], bins_hz
+        cfg = AcqConfig(self.S, self.N, bins_hz.size, len(self.prns), self.MODES[mode], int(prn_chunk), self.fs,
+                        float(bins_hz[0]), step, float(ds), (C.c_int32 * 37)(*self.prns), 0)
+        self._h = C.c_void_p(None)
+        _check(lib().dpe_acq_create(C.byref(cfg), C.byref(self._h)))
+        surf, mp = C.c_void_p(), C.c_void_p()
+        _check(lib().dpe_acq_surface(self._h, C.byref(surf), C.byref(mp)))
+        self.Surface, self.MaxPerCode = surf.value, mp.value
+
+    def search(self, Samples, stream=None):
+        _check(lib().dpe_acq_search(self._h, _ptr(Samples), _stream(stream)))
+
+    def results(self, stream=None):
+        res = (AcqResult * len(self.prns))()
+        _check(lib().dpe_acq_results(self._h, res, _stream(stream)))
+        return [dict(prn=r.prn, found=bool(r.found), max_code_idx=r.maxCodeIdx, max_dopp_idx=r.maxDoppIdx, rc=r.rc, fc=r.fc,
+                     fi=r.fi, cppr=r.cppr, cppm=r.cppm, peak=r.peak) for r in res]
+
+    def read_surface(self, stream=None):
+        n = len(self.prns) * self.bins.size * self.M
+        return d2h(self.Surface, n * 4, np.float32, stream).reshape(len(self.prns), self.bins.size, self.M)
+
+    def close(self):
+        if self._h:
+            lib().dpe_acq_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    __del__ = close
 
 
 class HipEventTimer:

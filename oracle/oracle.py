@@ -278,3 +278,69 @@ class ChanMgr:
                                 C.c_int(self.K), _d(tg), C.c_int(tg.size), _d(batch), _d(R))
         self.batchSatStates, self.enu2ecef = batch, R
         return batch, R
+
+
+# ---------------------------------------------------------------------------------------------
+# Cold-start acquisition.  Exists only in the reference's Python twin:
+# pygnss/pythonreceiver/scalar/correlator.py:53-103 (coarse_acquisition), :13-14 (search grids).
+def acq_bins(coherent=True):
+    """DOPPLER_SEARCH_MATRIX_COHERENT (125 x 100 Hz) / _NONCOHERENT (25 x 500 Hz), correlator.py:13-14."""
+    B, d = (125, 100.0) if coherent else (25, 500.0)
+    return np.arange((1 - B) / 2, (B - 1) / 2 + 1) * d
+
+
+def trim_mean(arr, percent):
+    """correlator.py:546-564: mean of the values strictly between the percent/2 and 100-percent/2
+    percentiles (scipy scoreatpercentile = linear interpolation)."""
+    lo = np.percentile(arr, percent / 2.0)
+    hi = np.percentile(arr, 100.0 - percent / 2.0)
+    sel = arr[(arr > lo) & (arr < hi)]
+    return sel.mean()
+
+
+def coarse_acquisition(iq, fs, prn, bins, coherent=True, mode=None, doppler_sign=1.0):
+    """numpy restatement of Correlator.coarse_acquisition (correlator.py:53-103).
+
+    mode None -> the reference's semantics (coherent flag as given).  mode 'textbook' -> the
+    BASELINE.json config-5 wording (1 ms coherent x N non-coherent): NOT a reference algorithm,
+    parity unpinned, provided for comparison only."""
+    iq = np.asarray(iq, dtype=np.int16)
+    S = iq.size // 2
+    N = int(round(S / fs / T_CA))
+    raw = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    t = np.arange(S) / fs                                                     # rawfile.py:164-165
+    code_idc = t * F_CA
+    chips = ca_code(prn).astype(np.float64)
+    rep = chips[np.mod(np.floor(code_idc), L_CA).astype(np.int64)]             # :66
+    bins = np.asarray(bins, dtype=np.float64)
+    M = S // N
+    if mode == "textbook":
+        R1 = np.conj(np.fft.fft(rep[:M]))
+        res = np.zeros((bins.size, M))
+        for b, f in enumerate(bins):
+            x = (raw * np.exp(-1j * (2 * CONST_PI * f * t))).reshape(N, M)
+            res[b] = np.abs(np.fft.ifft(np.fft.fft(x, axis=1) * R1[None, :], axis=1)).sum(0)
+        res_abs = res
+    else:
+        Rc = np.conj(np.fft.fft(rep))                                          # :67
+        res = np.zeros((bins.size, S), dtype=np.complex128)
+        for b, f in enumerate(bins):                                           # :73-75
+            res[b] = np.fft.ifft(np.fft.fft(raw * np.exp(-1j * (2 * CONST_PI * f * t))) * Rc)
+        if N != 1:                                                             # :77-82
+            tmp = res.reshape(bins.size, N, M)
+            res = tmp.sum(1) if coherent else np.abs(tmp).sum(1)
+        res_abs = np.abs(res)
+    max_percode = res_abs.max(0)                                               # :87-89
+    max_code_idx = int(max_percode.argmax())
+    max_dopp_idx = int(res_abs[:, max_code_idx].argmax())
+    rc = L_CA - code_idc[max_code_idx]
+    fi = bins[max_dopp_idx]
+    fc = F_CA + (doppler_sign * F_CA / F_L1) * fi
+    peak = max_percode[max_code_idx]
+    mask_S = int(np.ceil(fs / F_CA))
+    mp = max_percode.copy()
+    mp[np.arange(-mask_S, mask_S + 1) + max_code_idx] = 0                      # negative indices wrap, as in numpy
+    cppr = peak / mp.max()
+    cppm = peak / trim_mean(mp, 10)
+    return dict(surface=res_abs, max_code_idx=max_code_idx, max_dopp_idx=max_dopp_idx, rc=rc, fi=fi, fc=fc,
+                cppr=cppr, cppm=cppm, found=bool(cppm > 2.0), max_percode=max_percode)

@@ -16,6 +16,7 @@ reference callables that the CUDA authors used as their oracle (SURVEY.md sectio
   O5 utils.ECEF_to_LLA / ECEF_to_ENU rotation    utils.py:13-81,235-275
   O6 NavigationGuesses.generate_spread_grid      receiver.py:995-1026
   O7 Receiver.dp_track internals (one iteration) receiver.py:205-397, channel.py:194-245
+  O8 Correlator.coarse_acquisition               correlator.py:53-103
 
 Only DATA (inputs + expected outputs) is written; no reference source is copied into the
 repo.  The two harness adaptations below are marked HARNESS and do not touch arithmetic.
@@ -182,6 +183,44 @@ def main():
         argmax_pos=int(np.argmax(pos_corr)), argmax_vel=int(np.argmax(vel_fft)), e=e,
         pos_every97=pos_corr[::97], vel_every97=vel_fft[::97], top_pos_idx=top_p, top_pos=pos_corr[top_p],
         top_vel_idx=top_v, top_vel=vel_fft[top_v], gX_sel=np.asarray(gfv)[:, sel], sel=np.array(sel))
+    rf.close_rawfile()
+    # ---- O8: cold-start coarse acquisition (correlator.py:53-103) on a 10 ms synthetic window
+    fs, T = 2.5e6, 0.01
+    S = int(round(fs * T))
+    ch8 = dpe.synth.random_channels(8, 4, prns=[2, 12, 19, 28])
+    ch8["fi"] = np.array([1234.0, -2750.0, 310.0, 4490.0])          # off the 100 Hz search raster
+    ch8["fc"] = 1.023e6 * (1.0 + ch8["fi"] / 1.57542e9)
+    ch8["cp_ref"] = ch8["cp"].copy()                                # no nav-bit edge inside 10 ms
+    iq = dpe.synth.gen_iq(31, fs, S, ch8, amp=np.array([120.0, 90.0, 60.0, 150.0]), flip=np.zeros(4, dtype=bool))
+    path = os.path.join(SCRATCH, "o8.dat")
+    iq.tofile(path)
+    rf = open_rawfile(pg, path, fs, T)
+    rf.update_rawsnippet()
+
+    class Py2Int(int):           # HARNESS: Python-2 "int / int" floors (correlator.py:78 reshapes by S/N)
+        def __truediv__(self, other):
+            return int(self) // other
+    rf.S = Py2Int(rf.S)
+    cases = []
+    for prn in (2, 12, 19, 28, 5, 30):                              # four present, two absent
+        for coherent, mat in ((True, pg.correlator.DOPPLER_SEARCH_MATRIX_COHERENT),
+                              (False, pg.correlator.DOPPLER_SEARCH_MATRIX_NONCOHERENT)):
+            cor = pg.correlator.Correlator(prn)
+            m, found, rc, fc, fi, cppr, cppm = cor.coarse_acquisition(rf, mat, coherent, False)
+            a = np.abs(np.asarray(m))
+            mp = a.max(0)
+            ci = int(mp.argmax())
+            di = int(a[:, ci].argmax())
+            nb = a[max(di - 8, 0):di + 9, :][:, np.arange(ci - 8, ci + 9) % a.shape[1]]
+            cases.append(dict(prn=prn, coherent=coherent, found=bool(found), rc=float(rc), fc=float(fc), fi=float(fi),
+                              cppr=float(cppr), cppm=float(cppm), ci=ci, di=di, nb=nb, shape=a.shape,
+                              row_max=a.max(1), col_every25=mp[::25]))
+    np.savez_compressed(os.path.join(HERE, "o8_acquisition.npz"), iq=iq, fs=fs, T=T, S=S, N=rf.N,
+                        bins_coh=np.asarray(pg.correlator.DOPPLER_SEARCH_MATRIX_COHERENT).ravel(),
+                        bins_non=np.asarray(pg.correlator.DOPPLER_SEARCH_MATRIX_NONCOHERENT).ravel(),
+                        truth_prn=ch8["prn"], truth_rc=ch8["rc"], truth_fi=ch8["fi"],
+                        **{"c%d_%s" % (i, k): np.asarray(v) for i, c in enumerate(cases) for k, v in c.items()},
+                        ncases=len(cases))
     rf.close_rawfile()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
