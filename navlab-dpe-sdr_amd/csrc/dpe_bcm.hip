@@ -250,6 +250,7 @@ struct dpe_bcm {
     dpe::BcmSvDev *sv_d = nullptr, *sv_h = nullptr;  // [2][W][maxK]  (manifold-major)
     unsigned long long *keys_d = nullptr, *oob_d = nullptr;  // [W][2]
     double *wsum_d = nullptr;   // [W][2][split][5] per-block weighted sums
+    unsigned long long *keys_h = nullptr, *oob_h = nullptr;   // pinned mirrors, filled by async copies at the end of Update
     unsigned lastSplit[2] = {0, 0};
     static constexpr unsigned kMaxSplit = 4096;
     size_t wsumHalf = 0;
@@ -375,7 +376,9 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->wsumHalf = (size_t)(dpe_bcm::kMaxSplit + 8 * W) * 5;   // >= nWindows * blocks-per-window of any launch
     h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
     if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->oob_d || !h->wsum_d ||
-        hipHostMalloc((void **)&h->sv_h, 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&h->sv_h, 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->keys_h, 2 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->oob_h, 2 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
         dpe_bcm_destroy(h);
         return -1;
@@ -396,6 +399,8 @@ int dpe_bcm_destroy(dpe_bcm *h)
     void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->oob_d, h->wsum_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->sv_h) (void)hipHostFree(h->sv_h);
+    if (h->keys_h) (void)hipHostFree(h->keys_h);
+    if (h->oob_h) (void)hipHostFree(h->oob_h);
     delete h;
     return 0;
 }
@@ -491,6 +496,9 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
                            h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr);
         h->prof.end(1, stream);
     }
+    // results travel to pinned host memory on the same stream: dpe_bcm_results only has to synchronise
+    DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, h->keys_d, sizeof(unsigned long long) * 2 * nWindows, hipMemcpyDeviceToHost, stream));
+    DPE_CHECK_HIP(hipMemcpyAsync(h->oob_h, h->oob_d, sizeof(unsigned long long) * 2 * nWindows, hipMemcpyDeviceToHost, stream));
     DPE_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -520,9 +528,7 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
     DPE_REQUIRE(h && results && h->lastW > 0, "[BatchCorrManifold] results: no update yet");
     DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int W = h->lastW;
-    std::vector<unsigned long long> keys(2 * W), oob(2 * W);
-    DPE_CHECK_HIP(hipMemcpy(keys.data(), h->keys_d, sizeof(unsigned long long) * 2 * W, hipMemcpyDeviceToHost));
-    DPE_CHECK_HIP(hipMemcpy(oob.data(), h->oob_d, sizeof(unsigned long long) * 2 * W, hipMemcpyDeviceToHost));
+    const unsigned long long *keys = h->keys_h, *oob = h->oob_h;
     std::vector<double> ws(2 * h->wsumHalf, 0.0);
     if (h->cfg.weightedMean)
         DPE_CHECK_HIP(hipMemcpy(ws.data(), h->wsum_d, sizeof(double) * 2 * h->wsumHalf, hipMemcpyDeviceToHost));

@@ -267,38 +267,53 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSu
     const int NL = 2 * LH + 1;
     const BcsChanDev ch = chan[w * K + k];
     const float2 *pp = part + ((size_t)w * K + k) * nBlk * 2 * NL;
-    __shared__ int sNoFlip;
-    __shared__ float2 sRed[4][64];
-    if (tid == 0) {
-        // BCS_ChooseCodeCorr :512-516 -- decision at lag 0 only
-        float2 X = make_float2(0.f, 0.f), Y = make_float2(0.f, 0.f);
-        for (int b = 0; b < nBlk; ++b) {
-            const float2 a = pp[(size_t)(b * 2) * NL + LH], c = pp[(size_t)(b * 2 + 1) * NL + LH];
-            X.x += a.x; X.y += a.y; Y.x += c.x; Y.y += c.y;
+    __shared__ float2 sXY[2 * 65];      // [side][lag] totals of the per-block partials (NL <= 65)
+    __shared__ float2 sTmp[256];
+    __shared__ float2 sRed[16][16];
+    {
+        // fixed-order two-level sum (bit-reproducible, identical in every block): T threads per
+        // (side, lag) pair each add a strided subset of the blocks, then one thread adds the T partials
+        const int pairs = 2 * NL;
+        int np2 = 1;
+        while (np2 < pairs) np2 <<= 1;
+        const int T = 256 / np2;                     // pairs <= 130 -> T >= 1
+        const int pair = tid / T, sub = tid - pair * T;
+        float2 acc = make_float2(0.f, 0.f);
+        if (pair < pairs) {
+            const int side = pair / NL, lag = pair - side * NL;
+            for (int bq = sub; bq < nBlk; bq += T) {
+                const float2 v = pp[(size_t)(bq * 2 + side) * NL + lag];
+                acc.x += v.x; acc.y += v.y;
+            }
         }
-        const float nr = X.x + Y.x, ni = X.y + Y.y, fr = X.x - Y.x, fi = X.y - Y.y;
-        sNoFlip = (!ch.hasFlip) || (nr * nr + ni * ni > fr * fr + fi * fi);
+        sTmp[tid] = acc;
+        __syncthreads();
+        if (pair < pairs && sub == 0) {
+            float2 t = sTmp[tid];
+            for (int q = 1; q < T; ++q) { t.x += sTmp[tid + q].x; t.y += sTmp[tid + q].y; }
+            sXY[pair] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const int noFlip = sNoFlip;
+    // BCS_ChooseCodeCorr :512-516 -- decision at lag 0 only
+    const float2 X0 = sXY[LH], Y0 = sXY[NL + LH];
+    const float nr0 = X0.x + Y0.x, ni0 = X0.y + Y0.y, fr0 = X0.x - Y0.x, fi0 = X0.y - Y0.y;
+    const int noFlip = (!ch.hasFlip) || (nr0 * nr0 + ni0 * ni0 > fr0 * fr0 + fi0 * fi0);
     const float sgn = noFlip ? 1.f : -1.f;
 
     if (blockIdx.x == 0) {
         if (tid == 0) info[w * K + k] = noFlip;
         for (int j = tid; j < 2 * L + 1; j += 256) {
             const int jj = j + (LH - L);
-            float2 X = make_float2(0.f, 0.f), Y = make_float2(0.f, 0.f);
-            for (int b = 0; b < nBlk; ++b) {
-                const float2 a = pp[(size_t)(b * 2) * NL + jj], c = pp[(size_t)(b * 2 + 1) * NL + jj];
-                X.x += a.x; X.y += a.y; Y.x += c.x; Y.y += c.y;
-            }
+            const float2 X = sXY[jj], Y = sXY[NL + jj];
             codeBank[((size_t)w * maxK + k) * (2 * L + 1) + j] = make_float2(X.x + sgn * Y.x, X.y + sgn * Y.y);
         }
         return;
     }
     // ---- Doppler bins: F[b] = sum_sub tw(sub,b) * sum_p (-j theta)^p / p! * M_p[sub]
-    const int bi = (blockIdx.x - 1) * 64 + (tid & 63);  // bank entry
-    const int grp = tid >> 6;                           // 4 groups split the sub-tiles
+    // 16 bins per block, 16 thread groups striding the sub-tiles
+    const int bi = (blockIdx.x - 1) * 16 + (tid & 15);  // bank entry
+    const int grp = tid >> 4;
     const int b = bi - B;
     float2 F = make_float2(0.f, 0.f);
     if (bi < 2 * B + 1) {
@@ -307,25 +322,25 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSu
         const float2 *m1 = m0 + (size_t)nSub * kNMom;
         const float invC = 1.0f / (float)C;  // C is a power of two: exact
         // centre twiddle exp(-j 2 pi n_c b / C), n_c = 256 sub + 127.5: exact (integer-reduced phase +
-        // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 1024 b / C) between
+        // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 4096 b / C) between
         float stepS, stepC;
         {
-            long long ts = ((long long)2048 * (long long)b) % (2 * C);   // 2 * 1024 b  (phase unit: pi / C)
+            long long ts = ((long long)8192 * (long long)b) % (2 * C);   // 2 * (16 * 256) b  (phase unit: pi / C)
             if (ts < 0) ts += 2 * C;
             sincospif((float)ts * invC, &stepS, &stepC);
         }
         float sn = 0.f, cs = 1.f;
         int it = 0;
-        for (int sub = grp; sub < nSub; sub += 4, ++it) {
+        for (int sub = grp; sub < nSub; sub += 16, ++it) {
             const float2 *a0 = m0 + (size_t)sub * kNMom, *a1 = m1 + (size_t)sub * kNMom;
             float ar = a0[kNMom - 1].x + sgn * a1[kNMom - 1].x;
             float ai = a0[kNMom - 1].y + sgn * a1[kNMom - 1].y;
 #pragma unroll
             for (int p = kNMom - 1; p >= 1; --p) {
-                const float s = theta / (float)p;
+                const float sc = theta / (float)p;
                 const float mr = a0[p - 1].x + sgn * a1[p - 1].x, mi = a0[p - 1].y + sgn * a1[p - 1].y;
-                const float nr = fmaf(s, ai, mr);
-                ai = fmaf(-s, ar, mi);
+                const float nr = fmaf(sc, ai, mr);
+                ai = fmaf(-sc, ar, mi);
                 ar = nr;
             }
             if ((it & 7) == 0) {
@@ -342,14 +357,12 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSu
             F.y += cs * ai - sn * ar;
         }
     }
-    sRed[grp][tid & 63] = F;
+    sRed[grp][tid & 15] = F;
     __syncthreads();
     if (grp == 0 && bi < 2 * B + 1) {
-        float2 s = sRed[0][tid];
-        s.x += sRed[1][tid].x; s.y += sRed[1][tid].y;
-        s.x += sRed[2][tid].x; s.y += sRed[2][tid].y;
-        s.x += sRed[3][tid].x; s.y += sRed[3][tid].y;
-        carrBank[((size_t)w * maxK + k) * (2 * B + 1) + bi] = s;
+        float2 t = sRed[0][tid];
+        for (int q = 1; q < 16; ++q) { t.x += sRed[q][tid].x; t.y += sRed[q][tid].y; }
+        carrBank[((size_t)w * maxK + k) * (2 * B + 1) + bi] = t;
     }
 }
 
@@ -532,7 +545,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
 #undef DPE_LAUNCH_BANK2
     h->prof.end(1, stream);
     h->prof.begin(2, stream);
-    const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 63) / 64;
+    const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
     if (h->nMom == 4)
         hipLaunchKernelGGL(bcs_finalize_kernel<4>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
                            nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
