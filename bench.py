@@ -92,6 +92,9 @@ def main():
                          "all-reduce(SUM) of the zero-initialised full score vectors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scores", action="store_true", help="skip the per-point score write (arg-max only)")
+    ap.add_argument("--include-h2d", action="store_true",
+                    help="also time the steps with the window batch uploaded from pinned host memory inside the timed "
+                         "region (reported as pcie_inclusive_value; never the headline value)")
     args = ap.parse_args()
 
     import torch
@@ -191,6 +194,17 @@ def main():
     if world == 1:   # the banks must cover every index the grids reach
         assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res), "bank window too narrow"
 
+    pcie_value = None
+    if args.include_h2d and not use_dist:
+        iq_pin = torch.from_numpy(iq).pin_memory()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            iq_d.copy_(iq_pin, non_blocking=True)     # SampleBlock's H2D leg (sampleblock.cu:356-410), same stream
+            step()
+        fence()
+        pcie_value = float(args.steps) * W * 2.0 * G * K / (time.perf_counter() - t1)
+
     if rank == 0:
         units = float(args.steps) * W * 2.0 * G * K * world       # (gridpoint, SV) pairs, both manifolds, all ranks
         value = units / dt
@@ -212,6 +226,8 @@ def main():
                          "avg_launch_ms": ms_scan / n_scan if n_scan else None},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()},
         }
+        if pcie_value is not None:
+            out["pcie_inclusive_value"] = pcie_value
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
