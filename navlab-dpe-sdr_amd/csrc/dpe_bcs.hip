@@ -254,9 +254,200 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Wide lag windows (|lag| <= 32, i.e. high sampling rates where a chip spans many samples): instead of
+// 65 dense multiply-accumulates per sample, use that the replica is piecewise constant:
+//     corr[l+1] - corr[l] = sum_m J[m] b[(m + l) mod S],   J[m] = r[m-1] - r[m]
+// is a sum over the chip (and nav-bit / mask) boundaries only.  Per sub-tile: one direct lag (l = -32,
+// one FMA pair per sample) plus, for each of the ~codeStep*128 boundaries of the tile, one LDS read and
+// one FMA per LANE with lanes <-> the 64 lag steps.  The finalize kernel prefix-sums the steps.
+// part layout per (block, side): [0] = corr[-32], [1 + i] = D[-32 + i], i = 0..63  (65 entries, as NL).
+template <int kNMom>
+__global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
+                                                            int K, int nSub, int tilesPerBlock, int nBlk, int vecOK,
+                                                            const BcsChanDev *__restrict__ chan,
+                                                            const long long *__restrict__ sums,
+                                                            const int8_t *__restrict__ chipTable,
+                                                            float2 *__restrict__ part, float2 *__restrict__ mom)
+{
+    constexpr int LH = 32, NL = 2 * LH + 1;
+    constexpr int NREP = kSub + LH + 1;   // replica entries: m = sub0-1 .. sub0+255+LH
+    constexpr int NB = kSub + 2 * LH;     // wiped samples:   n = sub0-LH .. sub0+255+LH
+    __shared__ float sChips[2048];
+    __shared__ float sRep[4][NREP + 3];
+    __shared__ float2 sB[4][NB];
+    __shared__ float2 sAcc[4][NL];
+
+    const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const BcsChanDev ch = chan[w * K + k];
+    for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
+    const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;
+    const float mRe = (float)((double)sums[2 * w] / (double)(float)S);
+    const float mIm = (float)((double)sums[2 * w + 1] / (double)(float)S);
+    const int16_t *x = iq + (size_t)w * winStride * 2;
+    float xp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xp[i] = (float)(4 * lane + i) - 127.5f;
+    __syncthreads();
+
+    for (int side = 0; side < 2; ++side) {
+        f2 acc0 = f2{0.f, 0.f};   // direct sum at lag -LH (per-lane partial)
+        f2 D = f2{0.f, 0.f};      // this lane's lag step  l = lane - LH
+        for (int t = 0; t < tilesPerBlock; ++t) {
+            const int sub = (blk * tilesPerBlock + t) * 4 + wave;
+            const int sub0 = sub * kSub;
+            const int lo = sub0 - 1, hi = sub0 + kSub - 1 + LH;   // replica index range
+            bool active = sub < nSub;
+            if (active) {
+                if (!ch.hasFlip) active = (side == 0);
+                else if (lo >= 0 && hi < S) active = (side == 0) ? (lo < ch.idxNext) : (hi >= ch.idxNext);
+            }
+            f2 M[kNMom];
+#pragma unroll
+            for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
+            if (active) {
+                // ---- masked replica, entries e <-> m = lo + e (circular)
+                if (fastIdx && lo >= 0 && hi < S) {
+                    const int ci0 = (int)floor(fma((double)lo, ch.codeStep, ch.rc));
+                    const int shift = (ci0 % kLCA) - ci0;
+                    const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
+                    for (int e = lane; e < NREP; e += 64) {
+                        const int m = lo + e;
+                        float r = sChips[(int)floor(fma((double)m, ch.codeStep, ch.rc)) + shift];
+                        if (straddle) r = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
+                        sRep[wave][e] = r;
+                    }
+                } else {
+                    for (int e = lane; e < NREP; e += 64) {
+                        int m = lo + e;
+                        if (m < 0) m += S; else if (m >= S) m -= S;
+                        const int ci = ((int)floor(fma((double)m, ch.codeStep, ch.rc))) % kLCA;
+                        const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
+                        sRep[wave][e] = (sd == side) ? sChips[ci] : 0.f;
+                    }
+                }
+                // ---- wiped samples b[n] (circular), own 4 + one halo sample per lane -> LDS
+                const int n0 = sub0 + 4 * lane;
+                float re[4], im[4];
+                if (vecOK && n0 + 3 < S) {
+                    const int4 v = *reinterpret_cast<const int4 *>(x + 2 * (size_t)n0);
+                    re[0] = (float)(short)(v.x & 0xFFFF); im[0] = (float)(v.x >> 16);
+                    re[1] = (float)(short)(v.y & 0xFFFF); im[1] = (float)(v.y >> 16);
+                    re[2] = (float)(short)(v.z & 0xFFFF); im[2] = (float)(v.z >> 16);
+                    re[3] = (float)(short)(v.w & 0xFFFF); im[3] = (float)(v.w >> 16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int nn = n0 + i;
+                        if (nn >= S) nn -= S;   // beyond the window: the circular continuation (masked below where it is not a sample)
+                        const int v = *reinterpret_cast<const int *>(x + 2 * (size_t)nn);
+                        re[i] = (float)(short)(v & 0xFFFF);
+                        im[i] = (float)(v >> 16);
+                    }
+                }
+                f2 bown[4], wown[4];
+                {
+                    int nn = n0 >= S ? n0 - S : n0;
+                    double ph = fma((double)nn, ch.carrStep, ch.ri);
+                    ph -= floor(ph);
+                    const float f = (float)ph;
+                    float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (n0 + i == S) {   // phase restarts where the circular continuation begins
+                            double p2 = ch.ri - floor(ch.ri);
+                            wr = __builtin_amdgcn_cosf((float)p2); wi = -__builtin_amdgcn_sinf((float)p2);
+                        }
+                        wown[i] = f2{wr, wi};
+                        bown[i] = f2{re[i] * wr - im[i] * wi, re[i] * wi + im[i] * wr};
+                        sB[wave][LH + 4 * lane + i] = make_float2(bown[i].x, bown[i].y);
+                        const float nr = wr * ch.rotRe - wi * ch.rotIm;
+                        wi = wr * ch.rotIm + wi * ch.rotRe;
+                        wr = nr;
+                    }
+                }
+                {   // halo: lanes 0..31 -> n = sub0-LH+lane ; lanes 32..63 -> n = sub0+256+(lane-32)
+                    int nh = (lane < LH) ? (sub0 - LH + lane) : (sub0 + kSub + lane - LH);
+                    const int e = (lane < LH) ? lane : (kSub + lane);
+                    if (nh < 0) nh += S; else if (nh >= S) nh -= S;
+                    const int v = *reinterpret_cast<const int *>(x + 2 * (size_t)nh);
+                    const float hr = (float)(short)(v & 0xFFFF), hi2 = (float)(v >> 16);
+                    double ph = fma((double)nh, ch.carrStep, ch.ri);
+                    ph -= floor(ph);
+                    const float f = (float)ph;
+                    const float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
+                    sB[wave][e] = make_float2(hr * wr - hi2 * wi, hr * wi + hi2 * wr);
+                }
+                // ---- own samples: direct lag -LH, carrier moments (only real samples n < S)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool real = n0 + i < S;
+                    const float rl = real ? sRep[wave][4 * lane + i + 1 + LH] : 0.f;   // r[n + LH]
+                    acc0 = __builtin_elementwise_fma(bown[i], f2{rl, rl}, acc0);
+                    const float r0 = real ? sRep[wave][4 * lane + i + 1] : 0.f;        // r[n]
+                    const float cr = (bown[i].x - (mRe * wown[i].x - mIm * wown[i].y)) * r0;
+                    const float cim = (bown[i].y - (mRe * wown[i].y + mIm * wown[i].x)) * r0;
+                    f2 cp = f2{cr, cim};
+#pragma unroll
+                    for (int p = 0; p < kNMom; ++p) {
+                        M[p] += cp;
+                        cp *= xp[i];
+                    }
+                }
+                // ---- boundaries m = sub0 + 4*lane + i (only m < S exist): J = r[m-1] - r[m]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * lane + i;   // rep[e] = r[m-1], rep[e+1] = r[m]
+                    const float J = (sub0 + e < S) ? (sRep[wave][e] - sRep[wave][e + 1]) : 0.f;
+                    unsigned long long mask = __ballot(J != 0.f);
+                    while (mask) {
+                        const int src = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        const float Jv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, J), src));
+                        // b index for lag l = lane - LH:  n = m + l  ->  entry (m - sub0 + LH) + (lane - LH)
+                        const float2 bv = sB[wave][4 * src + i + lane];
+                        D = __builtin_elementwise_fma(f2{bv.x, bv.y}, f2{Jv, Jv}, D);
+                    }
+                }
+            }
+            if (sub < nSub) {
+                float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
+                if (active) {
+                    float mm[2 * kNMom];
+#pragma unroll
+                    for (int p = 0; p < kNMom; ++p) { mm[2 * p] = M[p].x; mm[2 * p + 1] = M[p].y; }
+                    dpp_sum_lane63(mm);
+                    if (lane == 63) {
+#pragma unroll
+                        for (int p = 0; p < kNMom; ++p) o[p] = make_float2(mm[2 * p], mm[2 * p + 1]);
+                    }
+                } else if (lane < kNMom) {
+                    o[lane] = make_float2(0.f, 0.f);
+                }
+            }
+        }
+        {
+            float aa[3] = {acc0.x, acc0.y, 0.f};
+            dpp_sum_lane63(aa);
+            if (lane == 63) sAcc[wave][0] = make_float2(aa[0], aa[1]);
+            sAcc[wave][1 + lane] = make_float2(D.x, D.y);
+        }
+        __syncthreads();
+        for (int j = tid; j < NL; j += 256) {
+            float2 sum = sAcc[0][j];
+            sum.x += sAcc[1][j].x; sum.y += sAcc[1][j].y;
+            sum.x += sAcc[2][j].x; sum.y += sAcc[2][j].y;
+            sum.x += sAcc[3][j].x; sum.y += sAcc[3][j].y;
+            part[((((size_t)w * K + k) * nBlk + blk) * 2 + side) * NL + j] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
 template <int kNMom>
-__global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSub, int nBlk, int LH, int L, int B,
+__global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide,
                                                            long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
                                                            const float2 *__restrict__ mom,
@@ -292,6 +483,16 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSu
             float2 t = sTmp[tid];
             for (int q = 1; q < T; ++q) { t.x += sTmp[tid + q].x; t.y += sTmp[tid + q].y; }
             sXY[pair] = t;
+        }
+        __syncthreads();
+    }
+    if (wide) {   // wide-lag layout: [0] = corr[-LH], [1+i] = step D[-LH+i]  ->  corr[j] by prefix sum
+        if (tid < 2) {
+            float2 run = sXY[tid * NL];
+            for (int j = 1; j < NL; ++j) {
+                run.x += sXY[tid * NL + j].x; run.y += sXY[tid * NL + j].y;
+                sXY[tid * NL + j] = run;
+            }
         }
         __syncthreads();
     }
@@ -385,6 +586,7 @@ struct dpe_bcs {
     dpe_bcs_config cfg;
     int LH;             // internal lag half width (4,8,16,32)
     int nSub, nBlk, tilesPerBlock, nMom;
+    bool wideAllowed = true;   // dpe_bcs_set_option("wide", 0) forces the dense kernel (A/B tests)
     long long C;
     int8_t *chipTable_d = nullptr;
     long long *sums_d = nullptr;
@@ -535,6 +737,16 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         if (h->nMom == 4) DPE_LAUNCH_BANK2(LHV, 4); \
         else DPE_LAUNCH_BANK2(LHV, 6);  \
     } while (0)
+    // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
+    // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else the dense kernel
+    const bool wide = h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
+    if (wide) {
+#define DPE_LAUNCH_WIDE(NM)                                                                                        \
+    hipLaunchKernelGGL((bcs_bank_wide_kernel<NM>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, h->part_d, h->mom_d)
+        if (h->nMom == 4) DPE_LAUNCH_WIDE(4); else DPE_LAUNCH_WIDE(6);
+#undef DPE_LAUNCH_WIDE
+    } else
     switch (h->LH) {
         case 4: DPE_LAUNCH_BANK(4); break;
         case 8: DPE_LAUNCH_BANK(8); break;
@@ -548,11 +760,11 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
     if (h->nMom == 4)
         hipLaunchKernelGGL(bcs_finalize_kernel<4>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
-                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
+                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     else
         hipLaunchKernelGGL(bcs_finalize_kernel<6>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
-                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, h->C, h->chan_d, h->part_d, h->mom_d,
+                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);
     DPE_CHECK_HIP(hipGetLastError());
