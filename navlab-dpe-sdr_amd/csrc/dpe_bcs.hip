@@ -36,7 +36,23 @@ struct BcsChanDev {
     int32_t hasFlip;  // 0 < idxNext < S
     int32_t prn;
     int32_t pad;
+    double fc, fi;    // raw code / carrier frequency (time-table mode)
 };
+
+// Time of sample n: n/fs, or (TABLE) the reference's ns-rounded table (BCS_GenTimeIdcs,
+// batchcorrscores.cu:185-196) when the sampling period is not an integer number of nanoseconds.
+template <bool TABLE>
+__device__ __forceinline__ double code_phase(const BcsChanDev &ch, const double *tT, int m)
+{
+    if (TABLE) return fma(tT[m], ch.fc, ch.rc);
+    return fma((double)m, ch.codeStep, ch.rc);
+}
+template <bool TABLE>
+__device__ __forceinline__ double carr_phase(const BcsChanDev &ch, const double *tT, int n)
+{
+    if (TABLE) return fma(tT[n], ch.fi, ch.ri);
+    return fma((double)n, ch.carrStep, ch.ri);
+}
 
 // ------------------------------------------------------------------------------------------
 // DC sum (thrust::reduce at batchcorrscores.cu:1065): exact int64 sums, order-independent.
@@ -80,12 +96,13 @@ __global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-template <int LH, int kNMom>
+template <int LH, int kNMom, bool TABLE>
 __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
                                                        int K, int nSub, int tilesPerBlock, int nBlk, int vecOK,
                                                        const BcsChanDev *__restrict__ chan,
                                                        const long long *__restrict__ sums,
                                                        const int8_t *__restrict__ chipTable,
+                                                       const double *__restrict__ tT,
                                                        float2 *__restrict__ part, float2 *__restrict__ mom)
 {
     constexpr int NL = 2 * LH + 1;      // lags
@@ -149,12 +166,12 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
                 if (fastIdx && lo >= 0 && hi < S) {
                     // common case (no circular wrap inside the sub-tile): the chip index relative to the
                     // sub-tile's first entry indexes the periodically extended table -- no modulo, no branch
-                    const int ci0 = (int)floor(fma((double)lo, ch.codeStep, ch.rc));
+                    const int ci0 = (int)floor(code_phase<TABLE>(ch, tT, lo));
                     const int shift = (ci0 % kLCA) - ci0;
                     const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
                     for (int e = lane; e < NREP; e += 64) {
                         const int m = lo + e;
-                        const int ci = (int)floor(fma((double)m, ch.codeStep, ch.rc)) + shift;
+                        const int ci = (int)floor(code_phase<TABLE>(ch, tT, m)) + shift;
                         float r = sChips[ci];
                         if (straddle) r = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
                         sRep[wave][e] = r;
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
                     for (int e = lane; e < NREP; e += 64) {
                         int m = lo + e;
                         if (m < 0) m += S; else if (m >= S) m -= S;
-                        const double cph = fma((double)m, ch.codeStep, ch.rc);
+                        const double cph = code_phase<TABLE>(ch, tT, m);
                         const int ci = ((int)floor(cph)) % kLCA;
                         const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
                         sRep[wave][e] = (sd == side) ? sChips[ci] : 0.f;
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
             if (active) {
                 // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300):
                 // fp64 phase seed per lane, hardware sin/cos in revolutions, 3 fp32 rotations.
-                double ph = fma((double)n0, ch.carrStep, ch.ri);
+                double ph = carr_phase<TABLE>(ch, tT, n0 < S ? n0 : S - 1);   // lanes past the window carry zero samples
                 ph -= floor(ph);
                 const float f = (float)ph;
                 float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
@@ -261,12 +278,13 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
 // one FMA pair per sample) plus, for each of the ~codeStep*128 boundaries of the tile, one LDS read and
 // one FMA per LANE with lanes <-> the 64 lag steps.  The finalize kernel prefix-sums the steps.
 // part layout per (block, side): [0] = corr[-32], [1 + i] = D[-32 + i], i = 0..63  (65 entries, as NL).
-template <int kNMom>
+template <int kNMom, bool TABLE>
 __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
                                                             int K, int nSub, int tilesPerBlock, int nBlk, int vecOK,
                                                             const BcsChanDev *__restrict__ chan,
                                                             const long long *__restrict__ sums,
                                                             const int8_t *__restrict__ chipTable,
+                                                            const double *__restrict__ tT,
                                                             float2 *__restrict__ part, float2 *__restrict__ mom)
 {
     constexpr int LH = 32, NL = 2 * LH + 1;
@@ -308,12 +326,12 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__res
             if (active) {
                 // ---- masked replica, entries e <-> m = lo + e (circular)
                 if (fastIdx && lo >= 0 && hi < S) {
-                    const int ci0 = (int)floor(fma((double)lo, ch.codeStep, ch.rc));
+                    const int ci0 = (int)floor(code_phase<TABLE>(ch, tT, lo));
                     const int shift = (ci0 % kLCA) - ci0;
                     const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
                     for (int e = lane; e < NREP; e += 64) {
                         const int m = lo + e;
-                        float r = sChips[(int)floor(fma((double)m, ch.codeStep, ch.rc)) + shift];
+                        float r = sChips[(int)floor(code_phase<TABLE>(ch, tT, m)) + shift];
                         if (straddle) r = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
                         sRep[wave][e] = r;
                     }
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__res
                     for (int e = lane; e < NREP; e += 64) {
                         int m = lo + e;
                         if (m < 0) m += S; else if (m >= S) m -= S;
-                        const int ci = ((int)floor(fma((double)m, ch.codeStep, ch.rc))) % kLCA;
+                        const int ci = ((int)floor(code_phase<TABLE>(ch, tT, m))) % kLCA;
                         const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
                         sRep[wave][e] = (sd == side) ? sChips[ci] : 0.f;
                     }
@@ -348,7 +366,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__res
                 f2 bown[4], wown[4];
                 {
                     int nn = n0 >= S ? n0 - S : n0;
-                    double ph = fma((double)nn, ch.carrStep, ch.ri);
+                    double ph = carr_phase<TABLE>(ch, tT, nn);
                     ph -= floor(ph);
                     const float f = (float)ph;
                     float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__res
                     if (nh < 0) nh += S; else if (nh >= S) nh -= S;
                     const int v = *reinterpret_cast<const int *>(x + 2 * (size_t)nh);
                     const float hr = (float)(short)(v & 0xFFFF), hi2 = (float)(v >> 16);
-                    double ph = fma((double)nh, ch.carrStep, ch.ri);
+                    double ph = carr_phase<TABLE>(ch, tT, nh);
                     ph -= floor(ph);
                     const float f = (float)ph;
                     const float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
@@ -589,6 +607,8 @@ struct dpe_bcs {
     bool wideAllowed = true;   // dpe_bcs_set_option("wide", 0) forces the dense kernel (A/B tests)
     long long C;
     int8_t *chipTable_d = nullptr;
+    double *tTable_d = nullptr;   // ns-rounded sample times (always allocated; used only when useTable)
+    bool useTable = false;
     long long *sums_d = nullptr;
     dpe::BcsChanDev *chan_d = nullptr;
     dpe::BcsChanDev *chan_h = nullptr;  // pinned staging
@@ -627,13 +647,14 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     DPE_REQUIRE(std::pow(th, 6) / 720.0 < 2e-7,
                 "[BatchCorrScores] create: binHalfWidth %d too wide for the moment expansion at C=%lld",
                 cfg->binHalfWidth, C);
-    // The kernels index time as n/fs; the reference rounds t_n to 1 ns (BCS_GenTimeIdcs :191-193).
-    // Accept only sampling rates for which that rounding is a no-op (all usual SDR rates).
+    // The reference rounds the sample times to 1 ns (BCS_GenTimeIdcs :191-193).  For integer-ns sampling
+    // periods (all usual SDR rates) that is a no-op and the kernels use n/fs; otherwise they read the
+    // reference's own table.
     const double fs = cfg->samplingFrequency;
-    for (int n = 0; n < S; n += (S > 4096 ? 97 : 1)) {
+    bool needTable = false;
+    for (int n = 0; n < S && !needTable; ++n) {
         const double t = (double)n / fs, tr = std::round(t * 1.0e9) / 1.0e9;
-        DPE_REQUIRE(std::fabs(t - tr) <= 4e-16 * (t + 1e-9),
-                    "[BatchCorrScores] create: samplingFrequency %.3f Hz has a non-integer-ns period (unsupported)", fs);
+        if (std::fabs(t - tr) > 4e-16 * (t + 1e-9)) needTable = true;
     }
     dpe_bcs *h = new dpe_bcs();
     h->cfg = *cfg;
@@ -648,6 +669,13 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     std::vector<int8_t> table(37 * 1024, 0);
     for (int prn = 1; prn <= 37; ++prn) gen_ca_code_host(prn, table.data() + (prn - 1) * 1024);
     h->chipTable_d = dev_alloc<int8_t>(table.size());
+    {
+        std::vector<double> tt(S);
+        for (int n = 0; n < S; ++n) tt[n] = std::round(((double)n / fs) * 1.0e9) / 1.0e9;
+        h->tTable_d = dev_alloc<double>(S);
+        if (h->tTable_d) (void)hipMemcpy(h->tTable_d, tt.data(), sizeof(double) * S, hipMemcpyHostToDevice);
+        h->useTable = needTable;
+    }
     h->sums_d = dev_alloc<long long>(2 * W);
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     h->part_d = dev_alloc<float2>(W * K * h->nBlk * 2 * (2 * h->LH + 1));
@@ -655,7 +683,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->codeBank_d = dev_alloc<float2>(W * K * (2 * cfg->lagHalfWidth + 1));
     h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
     h->info_d = dev_alloc<int>(W * K);
-    if (!h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->codeBank_d || !h->carrBank_d ||
+    if (!h->tTable_d || !h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->codeBank_d || !h->carrBank_d ||
         !h->info_d || hipHostMalloc((void **)&h->chan_h, W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrScores] create: device allocation failed");
         dpe_bcs_destroy(h);
@@ -672,7 +700,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
 int dpe_bcs_destroy(dpe_bcs *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->codeBank_d, h->carrBank_d, h->info_d};
+    void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->codeBank_d, h->carrBank_d, h->info_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chan_h) (void)hipHostFree(h->chan_h);
     delete h;
@@ -699,6 +727,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         d.codeStep = c.codeFrequency / fs;
         d.ri = c.carrierPhaseStart;
         d.carrStep = c.carrierFrequency / fs;
+        d.fc = c.codeFrequency;
+        d.fi = c.carrierFrequency;
         const double ang = -6.283185307179586476925286766559 * d.carrStep;
         d.rotRe = (float)std::cos(ang);
         d.rotIm = (float)std::sin(ang);
@@ -727,10 +757,15 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     if (tpb > 16) tpb = 16;
     const int nBlk = (nTiles + tpb - 1) / tpb;
     const dim3 grid(nBlk, nChan, nWindows), block(256);
-#define DPE_LAUNCH_BANK2(LHV, NM)                                                                                       \
-    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
+#define DPE_LAUNCH_BANK3(LHV, NM, TB)                                                                                   \
+    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, \
-                       h->part_d, h->mom_d)
+                       h->tTable_d, h->part_d, h->mom_d)
+#define DPE_LAUNCH_BANK2(LHV, NM)                           \
+    do {                                                    \
+        if (h->useTable) DPE_LAUNCH_BANK3(LHV, NM, true);   \
+        else DPE_LAUNCH_BANK3(LHV, NM, false);              \
+    } while (0)
     h->prof.begin(1, stream);
 #define DPE_LAUNCH_BANK(LHV)            \
     do {                                \
@@ -741,10 +776,11 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else the dense kernel
     const bool wide = h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
     if (wide) {
-#define DPE_LAUNCH_WIDE(NM)                                                                                        \
-    hipLaunchKernelGGL((bcs_bank_wide_kernel<NM>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
-                       S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, h->part_d, h->mom_d)
-        if (h->nMom == 4) DPE_LAUNCH_WIDE(4); else DPE_LAUNCH_WIDE(6);
+#define DPE_LAUNCH_WIDE(NM, TB)                                                                                    \
+    hipLaunchKernelGGL((bcs_bank_wide_kernel<NM, TB>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
+        if (h->nMom == 4) { if (h->useTable) DPE_LAUNCH_WIDE(4, true); else DPE_LAUNCH_WIDE(4, false); }
+        else { if (h->useTable) DPE_LAUNCH_WIDE(6, true); else DPE_LAUNCH_WIDE(6, false); }
 #undef DPE_LAUNCH_WIDE
     } else
     switch (h->LH) {
@@ -755,6 +791,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     }
 #undef DPE_LAUNCH_BANK
 #undef DPE_LAUNCH_BANK2
+#undef DPE_LAUNCH_BANK3
     h->prof.end(1, stream);
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;

@@ -231,6 +231,16 @@ def test_ragged_sizes(kw, L, B):
     helpers.assert_parity(out, ref, tol=TOL)
 
 
+def test_non_integer_ns_sampling_period():
+    """fs = 2.046 MHz (period 488.76 ns): the reference's 1 ns rounding of the sample times
+    (BCS_GenTimeIdcs, batchcorrscores.cu:191-193) moves chip boundaries; the kernels then read the
+    reference's own time table instead of n/fs."""
+    case = helpers.make_case(seed=41, fs=2.046e6, S=40920, K=6, G=3000, amp=200.0)
+    out = helpers.run_gpu(case, 8, 40)
+    ref = helpers.run_oracle(case, 8, 40)
+    helpers.assert_parity(out, ref, tol=TOL)
+
+
 def test_max_channels_37():
     """CONST_PRN_MAX = 37 tracked SVs (the reference's allocation stride; PRN 37 itself is generated
     here although BCS_GenCACode never writes it, batchcorrscores.cu:127)."""
@@ -269,8 +279,6 @@ def test_argument_errors_are_reported():
     e = dpe.engine
     with pytest.raises(dpe.DpeError, match="lagHalfWidth"):
         dpe.BatchCorrScores(2.5e6, samples_per_window=50000, lag_half_width=40).Start()
-    with pytest.raises(dpe.DpeError, match="non-integer-ns"):
-        dpe.BatchCorrScores(2.048e6 * 1.0000001, samples_per_window=40960).Start()
     with pytest.raises(dpe.DpeError, match="too wide"):
         dpe.BatchCorrScores(2.5e6, samples_per_window=50000, bin_half_width=400).Start()
     bcs = dpe.BatchCorrScores(2.5e6, samples_per_window=50000, max_channels=4)
