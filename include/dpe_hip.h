@@ -256,6 +256,16 @@ int dpe_acq_surface(dpe_acq *h, const float **surface_dev, const float **maxPerC
 int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count);
 int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count);
 
+/* Closed-loop latency: with enable != 0 an Update whose shape and device pointers repeat (the per-window
+ * call of a running receiver, one entry per SampleBlock ring slot) is captured once as a hipGraph and
+ * replayed with a single launch afterwards; the pinned parameter blocks are re-read on every replay, so
+ * results are identical to the eager path.  Needs a created stream (not the null stream, which cannot be
+ * captured -- eager launches are used there) and is bypassed while dpe_*_profile is enabled.  The
+ * reference has no counterpart: its Update enqueues ~20 kernels per window (batchcorrscores.cu:1026-1190,
+ * batchcorrmanifold.cu:2520-2632). */
+int dpe_bcs_set_graph(dpe_bcs *h, int32_t enable);
+int dpe_bcm_set_graph(dpe_bcm *h, int32_t enable);
+
 /* Timing helper for bench.py: HIP events on the stream the kernels run on. */
 int dpe_event_create(void **ev);
 int dpe_event_record(void *ev, dpe_stream_t stream);

@@ -239,6 +239,37 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
     }
 }
 
+// Clears the arg-max keys and the out-of-window counters (contiguous).  A kernel rather than memset
+// nodes: see GraphCache in dpe_common.h.
+__global__ void bcm_clear_kernel(unsigned long long *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
+// Single-window variant: the per-SV coefficients of both manifolds ride in the kernel-argument segment
+// (first argument, read through the kernarg pointer) and are stored to sv[] for the scans that follow.
+struct BcmParamBlock {
+    BcmSvDev s[2][DPE_MAX_CHAN];
+};
+typedef const int __attribute__((address_space(4))) *kernarg_words_t;
+
+__global__ __launch_bounds__(256) void bcm_clear_params_kernel(BcmParamBlock pb, unsigned long long *p, int n,
+                                                               int *__restrict__ sv, int nChan, int velOffsetWords)
+{
+    (void)pb;
+    if (blockIdx.x == 0) {
+        kernarg_words_t src = (kernarg_words_t)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr int kWordsPerSv = (int)(sizeof(BcmSvDev) / 4), kVelSrc = DPE_MAX_CHAN * kWordsPerSv;
+        for (int i = threadIdx.x; i < nChan * kWordsPerSv; i += 256) {
+            sv[i] = src[i];
+            sv[velOffsetWords + i] = src[kVelSrc + i];
+        }
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 }  // namespace dpe
 
 // ============================================================================================
@@ -258,6 +289,7 @@ struct dpe_bcm {
     int lastW = 0;
     double posExtent = 0, velExtent = 0;
     dpe::KernelProfiler prof;  // slots: 0 pos scan, 1 vel scan
+    dpe::GraphCache graphs;
 };
 
 static int upload_grid(const double *src, int64_t G, std::vector<double> &keep, float4 **dst)
@@ -371,14 +403,13 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
         h->velScores_d = dev_alloc<float>(W * (size_t)cfg->velGridSize);
     }
     h->sv_d = dev_alloc<BcmSvDev>(2 * W * K);
-    h->keys_d = dev_alloc<unsigned long long>(2 * W);
-    h->oob_d = dev_alloc<unsigned long long>(2 * W);
+    h->keys_d = dev_alloc<unsigned long long>(4 * W);   // keys [W][2] then out-of-window counts [W][2]
+    h->oob_d = h->keys_d ? h->keys_d + 2 * W : nullptr;
     h->wsumHalf = (size_t)(dpe_bcm::kMaxSplit + 8 * W) * 5;   // >= nWindows * blocks-per-window of any launch
     h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
     if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->oob_d || !h->wsum_d ||
         hipHostMalloc((void **)&h->sv_h, 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&h->keys_h, 2 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&h->oob_h, 2 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&h->keys_h, 4 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
         dpe_bcm_destroy(h);
         return -1;
@@ -388,6 +419,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, false, true>(); allow_big_lds<1, false, true>(); allow_big_lds<2, false, true>();
     allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
+    h->oob_h = h->keys_h + 2 * W;
     h->win_h.resize(W);
     *out = h;
     return 0;
@@ -396,11 +428,11 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
 int dpe_bcm_destroy(dpe_bcm *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->oob_d, h->wsum_d};
+    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->sv_h) (void)hipHostFree(h->sv_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
-    if (h->oob_h) (void)hipHostFree(h->oob_h);
+    h->graphs.clear();
     delete h;
     return 0;
 }
@@ -468,10 +500,27 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         }
     }
     h->lastW = nWindows;
-    // one copy covers both manifolds' coefficient blocks
-    DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
-    DPE_CHECK_HIP(hipMemsetAsync(h->keys_d, 0, sizeof(unsigned long long) * 2 * nWindows, stream));
-    DPE_CHECK_HIP(hipMemsetAsync(h->oob_d, 0, sizeof(unsigned long long) * 2 * nWindows, stream));
+    h->lastSplit[0] = scan_split(h->cfg.posGridSize, nWindows);
+    h->lastSplit[1] = scan_split(h->cfg.velGridSize, nWindows);
+    GraphCache::Guard graphGuard{h->graphs, stream};
+    if (h->graphs.enabled && !h->prof.enabled) {
+        const int rc = h->graphs.begin({codeBank_dev, carrBank_dev, 0, nWindows, nChan,
+                                        (posInside ? 1 : 0) | (velInside ? 2 : 0), stream}, stream);
+        DPE_REQUIRE(rc >= 0, "[BatchCorrManifold] Update: hipGraph capture/replay failed");
+        if (rc == 1) return 0;
+    }
+    if (nWindows == 1 && !h->graphs.capturing) {
+        // closed loop: coefficients as kernel arguments (a captured graph would freeze them, so that path copies)
+        BcmParamBlock pb;
+        memcpy(pb.s[0], h->sv_h, sizeof(BcmSvDev) * nChan);
+        memcpy(pb.s[1], h->sv_h + (size_t)W * maxK, sizeof(BcmSvDev) * nChan);
+        hipLaunchKernelGGL(bcm_clear_params_kernel, dim3((4 * W + 255) / 256), dim3(256), 0, stream, pb, h->keys_d, 4 * W,
+                           reinterpret_cast<int *>(h->sv_d), nChan, (int)((size_t)W * maxK * sizeof(BcmSvDev) / 4));
+    } else {
+        // one copy covers both manifolds' coefficient blocks, one launch clears keys and counters
+        DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(bcm_clear_kernel, dim3((4 * W + 255) / 256), dim3(256), 0, stream, h->keys_d, 4 * W);
+    }
     const int nLag = 2 * L + 1, nBin = 2 * B + 1;
     {
         const long long G = h->cfg.posGridSize;
@@ -497,9 +546,19 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         h->prof.end(1, stream);
     }
     // results travel to pinned host memory on the same stream: dpe_bcm_results only has to synchronise
-    DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, h->keys_d, sizeof(unsigned long long) * 2 * nWindows, hipMemcpyDeviceToHost, stream));
-    DPE_CHECK_HIP(hipMemcpyAsync(h->oob_h, h->oob_d, sizeof(unsigned long long) * 2 * nWindows, hipMemcpyDeviceToHost, stream));
+    // (keys and counters are contiguous on both sides: one copy up to the last counter in use)
+    DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, h->keys_d, sizeof(unsigned long long) * (2 * (size_t)W + 2 * nWindows),
+                                 hipMemcpyDeviceToHost, stream));
+    DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrManifold] Update: hipGraph instantiate/launch failed");
     DPE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int dpe_bcm_set_graph(dpe_bcm *h, int32_t enable)
+{
+    DPE_REQUIRE(h, "[BatchCorrManifold] set_graph: null handle");
+    h->graphs.enabled = enable != 0;
+    if (!enable) h->graphs.clear();
     return 0;
 }
 

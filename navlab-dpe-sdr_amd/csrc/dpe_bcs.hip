@@ -55,9 +55,11 @@ __device__ __forceinline__ double carr_phase(const BcsChanDev &ch, const double 
 }
 
 // ------------------------------------------------------------------------------------------
-// DC sum (thrust::reduce at batchcorrscores.cu:1065): exact int64 sums, order-independent.
-__global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
-                                                      long long *__restrict__ sums)
+// DC sum (thrust::reduce at batchcorrscores.cu:1065): exact int64 sums.  Each block writes its own slot
+// sums[w][blockIdx.x][2] (no atomics, nothing to zero beforehand -- the whole Update stays free of memset
+// nodes, which matters for the hipGraph replay); consumers add the <= kSumSlots slots (window_mean).
+constexpr int kSumSlots = 64;
+__device__ __forceinline__ void sum_body(const int16_t *__restrict__ iq, long long winStride, int S, long long *__restrict__ sums)
 {
     const int w = blockIdx.y;
     const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);
@@ -89,16 +91,56 @@ __global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict_
         tI += __shfl_xor(tI, off, 64);
         tQ += __shfl_xor(tQ, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sums[2 * w]), (unsigned long long)tI);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sums[2 * w + 1]), (unsigned long long)tQ);
+    __shared__ long long sW[4][2];
+    if ((threadIdx.x & 63) == 0) { sW[threadIdx.x >> 6][0] = tI; sW[threadIdx.x >> 6][1] = tQ; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        long long *o = sums + ((size_t)w * kSumSlots + blockIdx.x) * 2;
+        o[threadIdx.x] = sW[0][threadIdx.x] + sW[1][threadIdx.x] + sW[2][threadIdx.x] + sW[3][threadIdx.x];
     }
+}
+
+__global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
+                                                      long long *__restrict__ sums)
+{
+    sum_body(iq, winStride, S, sums);
+}
+
+// Closed-loop variant (few channels in flight): the channel parameters ride in the kernel-argument
+// segment and block (0,0) stores them to chan[] for the kernels that follow on the stream -- no H2D copy
+// command, no staging buffer to keep alive.  pb must stay the FIRST argument: it is read through the
+// kernarg segment pointer, so that dynamic indexing never copies the block to private memory.
+struct BcsParamBlock {
+    BcsChanDev c[DPE_MAX_CHAN];
+};
+typedef const int __attribute__((address_space(4))) *kernarg_words_t;
+
+__global__ __launch_bounds__(256) void bcs_sum_params_kernel(BcsParamBlock pb, const int16_t *__restrict__ iq,
+                                                             long long winStride, int S, long long *__restrict__ sums,
+                                                             int nWords, int *__restrict__ chanOut)
+{
+    (void)pb;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        kernarg_words_t src = (kernarg_words_t)__builtin_amdgcn_kernarg_segment_ptr();
+        for (int i = threadIdx.x; i < nWords; i += 256) chanOut[i] = src[i];
+    }
+    sum_body(iq, winStride, S, sums);
+}
+
+// DC mean = sum / (float)S in fp64 (batchcorrscores.cu:1065-1066,1210-1216), then fp32
+__device__ __forceinline__ void window_mean(const long long *__restrict__ sums, int w, int nSumBlk, int S, float &mRe, float &mIm)
+{
+    long long tI = 0, tQ = 0;
+    const long long *p = sums + (size_t)w * kSumSlots * 2;
+    for (int b = 0; b < nSumBlk; ++b) { tI += p[2 * b]; tQ += p[2 * b + 1]; }
+    mRe = (float)((double)tI / (double)(float)S);
+    mIm = (float)((double)tQ / (double)(float)S);
 }
 
 // ------------------------------------------------------------------------------------------
 template <int LH, int kNMom, bool TABLE>
 __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
-                                                       int K, int nSub, int tilesPerBlock, int nBlk, int vecOK,
+                                                       int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                        const BcsChanDev *__restrict__ chan,
                                                        const long long *__restrict__ sums,
                                                        const int8_t *__restrict__ chipTable,
@@ -117,9 +159,8 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
     const BcsChanDev ch = chan[w * K + k];
     for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
     const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;   // chip span of one sub-tile fits the extended table
-    // DC mean = sum / (float)S in fp64 (batchcorrscores.cu:1065-1066,1210-1216), then fp32
-    const float mRe = (float)((double)sums[2 * w] / (double)(float)S);
-    const float mIm = (float)((double)sums[2 * w + 1] / (double)(float)S);
+    float mRe, mIm;
+    window_mean(sums, w, nSumBlk, S, mRe, mIm);
     const int16_t *x = iq + (size_t)w * winStride * 2;
     float xp[4];
 #pragma unroll
@@ -280,7 +321,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
 // part layout per (block, side): [0] = corr[-32], [1 + i] = D[-32 + i], i = 0..63  (65 entries, as NL).
 template <int kNMom, bool TABLE>
 __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
-                                                            int K, int nSub, int tilesPerBlock, int nBlk, int vecOK,
+                                                            int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                             const BcsChanDev *__restrict__ chan,
                                                             const long long *__restrict__ sums,
                                                             const int8_t *__restrict__ chipTable,
@@ -300,8 +341,8 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__res
     const BcsChanDev ch = chan[w * K + k];
     for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
     const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;
-    const float mRe = (float)((double)sums[2 * w] / (double)(float)S);
-    const float mIm = (float)((double)sums[2 * w + 1] / (double)(float)S);
+    float mRe, mIm;
+    window_mean(sums, w, nSumBlk, S, mRe, mIm);
     const int16_t *x = iq + (size_t)w * winStride * 2;
     float xp[4];
 #pragma unroll
@@ -617,6 +658,7 @@ struct dpe_bcs {
     int lastW = 0, lastK = 0;
     std::vector<int32_t> idxNext_h;
     dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
+    dpe::GraphCache graphs;
 };
 
 static long long next_pow2(long long x)
@@ -676,7 +718,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         if (h->tTable_d) (void)hipMemcpy(h->tTable_d, tt.data(), sizeof(double) * S, hipMemcpyHostToDevice);
         h->useTable = needTable;
     }
-    h->sums_d = dev_alloc<long long>(2 * W);
+    h->sums_d = dev_alloc<long long>(2 * W * kSumSlots);
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     h->part_d = dev_alloc<float2>(W * K * h->nBlk * 2 * (2 * h->LH + 1));
     h->mom_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMomMax);
@@ -703,6 +745,7 @@ int dpe_bcs_destroy(dpe_bcs *h)
     void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->codeBank_d, h->carrBank_d, h->info_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chan_h) (void)hipHostFree(h->chan_h);
+    h->graphs.clear();
     delete h;
     return 0;
 }
@@ -742,13 +785,35 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     }
     h->lastW = nWindows;
     h->lastK = nChan;
-    DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
-    DPE_CHECK_HIP(hipMemsetAsync(h->sums_d, 0, sizeof(long long) * 2 * nWindows, stream));
-    const int sumBlocks = (S / 1024 / 8 > 0) ? (S / 1024 / 8 > 64 ? 64 : S / 1024 / 8) : 1;
-    h->prof.begin(0, stream);
-    hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
-                       (long long)windowStrideSamples, S, h->sums_d);
-    h->prof.end(0, stream);
+    // the per-kernel event timing and the graph replay exclude each other
+    const bool useGraph = h->graphs.enabled && !h->prof.enabled;
+    GraphCache::Guard graphGuard{h->graphs, stream};
+    const int sumBlocks = (S / 1024 / 8 > 0) ? (S / 1024 / 8 > kSumSlots ? kSumSlots : S / 1024 / 8) : 1;
+    if (useGraph) {
+        const int rc = h->graphs.begin({samples_dev, nullptr, (long long)windowStrideSamples, nWindows, nChan,
+                                        h->wideAllowed ? 1 : 0, stream}, stream);
+        DPE_REQUIRE(rc >= 0, "[BatchCorrScores] Update: hipGraph capture/replay failed");
+        if (rc == 1) return 0;
+    }
+    // few channels (the per-window call of a running receiver): parameters travel as kernel arguments;
+    // batches go through one H2D copy from the pinned staging block.  A captured graph would freeze
+    // by-value arguments, so the graph path always copies.
+    const bool inlineParams = !h->graphs.capturing && nWindows * nChan <= DPE_MAX_CHAN;
+    if (inlineParams) {
+        BcsParamBlock pb;
+        memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
+        h->prof.begin(0, stream);
+        hipLaunchKernelGGL(bcs_sum_params_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, pb, samples_dev,
+                           (long long)windowStrideSamples, S, h->sums_d, (int)(sizeof(BcsChanDev) / 4) * nWindows * nChan,
+                           reinterpret_cast<int *>(h->chan_d));
+        h->prof.end(0, stream);
+    } else {
+        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        h->prof.begin(0, stream);
+        hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
+                           (long long)windowStrideSamples, S, h->sums_d);
+        h->prof.end(0, stream);
+    }
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     // tiles per block: amortise the end-of-block lag reduction while keeping >= ~4096 blocks in flight
     const int nTiles = (h->nSub + 3) / 4;
@@ -759,7 +824,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const dim3 grid(nBlk, nChan, nWindows), block(256);
 #define DPE_LAUNCH_BANK3(LHV, NM, TB)                                                                                   \
     hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
-                       S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, \
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, \
                        h->tTable_d, h->part_d, h->mom_d)
 #define DPE_LAUNCH_BANK2(LHV, NM)                           \
     do {                                                    \
@@ -778,7 +843,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     if (wide) {
 #define DPE_LAUNCH_WIDE(NM, TB)                                                                                    \
     hipLaunchKernelGGL((bcs_bank_wide_kernel<NM, TB>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
-                       S, nChan, h->nSub, tpb, nBlk, vecOK, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
         if (h->nMom == 4) { if (h->useTable) DPE_LAUNCH_WIDE(4, true); else DPE_LAUNCH_WIDE(4, false); }
         else { if (h->useTable) DPE_LAUNCH_WIDE(6, true); else DPE_LAUNCH_WIDE(6, false); }
 #undef DPE_LAUNCH_WIDE
@@ -804,7 +869,16 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
                            nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);
+    DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrScores] Update: hipGraph instantiate/launch failed");
     DPE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int dpe_bcs_set_graph(dpe_bcs *h, int32_t enable)
+{
+    DPE_REQUIRE(h, "[BatchCorrScores] set_graph: null handle");
+    h->graphs.enabled = enable != 0;
+    if (!enable) h->graphs.clear();
     return 0;
 }
 
@@ -842,9 +916,16 @@ int dpe_bcs_read_info(dpe_bcs *h, int32_t *idxNext, int32_t *noFlipLarger, doubl
     if (idxNext) memcpy(idxNext, h->idxNext_h.data(), sizeof(int32_t) * n);
     if (noFlipLarger) DPE_CHECK_HIP(hipMemcpy(noFlipLarger, h->info_d, sizeof(int) * n, hipMemcpyDeviceToHost));
     if (mean) {
-        std::vector<long long> s(2 * h->lastW);
-        DPE_CHECK_HIP(hipMemcpy(s.data(), h->sums_d, sizeof(long long) * 2 * h->lastW, hipMemcpyDeviceToHost));
-        for (int i = 0; i < 2 * h->lastW; ++i) mean[i] = (double)s[i] / (double)(float)h->cfg.samplesPerWindow;
+        using dpe::kSumSlots;
+        const int S = h->cfg.samplesPerWindow;
+        const int sumBlocks = (S / 1024 / 8 > 0) ? (S / 1024 / 8 > kSumSlots ? kSumSlots : S / 1024 / 8) : 1;
+        std::vector<long long> s((size_t)2 * kSumSlots * h->lastW);
+        DPE_CHECK_HIP(hipMemcpy(s.data(), h->sums_d, sizeof(long long) * s.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 2 * h->lastW; ++i) {
+            long long t = 0;
+            for (int b = 0; b < sumBlocks; ++b) t += s[((size_t)(i / 2) * kSumSlots + b) * 2 + (i & 1)];
+            mean[i] = (double)t / (double)(float)S;
+        }
     }
     return 0;
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "dpe_bcm_scores", "dpe_bcm_keys", "dpe_bcm_results_from_keys", "dpe_event_create", "dpe_event_record",
     "dpe_event_elapsed_ms", "dpe_event_destroy", "dpe_chm_create", "dpe_chm_destroy", "dpe_chm_start",
     "dpe_chm_update", "dpe_chm_outputs", "dpe_bcs_profile", "dpe_bcm_profile", "dpe_acq_create", "dpe_acq_destroy",
-    "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface",
+    "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface", "dpe_bcs_set_graph", "dpe_bcm_set_graph",
 ]
 
 
@@ -116,6 +116,24 @@ def _stream(stream):
     if hasattr(stream, "cuda_stream"):
         return C.c_void_p(stream.cuda_stream)
     return C.c_void_p(int(stream))
+
+
+class Stream:
+    """A HIP stream owned by the library (dpe_stream_create); pass it as ``stream=`` to the modules."""
+
+    def __init__(self):
+        self._s = C.c_void_p(None)
+        _check(lib().dpe_stream_create(C.byref(self._s)))
+        self.cuda_stream = self._s.value
+
+    def synchronize(self):
+        _check(lib().dpe_stream_synchronize(self._s))
+
+    def close(self):
+        if self._s:
+            lib().dpe_stream_destroy(self._s)
+            self._s = C.c_void_p(None)
+            self.cuda_stream = 0
 
 
 def carr_fft_len(S):
@@ -212,6 +230,10 @@ class BatchCorrScores:
                                     chan.ctypes.data_as(C.POINTER(ChanStart)), _stream(stream)))
         self._W, self._K = W, K
         return 0
+
+    def set_graph(self, enable=True):
+        """Replay repeated Updates as one hipGraph launch (needs a created stream, see dpe_hip.h)."""
+        _check(lib().dpe_bcs_set_graph(self._h, C.c_int32(1 if enable else 0)))
 
     def profile(self, enable=True):
         """-> {kernel: (total_ms, launches)} since the previous call; sets the enable flag."""
@@ -333,6 +355,10 @@ class BatchCorrManifold:
         ps = d2h(self.PosScores, self._W * Gp * 4, np.float32, stream).reshape(self._W, Gp)
         vs = d2h(self.VelScores, self._W * Gv * 4, np.float32, stream).reshape(self._W, Gv)
         return ps, vs
+
+    def set_graph(self, enable=True):
+        """Replay repeated Updates as one hipGraph launch (needs a created stream, see dpe_hip.h)."""
+        _check(lib().dpe_bcm_set_graph(self._h, C.c_int32(1 if enable else 0)))
 
     def profile(self, enable=True):
         ms, cnt = (C.c_float * 2)(), (C.c_int32 * 2)()

@@ -27,6 +27,7 @@ int main(int argc, char **argv)
     std::string samples, handoff, out = "XFile.csv", loadGrid;
     double fs = 2.5e6, T = 0.02;
     int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
+    bool useGraph = false;
     float spacing = 1.0f, delta[4] = {0, 0, 0, 0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -56,6 +57,7 @@ int main(int argc, char **argv)
         else if (a == "--grid-type") { gridType = std::atoi(next()); ++i; }
         else if (a == "--spacing") { spacing = (float)std::atof(next()); ++i; }
         else if (a == "--lpower") { lpower = std::atoi(next()); ++i; }
+        else if (a == "--graph") { useGraph = true; }
         else if (a == "--init-delta") { next(4); for (int j = 0; j < 4; ++j) delta[j] = (float)std::atof(argv[i + 1 + j]); i += 4; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -114,6 +116,8 @@ int main(int argc, char **argv)
     }
     CHECK(flow.SetModParam("BatchCorrScores", "LagHalfWidth", L));
     CHECK(flow.SetModParam("BatchCorrScores", "BinHalfWidth", B));
+    CHECK(flow.SetModParam("BatchCorrScores", "UseGraph", useGraph));
+    CHECK(flow.SetModParam("BatchCorrManifold", "UseGraph", useGraph));
 
     // port table, dpeflow.cpp:140-213 (InitP / InitK belong to the disabled EKF and are dropped)
     static const char *wires[][4] = {

@@ -251,6 +251,7 @@ class BatchCorrScores : public Module {
         ConfigOutput(2, "NumFFTPoints", INT_t, VALUE, HOST, 1, nullptr, 0);
         InsertParam("LagHalfWidth", &lagHalf, INT_t, sizeof(int), sizeof(int));
         InsertParam("BinHalfWidth", &binHalf, INT_t, sizeof(int), sizeof(int));
+        InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
     }
     ~BatchCorrScores() override { Stop(); }
     int Start(void *) override
@@ -263,6 +264,7 @@ class BatchCorrScores : public Module {
         cfg.lagHalfWidth = lagHalf; cfg.binHalfWidth = binHalf;
         cfg.maxWindows = 1; cfg.maxChannels = DPE_MAX_CHAN;
         if (dpe_bcs_create(&cfg, &h)) return -1;
+        dpe_bcs_set_graph(h, useGraph ? 1 : 0);
         const float *code, *carr; int32_t nLag, nBin; int64_t nfft;
         dpe_bcs_outputs(h, &code, &carr, &nLag, &nBin, &nfft);
         carrSTot = (int)nfft;
@@ -291,7 +293,10 @@ class BatchCorrScores : public Module {
         }
         dpe_stream_t st = flow_stream(flowStream);
         if (dpe_bcs_update(h, (const int16_t *)inputs[0]->Data, S, 1, K, ch, st)) { Stop(); return -1; }
-        return dpe_stream_synchronize(st) ? -1 : 0;                        // outputs complete on return, :1192-1195
+        // The reference synchronises here (:1192-1195).  The banks are consumed by BatchCorrManifold on the
+        // same flow stream, so stream order already guarantees they are complete there; not waiting lets
+        // BatchCorrManifold's host-side geometry overlap the correlator kernels.
+        return 0;
     }
     int Stop() override
     {
@@ -306,6 +311,7 @@ class BatchCorrScores : public Module {
     dpe_bcs *h = nullptr;
     bool Started = false;
     int lagHalf = 8, binHalf = 48, carrSTot = 0, S = 0;
+    bool useGraph = false;  // replay the per-window launch sequence as one hipGraph (dpe_hip.h; measured slower)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -333,6 +339,7 @@ class BatchCorrManifold : public Module {
         InsertParam("GridLogFileName", gridLog, CHAR_t, sizeof(gridLog), 0);
         InsertParam("LoadPosGrid", &loadPosGrid, BOOL_t, sizeof(bool), sizeof(bool));
         InsertParam("LoadPosGridFilename", loadPosGridFilename, CHAR_t, sizeof(loadPosGridFilename), 0);
+        InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
         ConfigOutput(0, "zVal", DOUBLE_t, STATE, HOST, 8, zVal, 0);
         ConfigOutput(1, "RVal", DOUBLE_t, COVARIANCE, HOST, 64, RVal, 0);
         ConfigOutput(2, "TimeGrid", DOUBLE_t, VALUE, HOST, VECTORLENGTH_ANY, nullptr, 0);
@@ -362,6 +369,7 @@ class BatchCorrManifold : public Module {
         cfg.posGridSize = (int64_t)posGrid.size() / 4; cfg.velGridSize = (int64_t)velGrid.size() / 4;
         cfg.writeScores = 1;
         if (dpe_bcm_create(&cfg, &h)) return -1;
+        dpe_bcm_set_graph(h, useGraph ? 1 : 0);
         const float *ps, *vs;
         dpe_bcm_scores(h, &ps, &vs);
         UpdateOutput(2, (uint32_t)timeGrid.size(), timeGrid.data(), 0);
@@ -415,6 +423,7 @@ class BatchCorrManifold : public Module {
     dpe_bcm *h = nullptr;
     bool Started = false, loadPosGrid = false;
     int posDim = 25, velDim = 25, gridType = 0, LPower = 1;
+    bool useGraph = false;
     float spacing = 1.0f;
     char gridLog[512] = "", loadPosGridFilename[512] = "";
     std::vector<double> posGrid, velGrid, timeGrid;

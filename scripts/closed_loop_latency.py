@@ -3,7 +3,7 @@ manager, on a synthetic sample file.  Prints us per iteration for a 9^4 and the 
 import sys, os, subprocess, numpy as np, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import navlab_dpe_sdr_amd as dpe
-W, fs, S, K = 200, 2.5e6, 50000, 8
+W, fs, S, K = int(os.environ.get("DPE_LAT_WINDOWS", "200")), 2.5e6, 50000, 8
 iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=5, amp=200.0)
 d = tempfile.mkdtemp()
 dat = os.path.join(d, "s.dat"); iq.tofile(dat)
@@ -12,9 +12,9 @@ with open(dpe.workload.HANDOFF_CSV) as f, open(ho_path, "w") as g:
     for line in f:
         g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
 exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
-for dim in (9, 25):
-    r = subprocess.run([exe, "--samples", dat, "--handoff", ho_path, "--out", os.path.join(d, "X.csv"), "--iters", str(W), "--grid-dim", str(dim), "--spacing", "1.0"], capture_output=True, text=True)
-    print(dim, [l for l in r.stderr.splitlines() if "iterations" in l or "LoadFlow" in l])
+for dim, extra in ((9, []), (9, ["--graph"]), (25, []), (25, ["--graph"])):
+    r = subprocess.run([exe, "--samples", dat, "--handoff", ho_path, "--out", os.path.join(d, "X.csv"), "--iters", str(W), "--grid-dim", str(dim), "--spacing", "1.0"] + extra, capture_output=True, text=True)
+    print(dim, extra, [l for l in r.stderr.splitlines() if "iterations" in l or "LoadFlow" in l])
     rows = np.loadtxt(os.path.join(d, "X.csv"), delimiter=",")
     ho = dpe.handoff.read_handoff(ho_path)
     print("  max |fix - truth| m:", np.abs(rows[:, :3] - ho["X_ECEF"][:3]).max(), "rows", rows.shape)

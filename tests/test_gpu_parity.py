@@ -346,3 +346,50 @@ def test_batch_invariance_and_run_to_run_determinism():
     # arg-max consistency with the materialised scores (first maximum)
     for w in range(W):
         assert a[4][w]["posIndex"] == int(np.argmax(a[2][w])) and a[4][w]["velIndex"] == int(np.argmax(a[3][w]))
+
+
+def test_graph_replay_equals_eager_launches():
+    """dpe_*_set_graph: an Update replayed as one hipGraph (created stream, parameters changing every
+    window, two alternating sample buffers as with the SampleBlock ring) reproduces the eager path bit
+    for bit; on the null stream the flag silently keeps eager launches."""
+    import torch
+    cfg = dpe.workload.CONFIG_R
+    W = 6
+    iq, cs, ce, bw = dpe.workload.build_windows(W, cfg["fs"], cfg["S"], cfg["K"], seed=23, amp=cfg["amp"])
+    _, _, pos, vel, _ = dpe.workload.build_grids(6561)
+    L, B = cfg["L"], cfg["B"]
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+    ring = [torch.empty_like(iq_d[0]) for _ in range(2)]
+
+    def run(graph, stream):
+        bcs = dpe.BatchCorrScores(cfg["fs"], samples_per_window=cfg["S"], lag_half_width=L, bin_half_width=B,
+                                  max_windows=1, max_channels=cfg["K"])
+        bcs.Start()
+        bcm = dpe.BatchCorrManifold(cfg["fs"], cfg["S"], bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B,
+                                    max_windows=1, max_channels=cfg["K"])
+        bcm.Start()
+        bcs.set_graph(graph); bcm.set_graph(graph)
+        out = []
+        for w in range(W):
+            slot = ring[w % 2]
+            slot.copy_(iq_d[w]); torch.cuda.synchronize()
+            bcs.Update(slot, cs[w], stream=stream)
+            bcm.Update(bcs.CodeScores, bcs.CarrScores, bw[w:w + 1], ce[w], stream=stream)
+            r = bcm.results(stream=stream)[0]
+            code, carr = bcs.read_banks(stream=stream)
+            ps, vs = bcm.read_scores(stream=stream)
+            out.append((code.copy(), carr.copy(), ps.copy(), vs.copy(), r))
+        bcm.Stop(); bcs.Stop()
+        return out
+
+    st = dpe.engine.Stream()
+    eager = run(False, st)
+    for variant in (run(True, st), run(True, None)):
+        for a, b in zip(eager, variant):
+            for x, y in zip(a[:4], b[:4]):
+                assert np.array_equal(x, y)
+            assert a[4]["posIndex"] == b[4]["posIndex"] and a[4]["velIndex"] == b[4]["velIndex"]
+            assert np.array_equal(a[4]["zVal"], b[4]["zVal"])
+    st.close()
+    # the windows differ, so identical results would mean a stale replay
+    assert not np.array_equal(eager[0][0], eager[1][0])
