@@ -129,12 +129,19 @@ def main():
                                 max_channels=K, write_scores=write_scores, pos_index_offset=off, vel_index_offset=off)
     bcm.Start()
     stream = torch.cuda.current_stream()
-    keys_t = None
+    key_views = {}
+
+    def keys_tensor():
+        """torch view of the handle's packed keys of the LAST Update (two device sets alternate); int64:
+        scores are >= 0 so the sign bit is clear"""
+        ptr = bcm.Keys
+        if ptr not in key_views:
+            class _Cai:
+                __cuda_array_interface__ = {"shape": (W, 2), "typestr": "<i8", "data": (ptr, False), "version": 2}
+            key_views[ptr] = torch.as_tensor(_Cai(), device=dev)
+        return key_views[ptr]
+
     if use_dist:
-        # torch view of the handle's packed keys (int64: scores are >= 0 so the sign bit is clear)
-        class _Cai:
-            __cuda_array_interface__ = {"shape": (W, 2), "typestr": "<i8", "data": (bcm.Keys, False), "version": 2}
-        keys_t = torch.as_tensor(_Cai(), device=dev)
         if args.exchange == "scores":
             glob_p = torch.zeros((W, G * world), dtype=torch.float32, device=dev)
             glob_v = torch.zeros((W, G * world), dtype=torch.float32, device=dev)
@@ -150,7 +157,7 @@ def main():
         bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce, stream=stream)
         if use_dist:
             if args.exchange == "keys":
-                dpe.sharding.allreduce_argmax(keys_t, dist)
+                dpe.sharding.allreduce_argmax(keys_tensor(), dist)
             else:
                 glob_p.zero_(); glob_v.zero_()
                 glob_p[:, off:off + G].copy_(loc_p); glob_v[:, off:off + G].copy_(loc_v)
@@ -182,7 +189,7 @@ def main():
     # result sanity on rank 0: the synthetic windows put the truth at the grid centre -> the ML point must be
     # the grid point with the smallest geometric offset pattern; just check the fix is finite and in-grid.
     if use_dist:
-        res = bcm.results_from_keys(keys_t.cpu().numpy().view(np.uint64), pos_g, vel_g)
+        res = bcm.results_from_keys(keys_tensor().cpu().numpy().view(np.uint64), pos_g, vel_g)
         if world == 1:   # self-test: the exchanged keys decode to what the handle itself reports
             ref = bcm.results()
             assert all(a["posIndex"] == b["posIndex"] and a["velIndex"] == b["velIndex"] and

@@ -176,7 +176,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
 int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream);
 /* PosScores port (:2300,2404) and its velocity twin: float [maxWindows][gridSize]. */
 int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velScores_dev);
-/* Packed arg-max keys of the last update, device uint64 [maxWindows][2] (pos,vel):
+/* Packed arg-max keys of the LAST update (two sets alternate: query after every Update), device uint64 [maxWindows][2] (pos,vel):
  * (score bits << 32) | (0xFFFFFFFF - globalIndex): an integer max over shards reproduces
  * the "first maximum" tie-break of thrust::max_element (:2589-2590).  For RCCL all-reduce. */
 int dpe_bcm_keys(dpe_bcm *h, const uint64_t **keys_dev);

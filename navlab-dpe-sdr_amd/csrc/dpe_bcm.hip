@@ -28,6 +28,12 @@ struct BcmSvDev {
     float pad0, pad1;
 };
 
+// Single-window calls pass both manifolds' coefficients in the kernel-argument segment of the scan
+// kernels (params_ptr, dpe_common.h); pb must stay their FIRST argument.
+struct BcmParamBlock {
+    BcmSvDev s[2][DPE_MAX_CHAN];
+};
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 #ifndef DPE_PTS_PER_THREAD
@@ -40,7 +46,8 @@ constexpr int kPtsPerThread = DPE_PTS_PER_THREAD;
 constexpr int kPtsPerBlock = 256 * kPtsPerThread;
 
 template <int LP, bool SECOND, bool CLAMP, bool WMEAN>
-__global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict__ grid, long long G, int K, int nEnt,
+__global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl, unsigned long long *__restrict__ clearPtr,
+                                                       int clearN, const float4 *__restrict__ grid, long long G, int K, int nEnt,
                                                        int maxK, int lpower, const BcmSvDev *__restrict__ sv,
                                                        const float2 *__restrict__ bank, float *__restrict__ scores,
                                                        unsigned long long *__restrict__ keys,
@@ -57,7 +64,12 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
     __shared__ unsigned int sOob[4];
     __shared__ double sW[4][5];
 
+    (void)pb;
     const int w = blockIdx.y, tid = threadIdx.x;
+    // the key / counter set of the NEXT Update is cleared here (the sets alternate), so that no separate
+    // clearing launch or memset sits on the critical path
+    if (clearPtr && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = tid; i < clearN; i += 256) clearPtr[i] = 0ull;
     // first tile's grid points: issued before the bank fill so both latencies overlap
     float4 nxt[kPtsPerThread];
     {
@@ -92,7 +104,8 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
     // held as PAIRS so that the geometry runs on packed fp32 (v_pk_fma_f32: two points per instruction).
     constexpr int kPairs = kPtsPerThread / 2;
     const unsigned last = (unsigned)(nEnt - 1);
-    const BcmSvDev *svw = sv + (size_t)w * maxK;   // wave-uniform address -> scalar loads
+    // wave-uniform address -> scalar loads; inl = 1 / 2: this manifold's coefficients come from pb.s[inl - 1]
+    const BcmSvDev *svw = params_ptr(sv + (size_t)w * maxK, inl) + (inl == 2 ? DPE_MAX_CHAN : 0);
     const long long nTiles = (G + kPtsPerBlock - 1) / kPtsPerBlock;
     unsigned long long best = 0ull;
     unsigned int nOob = 0;
@@ -239,37 +252,6 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(const float4 *__restrict_
     }
 }
 
-// Clears the arg-max keys and the out-of-window counters (contiguous).  A kernel rather than memset
-// nodes: see GraphCache in dpe_common.h.
-__global__ void bcm_clear_kernel(unsigned long long *p, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0ull;
-}
-
-// Single-window variant: the per-SV coefficients of both manifolds ride in the kernel-argument segment
-// (first argument, read through the kernarg pointer) and are stored to sv[] for the scans that follow.
-struct BcmParamBlock {
-    BcmSvDev s[2][DPE_MAX_CHAN];
-};
-typedef const int __attribute__((address_space(4))) *kernarg_words_t;
-
-__global__ __launch_bounds__(256) void bcm_clear_params_kernel(BcmParamBlock pb, unsigned long long *p, int n,
-                                                               int *__restrict__ sv, int nChan, int velOffsetWords)
-{
-    (void)pb;
-    if (blockIdx.x == 0) {
-        kernarg_words_t src = (kernarg_words_t)__builtin_amdgcn_kernarg_segment_ptr();
-        constexpr int kWordsPerSv = (int)(sizeof(BcmSvDev) / 4), kVelSrc = DPE_MAX_CHAN * kWordsPerSv;
-        for (int i = threadIdx.x; i < nChan * kWordsPerSv; i += 256) {
-            sv[i] = src[i];
-            sv[velOffsetWords + i] = src[kVelSrc + i];
-        }
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0ull;
-}
-
 }  // namespace dpe
 
 // ============================================================================================
@@ -279,7 +261,8 @@ struct dpe_bcm {
     float4 *posGrid_d = nullptr, *velGrid_d = nullptr;
     float *posScores_d = nullptr, *velScores_d = nullptr;
     dpe::BcmSvDev *sv_d = nullptr, *sv_h = nullptr;  // [2][W][maxK]  (manifold-major)
-    unsigned long long *keys_d = nullptr, *oob_d = nullptr;  // [W][2]
+    unsigned long long *keys_d = nullptr;  // [2 sets][{keys [W][2], counts [W][2]}], alternating between Updates
+    int cur = 1;                           // set of the latest Update
     double *wsum_d = nullptr;   // [W][2][split][5] per-block weighted sums
     unsigned long long *keys_h = nullptr, *oob_h = nullptr;   // pinned mirrors, filled by async copies at the end of Update
     unsigned lastSplit[2] = {0, 0};
@@ -318,28 +301,28 @@ static unsigned scan_split(long long G, int nWindows)
 }
 
 template <bool SECOND, bool CLAMP, bool WMEAN>
-static void launch_scan3(int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
+static void launch_scan3(const dpe::BcmParamBlock &pb, int inl, unsigned long long *clr, int clrN, int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
                          int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores, unsigned long long *keys,
                          unsigned long long *oob, long long off, int slot, double *wsum)
 {
     using namespace dpe;
     if (lp == 1)
-        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
+        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, pb, inl, clr, clrN, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
     else if (lp == 2)
-        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
+        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, pb, inl, clr, clrN, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
     else
-        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
+        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, pb, inl, clr, clrN, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
 }
 
 // clamp = false only when the host has proved that every index of every (point, SV) pair stays inside
 // the bank (then the kernel drops the range clamp and the out-of-window bookkeeping); wsum != nullptr
 // selects the variant that also accumulates the weighted-mean sums
 template <bool SECOND>
-static void launch_scan(bool clamp, int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K,
+static void launch_scan(const dpe::BcmParamBlock &pb, int inl, unsigned long long *clr, int clrN, bool clamp, int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K,
                         int nEnt, int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores,
                         unsigned long long *keys, unsigned long long *oob, long long off, int slot, double *wsum)
 {
-#define DPE_SCAN_ARGS lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot, wsum
+#define DPE_SCAN_ARGS pb, inl, clr, clrN, lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot, wsum
     if (clamp) { if (wsum) launch_scan3<SECOND, true, true>(DPE_SCAN_ARGS); else launch_scan3<SECOND, true, false>(DPE_SCAN_ARGS); }
     else { if (wsum) launch_scan3<SECOND, false, true>(DPE_SCAN_ARGS); else launch_scan3<SECOND, false, false>(DPE_SCAN_ARGS); }
 #undef DPE_SCAN_ARGS
@@ -403,11 +386,10 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
         h->velScores_d = dev_alloc<float>(W * (size_t)cfg->velGridSize);
     }
     h->sv_d = dev_alloc<BcmSvDev>(2 * W * K);
-    h->keys_d = dev_alloc<unsigned long long>(4 * W);   // keys [W][2] then out-of-window counts [W][2]
-    h->oob_d = h->keys_d ? h->keys_d + 2 * W : nullptr;
+    h->keys_d = dev_alloc<unsigned long long>(8 * W);   // two alternating sets of {keys [W][2], out-of-window counts [W][2]}
     h->wsumHalf = (size_t)(dpe_bcm::kMaxSplit + 8 * W) * 5;   // >= nWindows * blocks-per-window of any launch
     h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
-    if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->oob_d || !h->wsum_d ||
+    if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->wsum_d ||
         hipHostMalloc((void **)&h->sv_h, 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->keys_h, 4 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
@@ -420,6 +402,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
     h->oob_h = h->keys_h + 2 * W;
+    DPE_CHECK_HIP(hipMemset(h->keys_d, 0, 8 * W * sizeof(unsigned long long)));
     h->win_h.resize(W);
     *out = h;
     return 0;
@@ -502,24 +485,27 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     h->lastW = nWindows;
     h->lastSplit[0] = scan_split(h->cfg.posGridSize, nWindows);
     h->lastSplit[1] = scan_split(h->cfg.velGridSize, nWindows);
+    // Two key / counter sets alternate between Updates: this call reduces into set `cur` (zero since it
+    // was cleared by the previous call's position scan, or by create) and clears the other one.
+    h->cur ^= 1;
+    unsigned long long *keys = h->keys_d + (size_t)h->cur * 4 * W, *oob = keys + 2 * W;
+    unsigned long long *other = h->keys_d + (size_t)(h->cur ^ 1) * 4 * W;
     GraphCache::Guard graphGuard{h->graphs, stream};
     if (h->graphs.enabled && !h->prof.enabled) {
         const int rc = h->graphs.begin({codeBank_dev, carrBank_dev, 0, nWindows, nChan,
-                                        (posInside ? 1 : 0) | (velInside ? 2 : 0), stream}, stream);
+                                        (posInside ? 1 : 0) | (velInside ? 2 : 0) | (h->cur << 2), stream}, stream);
         DPE_REQUIRE(rc >= 0, "[BatchCorrManifold] Update: hipGraph capture/replay failed");
         if (rc == 1) return 0;
     }
-    if (nWindows == 1 && !h->graphs.capturing) {
-        // closed loop: coefficients as kernel arguments (a captured graph would freeze them, so that path copies)
-        BcmParamBlock pb;
+    // one window: coefficients as kernel arguments of the scans (a captured graph would freeze them, so
+    // that path copies); batches: one copy covers both manifolds' coefficient blocks
+    const bool inlineParams = nWindows == 1 && !h->graphs.capturing;
+    BcmParamBlock pb{};
+    if (inlineParams) {
         memcpy(pb.s[0], h->sv_h, sizeof(BcmSvDev) * nChan);
         memcpy(pb.s[1], h->sv_h + (size_t)W * maxK, sizeof(BcmSvDev) * nChan);
-        hipLaunchKernelGGL(bcm_clear_params_kernel, dim3((4 * W + 255) / 256), dim3(256), 0, stream, pb, h->keys_d, 4 * W,
-                           reinterpret_cast<int *>(h->sv_d), nChan, (int)((size_t)W * maxK * sizeof(BcmSvDev) / 4));
     } else {
-        // one copy covers both manifolds' coefficient blocks, one launch clears keys and counters
         DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(bcm_clear_kernel, dim3((4 * W + 255) / 256), dim3(256), 0, stream, h->keys_d, 4 * W);
     }
     const int nLag = 2 * L + 1, nBin = 2 * B + 1;
     {
@@ -528,8 +514,8 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         h->lastSplit[0] = grid.x;
         const size_t lds = (size_t)nChan * nLag * 12;
         h->prof.begin(0, stream);
-        launch_scan<true>(!posInside, h->cfg.lPower, grid, lds, stream, h->posGrid_d, G, nChan, nLag, maxK, h->sv_d,
-                          reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, h->keys_d, h->oob_d,
+        launch_scan<true>(pb, inlineParams ? 1 : 0, other, 4 * W, !posInside, h->cfg.lPower, grid, lds, stream, h->posGrid_d, G,
+                          nChan, nLag, maxK, h->sv_d, reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, keys, oob,
                           h->cfg.posGridIndexOffset, 0, h->cfg.weightedMean ? h->wsum_d : nullptr);
         h->prof.end(0, stream);
     }
@@ -539,15 +525,15 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         h->lastSplit[1] = grid.x;
         const size_t lds = (size_t)nChan * nBin * 12;
         h->prof.begin(1, stream);
-        launch_scan<false>(!velInside, h->cfg.lPower, grid, lds, stream, h->velGrid_d, G, nChan, nBin, maxK,
-                           h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev), h->velScores_d,
-                           h->keys_d, h->oob_d, h->cfg.velGridIndexOffset, 1,
+        launch_scan<false>(pb, inlineParams ? 2 : 0, nullptr, 0, !velInside, h->cfg.lPower, grid, lds, stream, h->velGrid_d, G,
+                           nChan, nBin, maxK, h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev),
+                           h->velScores_d, keys, oob, h->cfg.velGridIndexOffset, 1,
                            h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr);
         h->prof.end(1, stream);
     }
     // results travel to pinned host memory on the same stream: dpe_bcm_results only has to synchronise
     // (keys and counters are contiguous on both sides: one copy up to the last counter in use)
-    DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, h->keys_d, sizeof(unsigned long long) * (2 * (size_t)W + 2 * nWindows),
+    DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, keys, sizeof(unsigned long long) * (2 * (size_t)W + 2 * nWindows),
                                  hipMemcpyDeviceToHost, stream));
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrManifold] Update: hipGraph instantiate/launch failed");
     DPE_CHECK_HIP(hipGetLastError());
@@ -648,7 +634,7 @@ int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velSco
 int dpe_bcm_keys(dpe_bcm *h, const uint64_t **keys_dev)
 {
     DPE_REQUIRE(h && keys_dev, "[BatchCorrManifold] keys: null argument");
-    *keys_dev = reinterpret_cast<const uint64_t *>(h->keys_d);
+    *keys_dev = reinterpret_cast<const uint64_t *>(h->keys_d + (size_t)h->cur * 4 * h->cfg.maxWindows);
     return 0;
 }
 

@@ -106,26 +106,12 @@ __global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict_
     sum_body(iq, winStride, S, sums);
 }
 
-// Closed-loop variant (few channels in flight): the channel parameters ride in the kernel-argument
-// segment and block (0,0) stores them to chan[] for the kernels that follow on the stream -- no H2D copy
-// command, no staging buffer to keep alive.  pb must stay the FIRST argument: it is read through the
-// kernarg segment pointer, so that dynamic indexing never copies the block to private memory.
+// Closed-loop calls (one window, <= 37 channels) pass the channel parameters in the kernel-argument
+// segment of the bank and finalize kernels (params_ptr, dpe_common.h): no H2D copy command, no staging
+// buffer that must outlive the call.  pb must stay the FIRST argument of those kernels.
 struct BcsParamBlock {
     BcsChanDev c[DPE_MAX_CHAN];
 };
-typedef const int __attribute__((address_space(4))) *kernarg_words_t;
-
-__global__ __launch_bounds__(256) void bcs_sum_params_kernel(BcsParamBlock pb, const int16_t *__restrict__ iq,
-                                                             long long winStride, int S, long long *__restrict__ sums,
-                                                             int nWords, int *__restrict__ chanOut)
-{
-    (void)pb;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        kernarg_words_t src = (kernarg_words_t)__builtin_amdgcn_kernarg_segment_ptr();
-        for (int i = threadIdx.x; i < nWords; i += 256) chanOut[i] = src[i];
-    }
-    sum_body(iq, winStride, S, sums);
-}
 
 // DC mean = sum / (float)S in fp64 (batchcorrscores.cu:1065-1066,1210-1216), then fp32
 __device__ __forceinline__ void window_mean(const long long *__restrict__ sums, int w, int nSumBlk, int S, float &mRe, float &mIm)
@@ -139,7 +125,7 @@ __device__ __forceinline__ void window_mean(const long long *__restrict__ sums, 
 
 // ------------------------------------------------------------------------------------------
 template <int LH, int kNMom, bool TABLE>
-__global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
+__global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride, int S,
                                                        int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                        const BcsChanDev *__restrict__ chan,
                                                        const long long *__restrict__ sums,
@@ -156,7 +142,8 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
 
     const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const BcsChanDev ch = chan[w * K + k];
+    (void)pb;
+    const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
     for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
     const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;   // chip span of one sub-tile fits the extended table
     float mRe, mIm;
@@ -320,7 +307,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(const int16_t *__restrict
 // one FMA per LANE with lanes <-> the 64 lag steps.  The finalize kernel prefix-sums the steps.
 // part layout per (block, side): [0] = corr[-32], [1 + i] = D[-32 + i], i = 0..63  (65 entries, as NL).
 template <int kNMom, bool TABLE>
-__global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
+__global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride, int S,
                                                             int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                             const BcsChanDev *__restrict__ chan,
                                                             const long long *__restrict__ sums,
@@ -338,7 +325,8 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__res
 
     const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const BcsChanDev ch = chan[w * K + k];
+    (void)pb;
+    const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
     for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
     const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;
     float mRe, mIm;
@@ -506,7 +494,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(const int16_t *__res
 // ------------------------------------------------------------------------------------------
 // blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
 template <int kNMom>
-__global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide,
+__global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide,
                                                            long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
                                                            const float2 *__restrict__ mom,
@@ -515,7 +503,8 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(int S, int K, int nSu
 {
     const int k = blockIdx.y, w = blockIdx.z, tid = threadIdx.x;
     const int NL = 2 * LH + 1;
-    const BcsChanDev ch = chan[w * K + k];
+    (void)pb;
+    const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
     const float2 *pp = part + ((size_t)w * K + k) * nBlk * 2 * NL;
     __shared__ float2 sXY[2 * 65];      // [side][lag] totals of the per-block partials (NL <= 65)
     __shared__ float2 sTmp[256];
@@ -795,25 +784,17 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         DPE_REQUIRE(rc >= 0, "[BatchCorrScores] Update: hipGraph capture/replay failed");
         if (rc == 1) return 0;
     }
-    // few channels (the per-window call of a running receiver): parameters travel as kernel arguments;
-    // batches go through one H2D copy from the pinned staging block.  A captured graph would freeze
-    // by-value arguments, so the graph path always copies.
-    const bool inlineParams = !h->graphs.capturing && nWindows * nChan <= DPE_MAX_CHAN;
-    if (inlineParams) {
-        BcsParamBlock pb;
-        memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
-        h->prof.begin(0, stream);
-        hipLaunchKernelGGL(bcs_sum_params_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, pb, samples_dev,
-                           (long long)windowStrideSamples, S, h->sums_d, (int)(sizeof(BcsChanDev) / 4) * nWindows * nChan,
-                           reinterpret_cast<int *>(h->chan_d));
-        h->prof.end(0, stream);
-    } else {
-        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
-        h->prof.begin(0, stream);
-        hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
-                           (long long)windowStrideSamples, S, h->sums_d);
-        h->prof.end(0, stream);
-    }
+    // few channels (the per-window call of a running receiver): parameters travel as kernel arguments of
+    // the bank / finalize kernels; batches go through one H2D copy from the pinned staging block.  A
+    // captured graph would freeze by-value arguments, so the graph path always copies.
+    const int inl = (!h->graphs.capturing && nWindows * nChan <= DPE_MAX_CHAN) ? 1 : 0;
+    BcsParamBlock pb{};
+    if (inl) memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
+    else DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+    h->prof.begin(0, stream);
+    hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
+                       (long long)windowStrideSamples, S, h->sums_d);
+    h->prof.end(0, stream);
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     // tiles per block: amortise the end-of-block lag reduction while keeping >= ~4096 blocks in flight
     const int nTiles = (h->nSub + 3) / 4;
@@ -823,7 +804,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int nBlk = (nTiles + tpb - 1) / tpb;
     const dim3 grid(nBlk, nChan, nWindows), block(256);
 #define DPE_LAUNCH_BANK3(LHV, NM, TB)                                                                                   \
-    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
+    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, \
                        h->tTable_d, h->part_d, h->mom_d)
 #define DPE_LAUNCH_BANK2(LHV, NM)                           \
@@ -842,7 +823,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const bool wide = h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
     if (wide) {
 #define DPE_LAUNCH_WIDE(NM, TB)                                                                                    \
-    hipLaunchKernelGGL((bcs_bank_wide_kernel<NM, TB>), grid, block, 0, stream, samples_dev, (long long)windowStrideSamples, \
+    hipLaunchKernelGGL((bcs_bank_wide_kernel<NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
         if (h->nMom == 4) { if (h->useTable) DPE_LAUNCH_WIDE(4, true); else DPE_LAUNCH_WIDE(4, false); }
         else { if (h->useTable) DPE_LAUNCH_WIDE(6, true); else DPE_LAUNCH_WIDE(6, false); }
@@ -861,11 +842,11 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
     if (h->nMom == 4)
-        hipLaunchKernelGGL(bcs_finalize_kernel<4>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
+        hipLaunchKernelGGL(bcs_finalize_kernel<4>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
                            nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     else
-        hipLaunchKernelGGL(bcs_finalize_kernel<6>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, S, nChan, h->nSub,
+        hipLaunchKernelGGL(bcs_finalize_kernel<6>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
                            nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);

@@ -187,6 +187,21 @@ struct GraphCache {
     };
 };
 
+#ifdef __HIPCC__
+// Small per-call parameter blocks (channel / SV coefficients of ONE window) travel in the kernel-argument
+// segment instead of through an H2D copy: the block is the kernel's FIRST argument and is read through
+// the kernarg segment pointer.  Both candidates are cast to the constant address space so that the
+// wave-uniform reads stay scalar loads (s_load) whichever source is selected.
+template <typename T>
+__device__ __forceinline__ const T *params_ptr(const T *global_ptr, int useKernarg)
+{
+    typedef const T __attribute__((address_space(4))) *c_t;
+    c_t k = (c_t)__builtin_amdgcn_kernarg_segment_ptr();
+    c_t g = (c_t)(unsigned long long)global_ptr;
+    return (const T *)(useKernarg ? k : g);
+}
+#endif
+
 template <typename T>
 static inline T *dev_alloc(size_t n)
 {

@@ -328,6 +328,9 @@ class BatchCorrManifold:
                                     win.ctypes.data_as(C.POINTER(BcmWindow)),
                                     chan.ctypes.data_as(C.POINTER(ChanEnd)), _stream(stream)))
         self._W = W
+        keys = C.c_void_p()   # the key sets alternate between Updates: refresh the device pointer
+        _check(lib().dpe_bcm_keys(self._h, C.byref(keys)))
+        self.Keys = keys.value
         return 0
 
     def results(self, stream=None):

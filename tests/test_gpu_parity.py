@@ -393,3 +393,37 @@ def test_graph_replay_equals_eager_launches():
     st.close()
     # the windows differ, so identical results would mean a stale replay
     assert not np.array_equal(eager[0][0], eager[1][0])
+
+
+def test_key_sets_stay_clean_across_changing_batch_sizes():
+    """The arg-max keys / out-of-window counters live in two alternating device sets, each cleared by the
+    following Update's position scan.  Repeated Updates with batch sizes 3, 1, 3, 2, 3 on ONE handle must
+    give, for every window, exactly what a fresh handle gives (no stale maximum from an earlier call)."""
+    import torch
+    case = helpers.make_case(seed=31, S=12500, K=5, G=4097, amp=200.0, W=3)
+    iq, cs, ce, bw = helpers.pack_gpu_inputs(case)
+    L, B = 8, 32
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+
+    def handles():
+        bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=L, bin_half_width=B, max_windows=3, max_channels=5)
+        bcs.Start()
+        bcm = dpe.BatchCorrManifold(case["fs"], case["S"], bcs.NumFFTPoints, case["pos"], case["vel"], lag_half_width=L,
+                                    bin_half_width=B, max_windows=3, max_channels=5)
+        bcm.Start()
+        return bcs, bcm
+
+    def update(bcs, bcm, n):
+        bcs.Update(iq_d[:n], cs[:n])
+        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw[:n], ce[:n])
+        return [(r["posIndex"], r["velIndex"], r["posScore"], r["velScore"], r["posOutOfWindow"], r["velOutOfWindow"])
+                for r in bcm.results()]
+
+    bcs, bcm = handles()
+    seq = [update(bcs, bcm, n) for n in (3, 1, 3, 2, 3)]
+    bcm.Stop(); bcs.Stop()
+    for n, got in zip((3, 1, 3, 2, 3), seq):
+        b2, m2 = handles()
+        assert got == update(b2, m2, n)
+        m2.Stop(); b2.Stop()
+    assert seq[0] == seq[2] == seq[4] and seq[1] == seq[0][:1] and seq[3] == seq[0][:2]
