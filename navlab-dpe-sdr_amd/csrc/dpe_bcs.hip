@@ -113,12 +113,22 @@ struct BcsParamBlock {
     BcsChanDev c[DPE_MAX_CHAN];
 };
 
-// DC mean = sum / (float)S in fp64 (batchcorrscores.cu:1065-1066,1210-1216), then fp32
+// DC mean = sum / (float)S in fp64 (batchcorrscores.cu:1065-1066,1210-1216), then fp32.  The <= 64 slots
+// are fetched by one vector load (lane <-> slot) and added across the wave: a single memory latency,
+// and integer sums are order-independent.
 __device__ __forceinline__ void window_mean(const long long *__restrict__ sums, int w, int nSumBlk, int S, float &mRe, float &mIm)
 {
+    const int lane = threadIdx.x & 63;
     long long tI = 0, tQ = 0;
-    const long long *p = sums + (size_t)w * kSumSlots * 2;
-    for (int b = 0; b < nSumBlk; ++b) { tI += p[2 * b]; tQ += p[2 * b + 1]; }
+    if (lane < nSumBlk) {
+        const longlong2 v = *reinterpret_cast<const longlong2 *>(sums + ((size_t)w * kSumSlots + lane) * 2);
+        tI = v.x; tQ = v.y;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tI += __shfl_xor(tI, off, 64);
+        tQ += __shfl_xor(tQ, off, 64);
+    }
     mRe = (float)((double)tI / (double)(float)S);
     mIm = (float)((double)tQ / (double)(float)S);
 }
@@ -506,9 +516,29 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     (void)pb;
     const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
     const float2 *pp = part + ((size_t)w * K + k) * nBlk * 2 * NL;
+    constexpr int kChunk = 256;         // sub-tiles staged in LDS at a time
     __shared__ float2 sXY[2 * 65];      // [side][lag] totals of the per-block partials (NL <= 65)
     __shared__ float2 sTmp[256];
     __shared__ float2 sRed[16][16];
+    __shared__ float2 sMom[kChunk * kNMom];   // flip-combined moments of the current chunk
+    // A single window keeps only a few of these blocks in flight, so the kernel is a chain of memory
+    // latencies: every stage issues ALL of its loads before consuming any.  Doppler blocks fetch their
+    // first chunk of moments up front, under the partial-sum stage.
+    const bool carrBlk = blockIdx.x != 0;
+    const float2 *m0 = mom + (((size_t)w * K + k) * 2) * nSub * kNMom;
+    const float2 *m1 = m0 + (size_t)nSub * kNMom;
+    float2 r0[kNMom], r1[kNMom];
+    auto load_chunk = [&](int c0) {
+        const int n = (nSub - c0 < kChunk ? nSub - c0 : kChunk) * kNMom;
+#pragma unroll
+        for (int i = 0; i < kNMom; ++i) {
+            const int idx = tid + 256 * i;
+            const bool ok = idx < n;
+            r0[i] = ok ? m0[(size_t)c0 * kNMom + idx] : make_float2(0.f, 0.f);
+            r1[i] = ok ? m1[(size_t)c0 * kNMom + idx] : make_float2(0.f, 0.f);
+        }
+    };
+    if (carrBlk) load_chunk(0);
     {
         // fixed-order two-level sum (bit-reproducible, identical in every block): T threads per
         // (side, lag) pair each add a strided subset of the blocks, then one thread adds the T partials
@@ -520,9 +550,15 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
         float2 acc = make_float2(0.f, 0.f);
         if (pair < pairs) {
             const int side = pair / NL, lag = pair - side * NL;
-            for (int bq = sub; bq < nBlk; bq += T) {
-                const float2 v = pp[(size_t)(bq * 2 + side) * NL + lag];
-                acc.x += v.x; acc.y += v.y;
+            for (int b0 = sub; b0 < nBlk; b0 += 8 * T) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int bq = b0 + u * T;
+                    v[u] = bq < nBlk ? pp[(size_t)(bq * 2 + side) * NL + lag] : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; }
             }
         }
         sTmp[tid] = acc;
@@ -550,7 +586,7 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     const int noFlip = (!ch.hasFlip) || (nr0 * nr0 + ni0 * ni0 > fr0 * fr0 + fi0 * fi0);
     const float sgn = noFlip ? 1.f : -1.f;
 
-    if (blockIdx.x == 0) {
+    if (!carrBlk) {
         if (tid == 0) info[w * K + k] = noFlip;
         for (int j = tid; j < 2 * L + 1; j += 256) {
             const int jj = j + (LH - L);
@@ -564,51 +600,61 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     const int bi = (blockIdx.x - 1) * 16 + (tid & 15);  // bank entry
     const int grp = tid >> 4;
     const int b = bi - B;
+    const bool live = bi < 2 * B + 1;
     float2 F = make_float2(0.f, 0.f);
-    if (bi < 2 * B + 1) {
-        const float theta = (float)(6.283185307179586476925286766559 * (double)b / (double)C);
-        const float2 *m0 = mom + (((size_t)w * K + k) * 2) * nSub * kNMom;
-        const float2 *m1 = m0 + (size_t)nSub * kNMom;
-        const float invC = 1.0f / (float)C;  // C is a power of two: exact
-        // centre twiddle exp(-j 2 pi n_c b / C), n_c = 256 sub + 127.5: exact (integer-reduced phase +
-        // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 4096 b / C) between
-        float stepS, stepC;
-        {
-            long long ts = ((long long)8192 * (long long)b) % (2 * C);   // 2 * (16 * 256) b  (phase unit: pi / C)
-            if (ts < 0) ts += 2 * C;
-            sincospif((float)ts * invC, &stepS, &stepC);
+    const float theta = (float)(6.283185307179586476925286766559 * (double)b / (double)C);
+    const float invC = 1.0f / (float)C;  // C is a power of two: exact
+    // centre twiddle exp(-j 2 pi n_c b / C), n_c = 256 sub + 127.5: exact (integer-reduced phase +
+    // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 4096 b / C) between
+    float stepS = 0.f, stepC = 1.f;
+    if (live) {
+        long long ts = ((long long)8192 * (long long)b) % (2 * C);   // 2 * (16 * 256) b  (phase unit: pi / C)
+        if (ts < 0) ts += 2 * C;
+        sincospif((float)ts * invC, &stepS, &stepC);
+    }
+    float sn = 0.f, cs = 1.f;
+    int it = 0;
+    for (int c0 = 0; c0 < nSub; c0 += kChunk) {
+        if (c0) {
+            __syncthreads();   // the previous chunk is fully consumed
+            load_chunk(c0);
         }
-        float sn = 0.f, cs = 1.f;
-        int it = 0;
-        for (int sub = grp; sub < nSub; sub += 16, ++it) {
-            const float2 *a0 = m0 + (size_t)sub * kNMom, *a1 = m1 + (size_t)sub * kNMom;
-            float ar = a0[kNMom - 1].x + sgn * a1[kNMom - 1].x;
-            float ai = a0[kNMom - 1].y + sgn * a1[kNMom - 1].y;
 #pragma unroll
-            for (int p = kNMom - 1; p >= 1; --p) {
-                const float sc = theta / (float)p;
-                const float mr = a0[p - 1].x + sgn * a1[p - 1].x, mi = a0[p - 1].y + sgn * a1[p - 1].y;
-                const float nr = fmaf(sc, ai, mr);
-                ai = fmaf(-sc, ar, mi);
-                ar = nr;
+        for (int i = 0; i < kNMom; ++i)
+            sMom[tid + 256 * i] = make_float2(r0[i].x + sgn * r1[i].x, r0[i].y + sgn * r1[i].y);
+        __syncthreads();
+        if (live) {
+            const int cEnd = nSub - c0 < kChunk ? nSub - c0 : kChunk;
+            for (int sl = grp; sl < cEnd; sl += 16, ++it) {   // kChunk is a multiple of 16: the stride continues across chunks
+                const int sub = c0 + sl;
+                const float2 *a = sMom + sl * kNMom;
+                float ar = a[kNMom - 1].x, ai = a[kNMom - 1].y;
+#pragma unroll
+                for (int p = kNMom - 1; p >= 1; --p) {
+                    const float sc = theta / (float)p;
+                    const float mr = a[p - 1].x, mi = a[p - 1].y;
+                    const float nr = fmaf(sc, ai, mr);
+                    ai = fmaf(-sc, ar, mi);
+                    ar = nr;
+                }
+                if ((it & 7) == 0) {
+                    long long tt = ((long long)(512 * sub + 255) * (long long)b) % (2 * C);
+                    if (tt < 0) tt += 2 * C;
+                    sincospif((float)tt * invC, &sn, &cs);  // angle = pi * tt / C
+                } else {
+                    const float nc = cs * stepC - sn * stepS;
+                    sn = sn * stepC + cs * stepS;
+                    cs = nc;
+                }
+                // (cs - j sn) * (ar + j ai)
+                F.x += cs * ar + sn * ai;
+                F.y += cs * ai - sn * ar;
             }
-            if ((it & 7) == 0) {
-                long long tt = ((long long)(512 * sub + 255) * (long long)b) % (2 * C);
-                if (tt < 0) tt += 2 * C;
-                sincospif((float)tt * invC, &sn, &cs);  // angle = pi * tt / C
-            } else {
-                const float nc = cs * stepC - sn * stepS;
-                sn = sn * stepC + cs * stepS;
-                cs = nc;
-            }
-            // (cs - j sn) * (ar + j ai)
-            F.x += cs * ar + sn * ai;
-            F.y += cs * ai - sn * ar;
         }
     }
     sRed[grp][tid & 15] = F;
     __syncthreads();
-    if (grp == 0 && bi < 2 * B + 1) {
+    if (grp == 0 && live) {
         float2 t = sRed[0][tid];
         for (int q = 1; q < 16; ++q) { t.x += sRed[q][tid].x; t.y += sRed[q][tid].y; }
         carrBank[((size_t)w * maxK + k) * (2 * B + 1) + bi] = t;
@@ -644,11 +690,22 @@ struct dpe_bcs {
     dpe::BcsChanDev *chan_h = nullptr;  // pinned staging
     float2 *part_d = nullptr, *mom_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
     int *info_d = nullptr;
-    int lastW = 0, lastK = 0;
+    int lastW = 0, lastK = 0, lastSumBlocks = 1;
     std::vector<int32_t> idxNext_h;
     dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
     dpe::GraphCache graphs;
 };
+
+// Blocks per window of the DC-sum kernel: ~8192 samples per block for batches; few windows get up to
+// one int4 load per thread (a lone window is latency-bound, not bandwidth-bound).
+static int sum_blocks(int S, int nWindows)
+{
+    const int base = S / 8192 > 0 ? S / 8192 : 1;
+    const int fine = (S / 4 + 255) / 256;
+    int want = 512 / nWindows < fine ? 512 / nWindows : fine;
+    if (want < base) want = base;
+    return want > dpe::kSumSlots ? dpe::kSumSlots : want;
+}
 
 static long long next_pow2(long long x)
 {
@@ -777,7 +834,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     // the per-kernel event timing and the graph replay exclude each other
     const bool useGraph = h->graphs.enabled && !h->prof.enabled;
     GraphCache::Guard graphGuard{h->graphs, stream};
-    const int sumBlocks = (S / 1024 / 8 > 0) ? (S / 1024 / 8 > kSumSlots ? kSumSlots : S / 1024 / 8) : 1;
+    const int sumBlocks = sum_blocks(S, nWindows);
+    h->lastSumBlocks = sumBlocks;
     if (useGraph) {
         const int rc = h->graphs.begin({samples_dev, nullptr, (long long)windowStrideSamples, nWindows, nChan,
                                         h->wideAllowed ? 1 : 0, stream}, stream);
@@ -899,7 +957,7 @@ int dpe_bcs_read_info(dpe_bcs *h, int32_t *idxNext, int32_t *noFlipLarger, doubl
     if (mean) {
         using dpe::kSumSlots;
         const int S = h->cfg.samplesPerWindow;
-        const int sumBlocks = (S / 1024 / 8 > 0) ? (S / 1024 / 8 > kSumSlots ? kSumSlots : S / 1024 / 8) : 1;
+        const int sumBlocks = h->lastSumBlocks;
         std::vector<long long> s((size_t)2 * kSumSlots * h->lastW);
         DPE_CHECK_HIP(hipMemcpy(s.data(), h->sums_d, sizeof(long long) * s.size(), hipMemcpyDeviceToHost));
         for (int i = 0; i < 2 * h->lastW; ++i) {
