@@ -38,7 +38,8 @@ def pmc_traffic(windows):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         d = json.load(open(f))
         if d.get("windows_per_step") == windows:
-            return d["kernels"]["bcm_scan_kernel<pos>"]["hbm_bytes_per_launch"]
+            k = d["kernels"].get("bcm_scan_kernel")
+            return k["hbm_bytes_per_launch"] if k else None
     return None
 
 
@@ -216,8 +217,9 @@ def main():
         units = float(args.steps) * W * 2.0 * G * K * world       # (gridpoint, SV) pairs, both manifolds, all ranks
         value = units / dt
         windows_per_s = args.steps * W / dt
-        ms_scan, n_scan = kern["bcm_scan_pos"]
-        bytes_per_launch = W * 20.0 * G                            # 16 B grid read + 4 B score write per point
+        ms_scan, n_scan = kern["bcm_scan"]
+        # one launch scans BOTH manifolds: 16 B grid read + 4 B score write per point
+        bytes_per_launch = 2 * W * 20.0 * G
         ach = bytes_per_launch / (ms_scan / n_scan * 1e-3) / 1e9 if n_scan else 0.0
         out = {
             "metric": "manifold gridpoints x SVs correlated/sec", "value": value, "unit": "gridpoint*SV/s",
@@ -227,7 +229,7 @@ def main():
                        "manifolds": 2, "windows_per_step": W, "lag_half_width": L, "bin_half_width": B,
                        "exchange": args.exchange if use_dist else "none", "scores_written": write_scores},
             "x_realtime": windows_per_s / 50.0, "windows_per_s": windows_per_s,
-            "roofline": {"bound": "hbm", "kernel": "bcm_scan_kernel<pos>", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "bcm_scan_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(W) if world == 1 else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": ms_scan / n_scan if n_scan else None},

@@ -45,15 +45,29 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kPtsPerThread = DPE_PTS_PER_THREAD;
 constexpr int kPtsPerBlock = 256 * kPtsPerThread;
 
+// One manifold's share of the fused launch
+struct ScanSide {
+    const float4 *grid;       // [G] ENU-dt offsets of this rank's shard
+    const float2 *bank;       // [W][maxK][nEnt] score bank
+    const BcmSvDev *sv;       // [W][maxK] coefficients (ignored when they ride in the kernel arguments)
+    float *scores;            // [W][G] or nullptr
+    double *wsum;             // weighted-sum partials (WMEAN) or nullptr
+    long long G, indexOffset;
+    int nEnt, split;          // bank entries per SV; blocks along x that work on this manifold
+};
+
 template <int LP, bool SECOND, bool CLAMP, bool WMEAN>
-__global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl, unsigned long long *__restrict__ clearPtr,
-                                                       int clearN, const float4 *__restrict__ grid, long long G, int K, int nEnt,
-                                                       int maxK, int lpower, const BcmSvDev *__restrict__ sv,
-                                                       const float2 *__restrict__ bank, float *__restrict__ scores,
-                                                       unsigned long long *__restrict__ keys,
-                                                       unsigned long long *__restrict__ oob, long long indexOffset,
-                                                       int keyStride, int keySlot, double *__restrict__ wsum)
+__device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, int maxK, int lpower,
+                                          unsigned long long *__restrict__ keys, unsigned long long *__restrict__ oob,
+                                          int keyStride, int keySlot)
 {
+    const float4 *__restrict__ grid = sd.grid;
+    const float2 *__restrict__ bank = sd.bank;
+    float *__restrict__ scores = sd.scores;
+    double *__restrict__ wsum = sd.wsum;
+    const long long G = sd.G, indexOffset = sd.indexOffset;
+    const int nEnt = sd.nEnt;
+    const unsigned nBlkX = (unsigned)sd.split;   // persistent stride of this manifold's blocks
     extern __shared__ __align__(16) unsigned char smem[];
     // |lerp|^2 = A + w (B + w C) per bank entry, split as {A,B} (ds_read_b64) + {C} (ds_read_b32): 4 LDS cycles per
     // wave access and conflict-free over 32 consecutive entries (a 12/16-byte ds_read_b96/b128 costs 8/4 and
@@ -64,12 +78,7 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
     __shared__ unsigned int sOob[4];
     __shared__ double sW[4][5];
 
-    (void)pb;
     const int w = blockIdx.y, tid = threadIdx.x;
-    // the key / counter set of the NEXT Update is cleared here (the sets alternate), so that no separate
-    // clearing launch or memset sits on the critical path
-    if (clearPtr && blockIdx.x == 0 && blockIdx.y == 0)
-        for (int i = tid; i < clearN; i += 256) clearPtr[i] = 0ull;
     // first tile's grid points: issued before the bank fill so both latencies overlap
     float4 nxt[kPtsPerThread];
     {
@@ -104,14 +113,14 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
     // held as PAIRS so that the geometry runs on packed fp32 (v_pk_fma_f32: two points per instruction).
     constexpr int kPairs = kPtsPerThread / 2;
     const unsigned last = (unsigned)(nEnt - 1);
-    // wave-uniform address -> scalar loads; inl = 1 / 2: this manifold's coefficients come from pb.s[inl - 1]
-    const BcmSvDev *svw = params_ptr(sv + (size_t)w * maxK, inl) + (inl == 2 ? DPE_MAX_CHAN : 0);
+    // wave-uniform address -> scalar loads; inl: this manifold's coefficients come from pb.s[SECOND ? 0 : 1]
+    const BcmSvDev *svw = params_ptr(sd.sv + (size_t)w * maxK, inl) + ((inl && !SECOND) ? DPE_MAX_CHAN : 0);
     const long long nTiles = (G + kPtsPerBlock - 1) / kPtsPerBlock;
     unsigned long long best = 0ull;
     unsigned int nOob = 0;
     // "Method 1" weighted-mean estimator (optional: wsum != nullptr): sum s, sum s*{x,y,z,t}, pair-packed fp32
     f2 w0 = f2{0.f, 0.f}, w1 = w0, w2 = w0, w3 = w0, w4 = w0;
-    for (long long tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    for (long long tile = blockIdx.x; tile < nTiles; tile += nBlkX) {
         const long long base = tile * kPtsPerBlock + tid;
         f2 dx[kPairs], dy[kPairs], dz[kPairs], dw[kPairs], q[kPairs], score[kPairs];
 #pragma unroll
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
             score[p] = f2{0.f, 0.f};
         }
         {   // prefetch the next tile of this block
-            const long long b1 = base + (long long)gridDim.x * kPtsPerBlock;
+            const long long b1 = base + (long long)nBlkX * kPtsPerBlock;
 #pragma unroll
             for (int it = 0; it < kPtsPerThread; ++it)
                 nxt[it] = (b1 + it * 256 < G) ? grid[b1 + it * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -240,15 +249,64 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
         b = sKey[1] > b ? sKey[1] : b;
         b = sKey[2] > b ? sKey[2] : b;
         b = sKey[3] > b ? sKey[3] : b;
-        atomicMax(&keys[(size_t)w * keyStride + keySlot], b);  // integer max: order-independent
+        // integer max: order-independent.  RETURNING atomics: their results are waited for before this
+        // block takes its ticket (see the fused kernel), which orders them without a release fence -- on
+        // gfx950 an agent-scope fence writes back the XCD's whole L2 (all the dirty score lines)
+        unsigned long long seen = atomicMax(&keys[(size_t)w * keyStride + keySlot], b);
         // per-block partial of the weighted sums, reduced on the host in block order (deterministic)
         if (WMEAN) {
-            double *o = wsum + ((size_t)w * gridDim.x + blockIdx.x) * 5;   // wsum already points at this manifold's half
+            double *o = wsum + ((size_t)w * nBlkX + blockIdx.x) * 5;   // wsum already points at this manifold's half
 #pragma unroll
             for (int j = 0; j < 5; ++j) o[j] = ((sW[0][j] + sW[1][j]) + sW[2][j]) + sW[3][j];
         }
         const unsigned int n = sOob[0] + sOob[1] + sOob[2] + sOob[3];
-        if (n) atomicAdd(&oob[(size_t)w * keyStride + keySlot], (unsigned long long)n);
+        if (n) seen += atomicAdd(&oob[(size_t)w * keyStride + keySlot], (unsigned long long)n);
+        asm volatile("" ::"v"(seen));   // keep the returns (and the s_waitcnt they imply) alive
+    }
+}
+
+// Both manifolds in ONE launch: blockIdx.z = 0 scores the position grid, 1 the velocity grid (a lone
+// window then pays one launch instead of two and the two scans overlap).  Around the scans the kernel
+//  * clears the key / counter set of the NEXT Update (the two sets alternate), so that no clearing
+//    launch or memset node sits on the critical path, and
+//  * lets the last block to finish publish keys and out-of-window counts of all windows straight
+//    into the pinned host mirror (system-scope stores): dpe_bcm_results needs no D2H copy command.
+// `done` cycles 0 .. total-1 through atomicInc and is back at 0 when the kernel ends.
+template <int LP, bool CLAMP_P, bool CLAMP_V, bool WMEAN>
+__global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl, ScanSide sp, ScanSide sv, int K, int maxK,
+                                                       int lpower, unsigned long long *__restrict__ keys,
+                                                       unsigned long long *__restrict__ oob,
+                                                       unsigned long long *__restrict__ clearPtr, int clearN,
+                                                       unsigned int *__restrict__ done,
+                                                       unsigned long long *__restrict__ hostKeys,
+                                                       unsigned long long *__restrict__ hostOob)
+{
+    (void)pb;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = threadIdx.x; i < clearN; i += 256) clearPtr[i] = 0ull;
+    if (blockIdx.z == 0) {
+        if (blockIdx.x < (unsigned)sp.split) scan_body<LP, true, CLAMP_P, WMEAN>(sp, inl, K, maxK, lpower, keys, oob, 2, 0);
+    } else {
+        if (blockIdx.x < (unsigned)sv.split) scan_body<LP, false, CLAMP_V, WMEAN>(sv, inl, K, maxK, lpower, keys, oob, 2, 1);
+    }
+    // ---- last block out publishes the results
+    // Thread 0 issued this block's key / counter atomics and has their return values, i.e. they are
+    // performed at the device's coherence point; its ticket follows in program order.  The block that
+    // draws the last ticket therefore reads final values with agent-scope loads.
+    __shared__ unsigned int sLast;
+    if (threadIdx.x == 0) {
+        const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+        sLast = (atomicInc(done, total - 1) == total - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (sLast) {
+        const int n = 2 * (int)gridDim.y;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const unsigned long long kv = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long ov = __hip_atomic_load(&oob[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&hostKeys[i], kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&hostOob[i], ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -263,6 +321,8 @@ struct dpe_bcm {
     dpe::BcmSvDev *sv_d = nullptr, *sv_h = nullptr;  // [2][W][maxK]  (manifold-major)
     unsigned long long *keys_d = nullptr;  // [2 sets][{keys [W][2], counts [W][2]}], alternating between Updates
     int cur = 1;                           // set of the latest Update
+    unsigned int *done_d = nullptr;        // finished-block ticket of the scan kernel (returns to 0 by itself)
+    unsigned long long *keys_hd = nullptr; // device view of the pinned mirror keys_h
     double *wsum_d = nullptr;   // [W][2][split][5] per-block weighted sums
     unsigned long long *keys_h = nullptr, *oob_h = nullptr;   // pinned mirrors, filled by async copies at the end of Update
     unsigned lastSplit[2] = {0, 0};
@@ -271,7 +331,7 @@ struct dpe_bcm {
     std::vector<dpe_bcm_window> win_h;
     int lastW = 0;
     double posExtent = 0, velExtent = 0;
-    dpe::KernelProfiler prof;  // slots: 0 pos scan, 1 vel scan
+    dpe::KernelProfiler prof;  // slot 0: the fused position + velocity scan
     dpe::GraphCache graphs;
 };
 
@@ -300,39 +360,50 @@ static unsigned scan_split(long long G, int nWindows)
     return (unsigned)s;
 }
 
-template <bool SECOND, bool CLAMP, bool WMEAN>
-static void launch_scan3(const dpe::BcmParamBlock &pb, int inl, unsigned long long *clr, int clrN, int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K, int nEnt,
-                         int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores, unsigned long long *keys,
-                         unsigned long long *oob, long long off, int slot, double *wsum)
+struct ScanLaunch {
+    dpe::BcmParamBlock pb;
+    int inl, K, maxK, lp;
+    dpe::ScanSide sp, sv;
+    unsigned long long *keys, *oob, *clr;
+    int clrN;
+    unsigned int *done;
+    unsigned long long *hostKeys, *hostOob;
+    dim3 grid;
+    size_t lds;
+    hipStream_t st;
+};
+
+template <int LP, bool CP, bool CV, bool WM>
+static void launch_scan4(const ScanLaunch &a)
 {
-    using namespace dpe;
-    if (lp == 1)
-        hipLaunchKernelGGL((bcm_scan_kernel<1, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, pb, inl, clr, clrN, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
-    else if (lp == 2)
-        hipLaunchKernelGGL((bcm_scan_kernel<2, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, pb, inl, clr, clrN, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
-    else
-        hipLaunchKernelGGL((bcm_scan_kernel<0, SECOND, CLAMP, WMEAN>), grid, dim3(256), lds, st, pb, inl, clr, clrN, g, G, K, nEnt, maxK, lp, sv, bank, scores, keys, oob, off, 2, slot, wsum);
+    hipLaunchKernelGGL((dpe::bcm_scan_kernel<LP, CP, CV, WM>), a.grid, dim3(256), a.lds, a.st, a.pb, a.inl, a.sp, a.sv, a.K, a.maxK,
+                       a.lp, a.keys, a.oob, a.clr, a.clrN, a.done, a.hostKeys, a.hostOob);
 }
 
-// clamp = false only when the host has proved that every index of every (point, SV) pair stays inside
-// the bank (then the kernel drops the range clamp and the out-of-window bookkeeping); wsum != nullptr
-// selects the variant that also accumulates the weighted-mean sums
-template <bool SECOND>
-static void launch_scan(const dpe::BcmParamBlock &pb, int inl, unsigned long long *clr, int clrN, bool clamp, int lp, dim3 grid, size_t lds, hipStream_t st, const float4 *g, long long G, int K,
-                        int nEnt, int maxK, const dpe::BcmSvDev *sv, const float2 *bank, float *scores,
-                        unsigned long long *keys, unsigned long long *oob, long long off, int slot, double *wsum)
+template <bool CP, bool CV, bool WM>
+static void launch_scan3(const ScanLaunch &a)
 {
-#define DPE_SCAN_ARGS pb, inl, clr, clrN, lp, grid, lds, st, g, G, K, nEnt, maxK, sv, bank, scores, keys, oob, off, slot, wsum
-    if (clamp) { if (wsum) launch_scan3<SECOND, true, true>(DPE_SCAN_ARGS); else launch_scan3<SECOND, true, false>(DPE_SCAN_ARGS); }
-    else { if (wsum) launch_scan3<SECOND, false, true>(DPE_SCAN_ARGS); else launch_scan3<SECOND, false, false>(DPE_SCAN_ARGS); }
-#undef DPE_SCAN_ARGS
+    if (a.lp == 1) launch_scan4<1, CP, CV, WM>(a);
+    else if (a.lp == 2) launch_scan4<2, CP, CV, WM>(a);
+    else launch_scan4<0, CP, CV, WM>(a);
 }
 
-template <int LP, bool SECOND, bool CLAMP>
+// clampP / clampV = false only when the host has proved that every index of every (point, SV) pair of
+// that manifold stays inside the bank (then the kernel drops the range clamp and the out-of-window
+// bookkeeping); wmean selects the variant that also accumulates the weighted-mean sums
+static void launch_scan(bool clampP, bool clampV, bool wmean, const ScanLaunch &a)
+{
+#define DPE_SCAN_PICK(CP, CV) do { if (wmean) launch_scan3<CP, CV, true>(a); else launch_scan3<CP, CV, false>(a); } while (0)
+    if (clampP) { if (clampV) DPE_SCAN_PICK(true, true); else DPE_SCAN_PICK(true, false); }
+    else { if (clampV) DPE_SCAN_PICK(false, true); else DPE_SCAN_PICK(false, false); }
+#undef DPE_SCAN_PICK
+}
+
+template <int LP, bool CP, bool CV>
 static void allow_big_lds()
 {
-    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, SECOND, CLAMP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
-    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, SECOND, CLAMP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, CP, CV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+    (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, CP, CV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
 }
 
 extern "C" {
@@ -403,6 +474,10 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
     h->oob_h = h->keys_h + 2 * W;
     DPE_CHECK_HIP(hipMemset(h->keys_d, 0, 8 * W * sizeof(unsigned long long)));
+    h->done_d = dev_alloc<unsigned int>(1);
+    DPE_REQUIRE(h->done_d, "[BatchCorrManifold] create: device allocation failed");
+    DPE_CHECK_HIP(hipMemset(h->done_d, 0, sizeof(unsigned int)));
+    DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->keys_hd, h->keys_h, 0));
     h->win_h.resize(W);
     *out = h;
     return 0;
@@ -411,7 +486,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
 int dpe_bcm_destroy(dpe_bcm *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d};
+    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d, h->done_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->sv_h) (void)hipHostFree(h->sv_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
@@ -508,33 +583,24 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
     }
     const int nLag = 2 * L + 1, nBin = 2 * B + 1;
-    {
-        const long long G = h->cfg.posGridSize;
-        const dim3 grid(scan_split(G, nWindows), nWindows);
-        h->lastSplit[0] = grid.x;
-        const size_t lds = (size_t)nChan * nLag * 12;
-        h->prof.begin(0, stream);
-        launch_scan<true>(pb, inlineParams ? 1 : 0, other, 4 * W, !posInside, h->cfg.lPower, grid, lds, stream, h->posGrid_d, G,
-                          nChan, nLag, maxK, h->sv_d, reinterpret_cast<const float2 *>(codeBank_dev), h->posScores_d, keys, oob,
-                          h->cfg.posGridIndexOffset, 0, h->cfg.weightedMean ? h->wsum_d : nullptr);
-        h->prof.end(0, stream);
-    }
-    {
-        const long long G = h->cfg.velGridSize;
-        const dim3 grid(scan_split(G, nWindows), nWindows);
-        h->lastSplit[1] = grid.x;
-        const size_t lds = (size_t)nChan * nBin * 12;
-        h->prof.begin(1, stream);
-        launch_scan<false>(pb, inlineParams ? 2 : 0, nullptr, 0, !velInside, h->cfg.lPower, grid, lds, stream, h->velGrid_d, G,
-                           nChan, nBin, maxK, h->sv_d + (size_t)W * maxK, reinterpret_cast<const float2 *>(carrBank_dev),
-                           h->velScores_d, keys, oob, h->cfg.velGridIndexOffset, 1,
-                           h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr);
-        h->prof.end(1, stream);
-    }
-    // results travel to pinned host memory on the same stream: dpe_bcm_results only has to synchronise
-    // (keys and counters are contiguous on both sides: one copy up to the last counter in use)
-    DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, keys, sizeof(unsigned long long) * (2 * (size_t)W + 2 * nWindows),
-                                 hipMemcpyDeviceToHost, stream));
+    ScanLaunch a;
+    a.pb = pb; a.inl = inlineParams ? 1 : 0; a.K = nChan; a.maxK = maxK; a.lp = h->cfg.lPower;
+    a.sp = ScanSide{h->posGrid_d, reinterpret_cast<const float2 *>(codeBank_dev), h->sv_d, h->posScores_d,
+                    h->cfg.weightedMean ? h->wsum_d : nullptr, h->cfg.posGridSize, h->cfg.posGridIndexOffset, nLag,
+                    (int)h->lastSplit[0]};
+    a.sv = ScanSide{h->velGrid_d, reinterpret_cast<const float2 *>(carrBank_dev), h->sv_d + (size_t)W * maxK, h->velScores_d,
+                    h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr, h->cfg.velGridSize, h->cfg.velGridIndexOffset, nBin,
+                    (int)h->lastSplit[1]};
+    a.keys = keys; a.oob = oob; a.clr = other; a.clrN = 4 * W;
+    a.done = h->done_d; a.hostKeys = h->keys_hd; a.hostOob = h->keys_hd + 2 * W;
+    a.grid = dim3(h->lastSplit[0] > h->lastSplit[1] ? h->lastSplit[0] : h->lastSplit[1], nWindows, 2);
+    a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * 12;
+    a.st = stream;
+    // the kernel's last block writes keys and counts into the pinned host mirror: dpe_bcm_results only
+    // has to synchronise
+    h->prof.begin(0, stream);
+    launch_scan(!posInside, !velInside, h->cfg.weightedMean != 0, a);
+    h->prof.end(0, stream);
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrManifold] Update: hipGraph instantiate/launch failed");
     DPE_CHECK_HIP(hipGetLastError());
     return 0;

@@ -366,7 +366,7 @@ class BatchCorrManifold:
     def profile(self, enable=True):
         ms, cnt = (C.c_float * 2)(), (C.c_int32 * 2)()
         _check(lib().dpe_bcm_profile(self._h, C.c_int32(1 if enable else 0), ms, cnt))
-        return {n: (ms[i], cnt[i]) for i, n in enumerate(("bcm_scan_pos", "bcm_scan_vel"))}
+        return {"bcm_scan": (ms[0], cnt[0])}   # one fused launch scores both manifolds
 
     def Stop(self):
         if self.Started:
