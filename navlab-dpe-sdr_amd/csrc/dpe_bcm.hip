@@ -69,11 +69,12 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
     const int nEnt = sd.nEnt;
     const unsigned nBlkX = (unsigned)sd.split;   // persistent stride of this manifold's blocks
     extern __shared__ __align__(16) unsigned char smem[];
-    // |lerp|^2 = A + w (B + w C) per bank entry, split as {A,B} (ds_read_b64) + {C} (ds_read_b32): 4 LDS cycles per
-    // wave access and conflict-free over 32 consecutive entries (a 12/16-byte ds_read_b96/b128 costs 8/4 and
-    // collides every 16 entries)
-    float2 *sAB = reinterpret_cast<float2 *>(smem);                         // [K][nEnt]
-    float *sC = reinterpret_cast<float *>(smem + sizeof(float2) * (size_t)K * nEnt);   // [K][nEnt]
+    // |lerp|^2 = A + w (B + w C) per bank entry, stored as {A, B, 0, C}: one address register serves the
+    // ds_read_b64 {A,B} and the ds_read_b32 {C} (immediate offset 12; the gap keeps the compiler from fusing
+    // them into a slower ds_read_b96).  A wave's 64 points land on a few
+    // neighbouring entries (the index moves by << 1 entry per grid step), so the 16-byte stride is
+    // conflict-free as long as a wave spans < 16 entries.
+    float4 *sE = reinterpret_cast<float4 *>(smem);                           // [K][nEnt]
     __shared__ unsigned long long sKey[4];
     __shared__ unsigned int sOob[4];
     __shared__ double sW[4][5];
@@ -96,11 +97,9 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
         if (j + 1 < nEnt) {
             const float2 c0 = bw[(size_t)k * nEnt + j], c1 = bw[(size_t)k * nEnt + j + 1];
             const float dr = c1.x - c0.x, di = c1.y - c0.y;
-            sAB[i] = make_float2(c0.x * c0.x + c0.y * c0.y, 2.f * (c0.x * dr + c0.y * di));
-            sC[i] = dr * dr + di * di;
+            sE[i] = make_float4(c0.x * c0.x + c0.y * c0.y, 2.f * (c0.x * dr + c0.y * di), 0.f, dr * dr + di * di);
         } else {
-            sAB[i] = make_float2(0.f, 0.f);
-            sC[i] = 0.f;
+            sE[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
@@ -140,8 +139,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
 #pragma unroll DPE_SV_UNROLL
         for (int k = 0; k < K; ++k) {
             const BcmSvDev s = svw[k];
-            const float2 *bkAB = sAB + k * nEnt;
-            const float *bkC = sC + k * nEnt;
+            const float4 *bk = sE + k * nEnt;
 #pragma unroll
             for (int p = 0; p < kPairs; ++p) {
                 f2 a = dx[p] * s.ue;
@@ -165,8 +163,8 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
                         e = min(e, last);
                         emax = max(emax, e);
                     }
-                    const float2 ab = bkAB[e];
-                    const float m2 = fmaf(wgt, fmaf(wgt, bkC[e], ab.y), ab.x);
+                    const float2 ab = *reinterpret_cast<const float2 *>(&bk[e]);
+                    const float m2 = fmaf(wgt, fmaf(wgt, bk[e].w, ab.y), ab.x);
                     if (LP == 1) c[j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(m2));    // raw v_sqrt_f32 (1 ulp)
                     else if (LP == 2) c[j] = m2;
                     else c[j] = powf(__builtin_amdgcn_sqrtf(__builtin_fabsf(m2)), (float)lpower);
@@ -594,7 +592,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     a.keys = keys; a.oob = oob; a.clr = other; a.clrN = 4 * W;
     a.done = h->done_d; a.hostKeys = h->keys_hd; a.hostOob = h->keys_hd + 2 * W;
     a.grid = dim3(h->lastSplit[0] > h->lastSplit[1] ? h->lastSplit[0] : h->lastSplit[1], nWindows, 2);
-    a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * 12;
+    a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * 16;
     a.st = stream;
     // the kernel's last block writes keys and counts into the pinned host mirror: dpe_bcm_results only
     // has to synchronise

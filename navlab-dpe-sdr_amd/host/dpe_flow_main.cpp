@@ -27,7 +27,7 @@ int main(int argc, char **argv)
     std::string samples, handoff, out = "XFile.csv", loadGrid;
     double fs = 2.5e6, T = 0.02;
     int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
-    bool useGraph = false;
+    bool useGraph = false, timing = false;
     float spacing = 1.0f, delta[4] = {0, 0, 0, 0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -58,6 +58,7 @@ int main(int argc, char **argv)
         else if (a == "--spacing") { spacing = (float)std::atof(next()); ++i; }
         else if (a == "--lpower") { lpower = std::atoi(next()); ++i; }
         else if (a == "--graph") { useGraph = true; }
+        else if (a == "--timing") { timing = true; }
         else if (a == "--init-delta") { next(4); for (int j = 0; j < 4; ++j) delta[j] = (float)std::atof(argv[i + 1 + j]); i += 4; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -177,10 +178,12 @@ int main(int argc, char **argv)
     dpe_stream_t stream = nullptr;
     CHECK(dpe_stream_create(&stream));
     CHECK(flow.Start(stream));
+    flow.EnableTiming(timing);
     int n = 0;
     const auto t0 = std::chrono::steady_clock::now();
     while (n < iters && flow.Step() == 0) ++n;                  // FlowThread loop, flow.cu:122-137
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    flow.ReportTiming(std::clog);
     flow.Stop();
     dpe_stream_destroy(stream);
     std::clog << "[DPEFlow] " << n << " iterations, " << (n ? dt / n * 1e6 : 0.0) << " us per iteration ("

@@ -11,6 +11,7 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <chrono>
 #include <vector>
 
 namespace dsp {
@@ -291,11 +292,25 @@ class Flow {
     // one iteration of FlowThread's loop (flow.cu:122-137); returns the first non-zero Update()
     int Step()
     {
+        if (Timing) return TimedStep();
         for (Module *m : Mods) {
             const int r = m->Update(&Stream);
             if (r) return r;
         }
         return 0;
+    }
+    // per-module wall time of Update() (host side; a module that waits on the stream is charged the wait)
+    void EnableTiming(bool on)
+    {
+        Timing = on;
+        Spent.assign(Mods.size(), 0.0);
+        Steps = 0;
+    }
+    void ReportTiming(std::ostream &os) const
+    {
+        if (!Timing || !Steps) return;
+        for (size_t i = 0; i < Mods.size(); ++i)
+            os << "[Flow] " << Mods[i]->GetModuleName() << ": " << Spent[i] / Steps * 1e6 << " us per Update" << std::endl;
     }
     void Stop()
     {
@@ -303,7 +318,21 @@ class Flow {
     }
 
   private:
+    int TimedStep()
+    {
+        for (size_t i = 0; i < Mods.size(); ++i) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int r = Mods[i]->Update(&Stream);
+            Spent[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (r) return r;
+        }
+        ++Steps;
+        return 0;
+    }
     std::vector<Module *> Mods;
+    std::vector<double> Spent;
+    long long Steps = 0;
+    bool Timing = false;
     void *Stream = nullptr;
 };
 
