@@ -247,6 +247,25 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out);
 int dpe_acq_destroy(dpe_acq *h);
 int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream);   /* one window, asynchronous */
 int dpe_acq_results(dpe_acq *h, dpe_acq_result *results /* [nPrn] */, dpe_stream_t stream);   /* synchronises */
+/* Correlator.fine_frequency_acquisition (correlator.py:105-133): code wipe-off with the coarse (rc, fc),
+ * zero-padded FFT of rawfile.carr_fftpts = 8 << S.bit_length() points (rawfile.py:173), first maximum of
+ * |.| inside [min(bins), max(bins)] -> ri = angle / 2 pi (cycles), fi, fc.  Synchronises. */
+typedef struct dpe_acq_fine_result {
+    int32_t prn, maxCarrIdx;    /* index into the fft-shifted spectrum */
+    double rc, ri, fc, fi, peakRe, peakIm;
+} dpe_acq_fine_result;
+int dpe_acq_fine(dpe_acq *h, const int16_t *samples_dev, const dpe_acq_result *coarse /* [nPrn] */,
+                 dpe_acq_fine_result *fine /* [nPrn] */, dpe_stream_t stream);
+/* Receiver.scalar_acquisition (receiver.py:452-520): search_signal (coarse + fine) on two consecutive
+ * windows, keep per PRN the window with the larger cppm; a second-window result is propagated back by one
+ * window (rc - fc T mod 1023, ri - fi T mod 1), so the parameters always refer to the first window's start. */
+typedef struct dpe_acq_track_init {
+    int32_t prn, found, fromSecondWindow, reserved;
+    double rc, ri, fc, fi, cppr, cppm;
+    double cppmWindow[2];
+} dpe_acq_track_init;
+int dpe_acq_scalar_acquisition(dpe_acq *h, const int16_t *window0_dev, const int16_t *window1_dev,
+                               dpe_acq_track_init *out /* [nPrn] */, dpe_stream_t stream);
 /* |coarse_result_matrix| as float [nPrn][nBins][S/N] and its per-lag maximum over bins [nPrn][S/N] */
 int dpe_acq_surface(dpe_acq *h, const float **surface_dev, const float **maxPerCode_dev);
 

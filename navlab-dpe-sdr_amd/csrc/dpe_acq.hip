@@ -90,6 +90,90 @@ __global__ __launch_bounds__(256) void acq_colmax_kernel(const float *__restrict
 
 }  // namespace dpe
 
+namespace dpe {
+
+// ---- fine frequency (correlator.py:105-133)
+struct AcqFineChan {
+    double rc, fc;   // coarse code phase (chips) and code frequency
+};
+
+__global__ __launch_bounds__(256) void acq_sum_kernel(const int16_t *__restrict__ iq, int S, long long *__restrict__ sums)
+{
+    const int *x = reinterpret_cast<const int *>(iq);
+    long long sI = 0, sQ = 0;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < S; n += gridDim.x * blockDim.x) {
+        const int v = x[n];
+        sI += (short)(v & 0xFFFF);
+        sQ += v >> 16;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sI += __shfl_xor(sI, off, 64);
+        sQ += __shfl_xor(sQ, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sums[0]), (unsigned long long)sI);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sums[1]), (unsigned long long)sQ);
+    }
+}
+
+// carr[p][n] = (raw[n] - mean) * chips_p[floor(t_n fc_p + rc_p) mod 1023] for n < S, 0 up to the FFT length (:114-121)
+__global__ __launch_bounds__(256) void acq_fine_build_kernel(const int16_t *__restrict__ iq, int S, int C, double fs,
+                                                             const AcqFineChan *__restrict__ chan,
+                                                             const long long *__restrict__ sums,
+                                                             const int8_t *__restrict__ chips, float2 *__restrict__ out)
+{
+    const int p = blockIdx.y;
+    const AcqFineChan ch = chan[p];
+    const float mRe = (float)((double)sums[0] / (double)S), mIm = (float)((double)sums[1] / (double)S);
+    const int *x = reinterpret_cast<const int *>(iq);
+    const int8_t *cp = chips + (size_t)p * 1024;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < C; n += gridDim.x * blockDim.x) {
+        float2 o = make_float2(0.f, 0.f);
+        if (n < S) {
+            const int v = x[n];
+            const double t = (double)n / fs;                                   // rawfile.time_idc
+            const double ph = __dadd_rn(__dmul_rn(t, ch.fc), ch.rc);           // time_idc * fc + rc, two roundings as numpy
+            const long long ci = (long long)floor(ph);
+            const float r = (float)cp[(int)(((ci % kLCA) + kLCA) % kLCA)];
+            o = make_float2(((float)(short)(v & 0xFFFF) - mRe) * r, ((float)(v >> 16) - mIm) * r);
+        }
+        out[(size_t)p * C + n] = o;
+    }
+}
+
+// first maximum of |fftshift(X)| over the shifted indices [iLo, iHi] (:124-127); one block per PRN
+__global__ __launch_bounds__(256) void acq_fine_peak_kernel(const float2 *__restrict__ X, int C, int iLo, int iHi,
+                                                            int *__restrict__ idxOut, float2 *__restrict__ valOut)
+{
+    const int p = blockIdx.x;
+    const float2 *x = X + (size_t)p * C;
+    unsigned long long best = 0ull;
+    for (int i = iLo + threadIdx.x; i <= iHi; i += 256) {
+        const float2 v = x[(i + C / 2) % C];
+        const float m = v.x * v.x + v.y * v.y;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    __shared__ unsigned long long sB[4];
+    if ((threadIdx.x & 63) == 0) sB[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = sB[0];
+        for (int q = 1; q < 4; ++q) b = sB[q] > b ? sB[q] : b;
+        const int i = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+        idxOut[p] = i;
+        valOut[p] = x[(i + C / 2) % C];
+    }
+}
+
+}  // namespace dpe
+
 struct dpe_acq {
     dpe_acq_config cfg;
     int S, N, M, B, P, len, chunk;   // len = FFT length (S, or M in mode 2)
@@ -98,6 +182,15 @@ struct dpe_acq {
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
     float *surf_d = nullptr, *mp_d = nullptr;
     bool searched = false;
+    // fine-frequency stage, allocated on first use
+    int fineC = 0, fineLo = 0, fineHi = -1;
+    hipfftHandle planFine = 0;
+    bool haveFine = false;
+    float2 *F_d = nullptr, *fineVal_d = nullptr;
+    int *fineIdx_d = nullptr;
+    long long *fineSums_d = nullptr;
+    dpe::AcqFineChan *fineChan_d = nullptr;
+    int8_t *chips_d = nullptr;
 };
 
 #define DPE_CHECK_FFT(expr)                                                                  \
@@ -116,7 +209,8 @@ int dpe_acq_destroy(dpe_acq *h)
     if (!h) return 0;
     if (h->haveFwd) hipfftDestroy(h->planFwd);
     if (h->haveInv) hipfftDestroy(h->planInv);
-    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d};
+    if (h->haveFine) hipfftDestroy(h->planFine);
+    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d};
     for (void *b : bufs) (void)hipFree(b);
     delete h;
     return 0;
@@ -255,6 +349,124 @@ int dpe_acq_results(dpe_acq *h, dpe_acq_result *out, dpe_stream_t stream)
             if (v > lo && v < hi) { sum += v; ++cnt; }
         r.cppm = cnt ? r.peak / (sum / cnt) : 0.0;
         r.found = r.cppm > 2.0 ? 1 : 0;                                            // :103
+    }
+    return 0;
+}
+
+static int fine_prepare(dpe_acq *h)
+{
+    using namespace dpe;
+    if (h->haveFine) return 0;
+    const int S = h->S, P = h->P;
+    int bl = 0;
+    for (int v = S; v; v >>= 1) ++bl;            // S.bit_length()
+    const long long C = 8ll * (1ll << bl);       // rawfile.carr_fftpts, rawfile.py:173
+    DPE_REQUIRE(C <= (1ll << 27), "[Acquisition] fine: FFT length %lld too large", C);
+    h->fineC = (int)C;
+    // shifted indices kept by the mask (:124-125): min(bins) <= fftfreq <= max(bins), fftfreq = k * (1 / (C * (1 / fs)))
+    const double fs = h->cfg.samplingFrequency, val = 1.0 / ((double)C * (1.0 / fs));
+    const double b0 = h->cfg.binStartHz, b1 = h->cfg.binStartHz + h->cfg.binStepHz * (h->B - 1);
+    const double fmin = std::min(b0, b1), fmax = std::max(b0, b1);
+    long long lo = (long long)std::floor(fmin / val) - 2, hi = (long long)std::ceil(fmax / val) + 2;
+    while ((double)lo * val < fmin) ++lo;
+    while ((double)hi * val > fmax) --hi;
+    lo = std::max(lo, -C / 2); hi = std::min(hi, C / 2 - 1);
+    DPE_REQUIRE(lo <= hi, "[Acquisition] fine: empty search range");
+    h->fineLo = (int)(lo + C / 2); h->fineHi = (int)(hi + C / 2);
+    h->F_d = dev_alloc<float2>((size_t)P * C);
+    h->fineVal_d = dev_alloc<float2>(P);
+    h->fineIdx_d = dev_alloc<int>(P);
+    h->fineSums_d = dev_alloc<long long>(2);
+    h->fineChan_d = dev_alloc<AcqFineChan>(P);
+    h->chips_d = dev_alloc<int8_t>((size_t)P * 1024);
+    DPE_REQUIRE(h->F_d && h->fineVal_d && h->fineIdx_d && h->fineSums_d && h->fineChan_d && h->chips_d,
+                "[Acquisition] fine: device allocation failed");
+    std::vector<int8_t> chips((size_t)P * 1024, 0);
+    for (int p = 0; p < P; ++p) gen_ca_code_host(h->cfg.prn[p], chips.data() + (size_t)p * 1024);
+    DPE_CHECK_HIP(hipMemcpy(h->chips_d, chips.data(), chips.size(), hipMemcpyHostToDevice));
+    int n[1] = {(int)C};
+    DPE_CHECK_FFT(hipfftPlanMany(&h->planFine, 1, n, nullptr, 1, (int)C, nullptr, 1, (int)C, HIPFFT_C2C, P));
+    h->haveFine = true;
+    return 0;
+}
+
+int dpe_acq_fine(dpe_acq *h, const int16_t *samples_dev, const dpe_acq_result *coarse, dpe_acq_fine_result *fine,
+                 dpe_stream_t stream_)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && samples_dev && coarse && fine, "[Acquisition] fine: null argument");
+    if (fine_prepare(h)) return -1;
+    hipStream_t st = (hipStream_t)stream_;
+    const int S = h->S, P = h->P, C = h->fineC;
+    std::vector<AcqFineChan> ch(P);
+    for (int p = 0; p < P; ++p) {
+        DPE_REQUIRE(coarse[p].fc > 0, "[Acquisition] fine: bad coarse code frequency (PRN %d)", h->cfg.prn[p]);
+        ch[p].rc = coarse[p].rc; ch[p].fc = coarse[p].fc;
+    }
+    DPE_CHECK_HIP(hipMemcpyAsync(h->fineChan_d, ch.data(), sizeof(AcqFineChan) * P, hipMemcpyHostToDevice, st));
+    DPE_CHECK_HIP(hipStreamSynchronize(st));   // ch is a stack-lifetime staging buffer
+    DPE_CHECK_HIP(hipMemsetAsync(h->fineSums_d, 0, sizeof(long long) * 2, st));
+    hipLaunchKernelGGL(acq_sum_kernel, dim3(32), dim3(256), 0, st, samples_dev, S, h->fineSums_d);
+    hipLaunchKernelGGL(acq_fine_build_kernel, dim3((C + 1023) / 1024, P), dim3(256), 0, st, samples_dev, S, C,
+                       h->cfg.samplingFrequency, h->fineChan_d, h->fineSums_d, h->chips_d, h->F_d);
+    DPE_CHECK_FFT(hipfftSetStream(h->planFine, st));
+    DPE_CHECK_FFT(hipfftExecC2C(h->planFine, (hipfftComplex *)h->F_d, (hipfftComplex *)h->F_d, HIPFFT_FORWARD));
+    hipLaunchKernelGGL(acq_fine_peak_kernel, dim3(P), dim3(256), 0, st, h->F_d, C, h->fineLo, h->fineHi, h->fineIdx_d, h->fineVal_d);
+    DPE_CHECK_HIP(hipGetLastError());
+    std::vector<int> idx(P);
+    std::vector<float2> val(P);
+    DPE_CHECK_HIP(hipMemcpyAsync(idx.data(), h->fineIdx_d, sizeof(int) * P, hipMemcpyDeviceToHost, st));
+    DPE_CHECK_HIP(hipMemcpyAsync(val.data(), h->fineVal_d, sizeof(float2) * P, hipMemcpyDeviceToHost, st));
+    DPE_CHECK_HIP(hipStreamSynchronize(st));
+    const double fs = h->cfg.samplingFrequency, fval = 1.0 / ((double)C * (1.0 / fs));
+    for (int p = 0; p < P; ++p) {
+        dpe_acq_fine_result &r = fine[p];
+        r.prn = h->cfg.prn[p];
+        r.maxCarrIdx = idx[p];
+        r.peakRe = val[p].x; r.peakIm = val[p].y;
+        r.rc = coarse[p].rc;                                                      // :133 (rc passes through)
+        r.ri = std::atan2((double)val[p].y, (double)val[p].x) / (2.0 * kPi);      // :129
+        r.fi = (double)(idx[p] - C / 2) * fval;                                   // :130
+        r.fc = kFCA + (h->cfg.dopplerSign * kFCA / kFL1) * r.fi;                  // :131
+    }
+    return 0;
+}
+
+static double pos_mod(double v, double m)   // np.mod for m > 0
+{
+    const double t = std::fmod(v, m);
+    return t < 0.0 ? t + m : t;
+}
+
+int dpe_acq_scalar_acquisition(dpe_acq *h, const int16_t *window0_dev, const int16_t *window1_dev,
+                               dpe_acq_track_init *out, dpe_stream_t stream)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && window0_dev && window1_dev && out, "[Acquisition] scalar_acquisition: null argument");
+    const int P = h->P;
+    const double T = (double)h->S / h->cfg.samplingFrequency;
+    std::vector<dpe_acq_result> c0(P), c1(P);
+    std::vector<dpe_acq_fine_result> f0(P), f1(P);
+    if (dpe_acq_search(h, window0_dev, stream) || dpe_acq_results(h, c0.data(), stream) ||
+        dpe_acq_fine(h, window0_dev, c0.data(), f0.data(), stream))
+        return -1;
+    if (dpe_acq_search(h, window1_dev, stream) || dpe_acq_results(h, c1.data(), stream) ||
+        dpe_acq_fine(h, window1_dev, c1.data(), f1.data(), stream))
+        return -1;
+    for (int p = 0; p < P; ++p) {
+        dpe_acq_track_init &r = out[p];
+        r.prn = h->cfg.prn[p];
+        r.fromSecondWindow = c1[p].cppm > c0[p].cppm ? 1 : 0;                     // receiver.py:493
+        if (r.fromSecondWindow) {
+            r.rc = pos_mod(f1[p].rc - f1[p].fc * T, (double)kLCA);               // :495-496: back to the first window's start
+            r.ri = pos_mod(f1[p].ri - f1[p].fi * T, 1.0);
+            r.fc = f1[p].fc; r.fi = f1[p].fi;
+            r.found = c1[p].found; r.cppr = c1[p].cppr; r.cppm = c1[p].cppm;
+        } else {
+            r.rc = f0[p].rc; r.ri = f0[p].ri; r.fc = f0[p].fc; r.fi = f0[p].fi;  // :507
+            r.found = c0[p].found; r.cppr = c0[p].cppr; r.cppm = c0[p].cppm;
+        }
+        r.cppmWindow[0] = c0[p].cppm; r.cppmWindow[1] = c1[p].cppm;
     }
     return 0;
 }

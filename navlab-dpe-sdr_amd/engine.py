@@ -24,6 +24,7 @@ EXPORTS = [
     "dpe_event_elapsed_ms", "dpe_event_destroy", "dpe_chm_create", "dpe_chm_destroy", "dpe_chm_start",
     "dpe_chm_update", "dpe_chm_outputs", "dpe_bcs_profile", "dpe_bcm_profile", "dpe_acq_create", "dpe_acq_destroy",
     "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface", "dpe_bcs_set_graph", "dpe_bcm_set_graph",
+    "dpe_acq_fine", "dpe_acq_scalar_acquisition",
 ]
 
 
@@ -456,6 +457,17 @@ class AcqResult(C.Structure):
                 ("peak", C.c_double)]
 
 
+class AcqFineResult(C.Structure):
+    _fields_ = [("prn", C.c_int32), ("maxCarrIdx", C.c_int32), ("rc", C.c_double), ("ri", C.c_double), ("fc", C.c_double),
+                ("fi", C.c_double), ("peakRe", C.c_double), ("peakIm", C.c_double)]
+
+
+class AcqTrackInit(C.Structure):
+    _fields_ = [("prn", C.c_int32), ("found", C.c_int32), ("fromSecondWindow", C.c_int32), ("reserved", C.c_int32),
+                ("rc", C.c_double), ("ri", C.c_double), ("fc", C.c_double), ("fi", C.c_double), ("cppr", C.c_double),
+                ("cppm", C.c_double), ("cppmWindow", C.c_double * 2)]
+
+
 class Acquisition:
     """Coarse acquisition over `prns` x Doppler bins x all code delays of one window.
     mode: "coherent" / "noncoherent" = Correlator.coarse_acquisition(coherent=True/False)
@@ -486,6 +498,32 @@ class Acquisition:
         _check(lib().dpe_acq_results(self._h, res, _stream(stream)))
         return [dict(prn=r.prn, found=bool(r.found), max_code_idx=r.maxCodeIdx, max_dopp_idx=r.maxDoppIdx, rc=r.rc, fc=r.fc,
                      fi=r.fi, cppr=r.cppr, cppm=r.cppm, peak=r.peak) for r in res]
+
+    def fine(self, Samples, coarse, stream=None):
+        """Correlator.fine_frequency_acquisition (correlator.py:105-133) for every PRN, from `coarse` = results()."""
+        res = (AcqResult * len(self.prns))()
+        for r, c in zip(res, coarse):
+            r.prn, r.rc, r.fc, r.fi = c["prn"], c["rc"], c["fc"], c["fi"]
+        out = (AcqFineResult * len(self.prns))()
+        _check(lib().dpe_acq_fine(self._h, _ptr(Samples), res, out, _stream(stream)))
+        return [dict(prn=r.prn, max_carr_idx=r.maxCarrIdx, rc=r.rc, ri=r.ri, fc=r.fc, fi=r.fi,
+                     peak=complex(r.peakRe, r.peakIm)) for r in out]
+
+    def search_signal(self, Samples, stream=None):
+        """Correlator.search_signal (correlator.py:38-51): coarse then fine; one dict per PRN."""
+        self.search(Samples, stream)
+        coarse = self.results(stream)
+        fine = self.fine(Samples, coarse, stream)
+        return [dict(found=c["found"], rc=f["rc"], ri=f["ri"], fc=f["fc"], fi=f["fi"], cppr=c["cppr"], cppm=c["cppm"],
+                     max_carr_idx=f["max_carr_idx"], max_code_idx=c["max_code_idx"], max_dopp_idx=c["max_dopp_idx"])
+                for c, f in zip(coarse, fine)]
+
+    def scalar_acquisition(self, Window0, Window1, stream=None):
+        """Receiver.scalar_acquisition (receiver.py:452-520) on two consecutive windows (device buffers)."""
+        out = (AcqTrackInit * len(self.prns))()
+        _check(lib().dpe_acq_scalar_acquisition(self._h, _ptr(Window0), _ptr(Window1), out, _stream(stream)))
+        return [dict(prn=r.prn, found=bool(r.found), from_second_window=bool(r.fromSecondWindow), rc=r.rc, ri=r.ri, fc=r.fc,
+                     fi=r.fi, cppr=r.cppr, cppm=r.cppm, cppm_window=(r.cppmWindow[0], r.cppmWindow[1])) for r in out]
 
     def read_surface(self, stream=None):
         n = len(self.prns) * self.bins.size * self.M

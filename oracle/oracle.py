@@ -344,3 +344,57 @@ def coarse_acquisition(iq, fs, prn, bins, coherent=True, mode=None, doppler_sign
     cppm = peak / trim_mean(mp, 10)
     return dict(surface=res_abs, max_code_idx=max_code_idx, max_dopp_idx=max_dopp_idx, rc=rc, fi=fi, fc=fc,
                 cppr=cppr, cppm=cppm, found=bool(cppm > 2.0), max_percode=max_percode)
+
+
+def fine_fft_len(S):
+    """rawfile.carr_fftpts (rawfile.py:173): 8 * (1 << S.bit_length()) -- NOT BatchCorrScores' 8 * 2^ceil(log2 S)
+    (they differ when S is a power of two)."""
+    return 8 * (1 << int(S).bit_length())
+
+
+def fine_frequency_acquisition(iq, fs, prn, rc, fc, bins, doppler_sign=1.0):
+    """numpy restatement of Correlator.fine_frequency_acquisition (correlator.py:105-133): code wipe-off with
+    the coarse (rc, fc), zero-padded FFT, peak inside [min(bins), max(bins)] -> ri (cycles), fi, fc."""
+    iq = np.asarray(iq, dtype=np.int16)
+    S = iq.size // 2
+    raw = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    t = np.arange(S) / fs
+    chips = ca_code(prn).astype(np.float64)
+    rep = chips[np.mod(np.floor(t * fc + rc), L_CA).astype(np.int64)]          # :114-115
+    carr = (raw - np.mean(raw)) * rep                                          # :118
+    C = fine_fft_len(S)
+    X = np.fft.fftshift(np.fft.fft(carr, C))                                   # :121
+    fidc = np.fft.fftshift(np.fft.fftfreq(n=C, d=1.0 / fs))                    # rawfile.py:174
+    bins = np.asarray(bins, dtype=np.float64)
+    X[fidc < bins.min()] = 0.0                                                 # :124-125
+    X[fidc > bins.max()] = 0.0
+    idx = int(np.abs(X).argmax())
+    ri = np.angle(X[idx]) / (2.0 * CONST_PI)
+    fi = fidc[idx]
+    return dict(rc=rc, ri=ri, fc=F_CA + (doppler_sign * F_CA / F_L1) * fi, fi=fi, max_carr_idx=idx, peak=X[idx], C=C)
+
+
+def search_signal(iq, fs, prn, bins=None, coherent=True, doppler_sign=1.0):
+    """Correlator.search_signal (correlator.py:38-51): coarse, then fine frequency."""
+    bins = acq_bins(coherent) if bins is None else bins
+    c = coarse_acquisition(iq, fs, prn, bins, coherent=coherent, doppler_sign=doppler_sign)
+    f = fine_frequency_acquisition(iq, fs, prn, c["rc"], c["fc"], bins, doppler_sign)
+    return dict(found=c["found"], rc=f["rc"], ri=f["ri"], fc=f["fc"], fi=f["fi"], cppr=c["cppr"], cppm=c["cppm"],
+                max_carr_idx=f["max_carr_idx"], max_code_idx=c["max_code_idx"], max_dopp_idx=c["max_dopp_idx"])
+
+
+def scalar_acquisition(iq_two_windows, fs, prn_list, doppler_sign=1.0):
+    """Receiver.scalar_acquisition (receiver.py:452-520): search two consecutive windows, keep the one with the
+    larger cppm; a second-window hit is propagated back by one window (rc - fc T, ri - fi T).  Returns
+    (per_window [2][P] dicts, final [P] (rc, ri, fc, fi)) -- parameters at the start of the FIRST window."""
+    iq = np.asarray(iq_two_windows, dtype=np.int16)
+    S = iq.size // 4
+    T = S / fs
+    wins = [[search_signal(iq[2 * S * w:2 * S * (w + 1)], fs, p, doppler_sign=doppler_sign) for p in prn_list] for w in range(2)]
+    final = []
+    for a, b in zip(*wins):
+        if b["cppm"] > a["cppm"]:                                              # :493-498
+            final.append((np.mod(b["rc"] - b["fc"] * T, L_CA), np.mod(b["ri"] - b["fi"] * T, 1.0), b["fc"], b["fi"]))
+        else:                                                                  # :507
+            final.append((a["rc"], a["ri"], a["fc"], a["fi"]))
+    return wins, np.array(final)

@@ -17,6 +17,8 @@ reference callables that the CUDA authors used as their oracle (SURVEY.md sectio
   O6 NavigationGuesses.generate_spread_grid      receiver.py:995-1026
   O7 Receiver.dp_track internals (one iteration) receiver.py:205-397, channel.py:194-245
   O8 Correlator.coarse_acquisition               correlator.py:53-103
+  O9 Correlator.search_signal (coarse + fine_frequency_acquisition) on two consecutive windows and
+     Receiver.scalar_acquisition's keep-the-better rule   correlator.py:38-51,105-133; receiver.py:452-520
 
 Only DATA (inputs + expected outputs) is written; no reference source is copied into the
 repo.  The two harness adaptations below are marked HARNESS and do not touch arithmetic.
@@ -75,8 +77,61 @@ def open_rawfile(pg, path, fs, T):
     return rf
 
 
+def make_o9(pg):
+    """O9: the reference's own two-window acquisition driver on 20 ms of seeded synthetic samples."""
+    fs, T = 2.5e6, 0.01
+    S = int(round(fs * T))
+    ch = dpe.synth.random_channels(9, 4, prns=[3, 11, 22, 31])
+    ch["fi"] = np.array([-3671.0, 842.0, 2955.0, -120.0])
+    ch["fc"] = 1.023e6 * (1.0 + ch["fi"] / 1.57542e9)
+    ch["cp_ref"] = ch["cp"].copy()
+    iq = dpe.synth.gen_iq(47, fs, 2 * S, ch, amp=np.array([110.0, 70.0, 140.0, 95.0]), flip=np.zeros(4, dtype=bool))
+    path = os.path.join(SCRATCH, "o9.dat")
+    iq.tofile(path)
+    rf = open_rawfile(pg, path, fs, T)
+
+    class Py2Int(int):           # HARNESS: Python-2 "int / int" floors (correlator.py:78 reshapes by S/N)
+        def __truediv__(self, other):
+            return int(self) // other
+    orig = rf.set_rawsnippet_settings
+
+    def settings(T, T_big, verbose=True):   # HARNESS: keep S an int that floors under "/" after every re-setting
+        orig(T=T, T_big=T_big, verbose=False)
+        rf.S = Py2Int(rf.S)
+    rf.set_rawsnippet_settings = settings
+    prn_list = [3, 11, 22, 31, 7, 26]                               # four present, two absent
+    # per-window outputs of search_signal (coarse + fine), the two windows scalar_acquisition reads
+    rf.set_rawsnippet_settings(T=T, T_big=T)
+    per_window = []
+    for w in range(2):
+        rf.update_rawsnippet()
+        rows = []
+        for prn in prn_list:
+            cor = pg.correlator.Correlator(prn)
+            _, found, rc, ri, fc, fi, cppr, cppm = cor.search_signal(rf)
+            rows.append([float(found), rc, ri, fc, fi, cppr, cppm])
+        per_window.append(rows)
+    rf.seek_rawfile(-2 * int(rf.S))
+    # the driver itself
+    rx = pg.receiver.Receiver(rf, mcount_max=16)
+    rx.add_channels(prn_list)
+    rx.scalar_acquisition(prn_list, T=T)
+    mc = rx._mcount
+    final = np.array([[rx.channels[p].rc[mc], rx.channels[p].ri[mc], rx.channels[p].fc[mc], rx.channels[p].fi[mc]]
+                      for p in prn_list])
+    np.savez_compressed(os.path.join(HERE, "o9_scalar_acquisition.npz"), iq=iq, fs=fs, T=T, S=S,
+                        prn_list=np.array(prn_list), per_window=np.array(per_window), final=final,
+                        carr_fftpts=int(rf.carr_fftpts),
+                        bins=np.asarray(pg.correlator.DOPPLER_SEARCH_MATRIX_COHERENT).ravel(),
+                        truth_prn=ch["prn"], truth_rc=ch["rc"], truth_fi=ch["fi"], truth_ri=ch["ri"])
+    rf.close_rawfile()
+
+
 def main():
     pg = import_pygnss()
+    if "--only-o9" in sys.argv:
+        make_o9(pg)
+        return
     ho = dpe.handoff.read_handoff(os.path.join(REF, "demofiles", "handoff_params_usrp6.csv"))
     prns = [int(p) for p in ho["prn_list"]]
     K = len(prns)
@@ -222,6 +277,7 @@ def main():
                         **{"c%d_%s" % (i, k): np.asarray(v) for i, c in enumerate(cases) for k, v in c.items()},
                         ncases=len(cases))
     rf.close_rawfile()
+    make_o9(pg)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -78,3 +78,39 @@ def test_acq_32_prns_full_search():
             d = (r["rc"] - ch["rc"][k] + 511.5) % 1023 - 511.5
             assert abs(d) < 0.5 and abs(r["fi"] - ch["fi"][k]) < 100.0   # within one 100 Hz bin
     acq.close()
+
+
+@pytest.mark.gpu
+def test_o9_fine_frequency_and_two_window_driver(golden):
+    """HIP search_signal (coarse + fine frequency) and the two-window driver against the reference's own
+    outputs (fixture O9) and against the oracle.  The fine stage runs a 262144-point fp32 FFT: the peak bin
+    must be the reference's, ri within 2e-5 cycles, fi / fc exact functions of the bin."""
+    import torch
+    from oracle import oracle as o
+    g = golden("o9_scalar_acquisition")
+    fs, S = float(g["fs"]), int(g["S"])
+    prns = [int(p) for p in g["prn_list"]]
+    iq = np.ascontiguousarray(g["iq"])
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+    w0, w1 = iq_d[:2 * S], iq_d[2 * S:]
+    acq = dpe.Acquisition(fs, S, prns, g["bins"], mode="coherent")
+    ref = g["per_window"]                               # [2][P][found, rc, ri, fc, fi, cppr, cppm]
+    for w, buf in enumerate((w0, w1)):
+        got = acq.search_signal(buf)
+        for i, r in enumerate(got):
+            assert r["found"] == bool(ref[w, i, 0])
+            assert abs(r["rc"] - ref[w, i, 1]) < 1e-9
+            assert abs(r["fi"] - ref[w, i, 4]) < 1e-9 and abs(r["fc"] - ref[w, i, 3]) < 1e-6      # same FFT bin
+            d = abs(r["ri"] - ref[w, i, 2])
+            assert min(d, 1.0 - d) < 2e-5
+            assert abs(r["cppr"] / ref[w, i, 5] - 1) < 2e-4 and abs(r["cppm"] / ref[w, i, 6] - 1) < 2e-4
+            orc = o.search_signal(iq[2 * S * w:2 * S * (w + 1)], fs, prns[i])
+            assert orc["max_carr_idx"] == r["max_carr_idx"]
+    fin = acq.scalar_acquisition(w0, w1)
+    for i, r in enumerate(fin):
+        assert r["from_second_window"] == bool(ref[1, i, 6] > ref[0, i, 6])
+        assert abs(r["rc"] - g["final"][i, 0]) < 1e-6 and abs(r["fc"] - g["final"][i, 2]) < 1e-6
+        assert abs(r["fi"] - g["final"][i, 3]) < 1e-9
+        d = abs(r["ri"] - g["final"][i, 1])
+        assert min(d, 1.0 - d) < 2e-5
+    acq.close()
