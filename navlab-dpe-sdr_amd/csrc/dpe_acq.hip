@@ -38,6 +38,33 @@ __global__ __launch_bounds__(256) void acq_wipe_kernel(const int16_t *__restrict
     }
 }
 
+// Coherent mode: X[b][j] = sum_n raw[j + n M] exp(-j 2 pi f_b (j + n M) / fs), j < M.  Summing the N lag aliases
+// of a length-S circular correlation (correlator.py:77-80) equals a length-M circular correlation of the
+// time-folded inputs (sampling the product spectrum at every N-th bin), so the coherent search runs
+// length-M transforms on folded data: N times less FFT work and memory than the literal formulation.
+__global__ __launch_bounds__(256) void acq_wipe_fold_kernel(const int16_t *__restrict__ iq, int M, int N, double binStart,
+                                                            double binStep, double invFs, float2 *__restrict__ X)
+{
+    const int b = blockIdx.y;
+    const double cyclesPerSample = (binStart + binStep * b) * invFs;
+    const int *x = reinterpret_cast<const int *>(iq);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+        float ar = 0.f, ai = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const int i = j + n * M;
+            const int v = x[i];
+            const float re = (float)(short)(v & 0xFFFF), im = (float)(v >> 16);
+            double ph = cyclesPerSample * (double)i;
+            ph -= floor(ph);
+            const float f = (float)ph;
+            const float c = __builtin_amdgcn_cosf(f), s = -__builtin_amdgcn_sinf(f);
+            ar += re * c - im * s;
+            ai += re * s + im * c;
+        }
+        X[(size_t)b * M + j] = make_float2(ar, ai);
+    }
+}
+
 // Rc = conj(FFT(replica)) / len   (correlator.py:67; the 1/len is numpy's ifft normalisation)
 __global__ void acq_conj_scale_kernel(float2 *__restrict__ R, long long n, float scale)
 {
@@ -85,6 +112,55 @@ __global__ __launch_bounds__(256) void acq_colmax_kernel(const float *__restrict
         float m = 0.f;
         for (int b = 0; b < B; ++b) m = fmaxf(m, surf[((size_t)p * B + b) * M + j]);
         mp[(size_t)p * M + j] = m;
+    }
+}
+
+// per PRN: max_code_idx = first maximum of max_percode, max_dopp_idx = first maximum of that column (:88-89)
+__global__ __launch_bounds__(256) void acq_peak_kernel(const float *__restrict__ surf, const float *__restrict__ mp, int B, int M,
+                                                       int *__restrict__ codeIdx, int *__restrict__ doppIdx)
+{
+    const int p = blockIdx.x;
+    unsigned long long best = 0ull;
+    for (int j = threadIdx.x; j < M; j += 256) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(mp[(size_t)p * M + j]) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+        best = key > best ? key : best;
+    }
+    __shared__ unsigned long long sB[4];
+    __shared__ int sCi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) sB[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = sB[0];
+        for (int q = 1; q < 4; ++q) b = sB[q] > b ? sB[q] : b;
+        sCi = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+        codeIdx[p] = sCi;
+    }
+    __syncthreads();
+    const int ci = sCi;
+    best = 0ull;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(surf[((size_t)p * B + b) * M + ci]) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)b);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sB[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = sB[0];
+        for (int q = 1; q < 4; ++q) b = sB[q] > b ? sB[q] : b;
+        doppIdx[p] = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
     }
 }
 
@@ -176,11 +252,13 @@ __global__ __launch_bounds__(256) void acq_fine_peak_kernel(const float2 *__rest
 
 struct dpe_acq {
     dpe_acq_config cfg;
-    int S, N, M, B, P, len, chunk;   // len = FFT length (S, or M in mode 2)
+    int S, N, M, B, P, len, chunk;   // len = FFT length (S in mode 1; M in modes 0 and 2)
+    int SX;                          // samples per Doppler row after the wipe-off (M in mode 0: time-folded)
     hipfftHandle planFwd = 0, planInv = 0;
     bool haveFwd = false, haveInv = false;
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
     float *surf_d = nullptr, *mp_d = nullptr;
+    int *peakIdx_d = nullptr;   // [2][P]: max_code_idx, max_dopp_idx
     bool searched = false;
     // fine-frequency stage, allocated on first use
     int fineC = 0, fineLo = 0, fineHi = -1;
@@ -210,7 +288,7 @@ int dpe_acq_destroy(dpe_acq *h)
     if (h->haveFwd) hipfftDestroy(h->planFwd);
     if (h->haveInv) hipfftDestroy(h->planInv);
     if (h->haveFine) hipfftDestroy(h->planFine);
-    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d};
+    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d};
     for (void *b : bufs) (void)hipFree(b);
     delete h;
     return 0;
@@ -230,15 +308,17 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     dpe_acq *h = new dpe_acq();
     h->cfg = *cfg;
     h->S = cfg->samplesPerWindow; h->N = cfg->nCodePeriods; h->M = h->S / h->N; h->B = cfg->nBins; h->P = cfg->nPrn;
-    h->len = (cfg->mode == 2) ? h->M : h->S;
+    h->len = (cfg->mode == 1) ? h->S : h->M;
+    h->SX = (cfg->mode == 0) ? h->M : h->S;
     h->chunk = cfg->prnChunk > 0 ? std::min(cfg->prnChunk, h->P) : std::min(8, h->P);
-    const size_t S = h->S, B = h->B, P = h->P;
+    const size_t S = h->SX, B = h->B, P = h->P;
     h->X_d = dev_alloc<float2>(B * S);
     h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
     h->Y_d = dev_alloc<float2>((size_t)h->chunk * B * S);
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
-    if (!h->X_d || !h->Rc_d || !h->Y_d || !h->surf_d || !h->mp_d) {
+    h->peakIdx_d = dev_alloc<int>(2 * P);
+    if (!h->X_d || !h->Rc_d || !h->Y_d || !h->surf_d || !h->mp_d || !h->peakIdx_d) {
         set_error("[Acquisition] create: device allocation failed");
         dpe_acq_destroy(h);
         return -1;
@@ -263,9 +343,14 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     for (size_t p = 0; p < P; ++p) {
         gen_ca_code_host(cfg->prn[p], chips);
         for (int i = 0; i < h->len; ++i) {
-            const double t = (double)i / cfg->samplingFrequency;
-            const long long ci = (long long)std::floor(t * kFCA);
-            rep[p * h->len + i] = make_float2((float)chips[ci % kLCA], 0.f);
+            // mode 0: the replica folded over the N code periods of the window (see acq_wipe_fold_kernel)
+            double acc = 0.0;
+            for (int n = 0; n < (cfg->mode == 0 ? h->N : 1); ++n) {
+                const double t = (double)(i + n * h->M) / cfg->samplingFrequency;
+                const long long ci = (long long)std::floor(t * kFCA);
+                acc += (double)chips[ci % kLCA];
+            }
+            rep[p * h->len + i] = make_float2((float)acc, 0.f);
         }
     }
     DPE_CHECK_HIP(hipMemcpy(h->Rc_d, rep.data(), sizeof(float2) * rep.size(), hipMemcpyHostToDevice));
@@ -288,9 +373,13 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     hipStream_t st = (hipStream_t)stream_;
     DPE_CHECK_FFT(hipfftSetStream(h->planFwd, st));
     DPE_CHECK_FFT(hipfftSetStream(h->planInv, st));
-    const int S = h->S, B = h->B, P = h->P, M = h->M;
-    hipLaunchKernelGGL(acq_wipe_kernel, dim3((S + 1023) / 1024, B), dim3(256), 0, st, samples_dev, S, B, h->cfg.binStartHz,
-                       h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d);
+    const int S = h->SX, B = h->B, P = h->P, M = h->M;
+    if (h->cfg.mode == 0)
+        hipLaunchKernelGGL(acq_wipe_fold_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, samples_dev, M, h->N,
+                           h->cfg.binStartHz, h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d);
+    else
+        hipLaunchKernelGGL(acq_wipe_kernel, dim3((S + 1023) / 1024, B), dim3(256), 0, st, samples_dev, S, B, h->cfg.binStartHz,
+                           h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d);
     DPE_CHECK_FFT(hipfftExecC2C(h->planFwd, (hipfftComplex *)h->X_d, (hipfftComplex *)h->X_d, HIPFFT_FORWARD));
     for (int p0 = 0; p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
@@ -298,21 +387,28 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                            h->Rc_d + (size_t)p0 * h->len, S, h->len, B, h->Y_d);
         // a short last chunk still runs the full-batch plan over stale rows; they are never read
         DPE_CHECK_FFT(hipfftExecC2C(h->planInv, (hipfftComplex *)h->Y_d, (hipfftComplex *)h->Y_d, HIPFFT_BACKWARD));
-        hipLaunchKernelGGL(acq_fold_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->Y_d, S, M, h->N,
-                           h->cfg.mode == 0 ? 1 : 0, h->surf_d + (size_t)p0 * B * M);
+        // mode 0 arrives already folded: one term, |.|
+        hipLaunchKernelGGL(acq_fold_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->Y_d, S, M,
+                           h->cfg.mode == 0 ? 1 : h->N, h->cfg.mode == 0 ? 1 : 0, h->surf_d + (size_t)p0 * B * M);
     }
     hipLaunchKernelGGL(acq_colmax_kernel, dim3((M + 255) / 256, P), dim3(256), 0, st, h->surf_d, B, M, h->mp_d);
+    hipLaunchKernelGGL(acq_peak_kernel, dim3(P), dim3(256), 0, st, h->surf_d, h->mp_d, B, M, h->peakIdx_d, h->peakIdx_d + P);
     DPE_CHECK_HIP(hipGetLastError());
     h->searched = true;
     return 0;
 }
 
-static double percentile_sorted(const std::vector<float> &a, double q)   // numpy/scipy linear interpolation
+// numpy/scipy percentile with linear interpolation, by selection (reorders a; O(n) instead of a sort)
+static double percentile_select(std::vector<float> &a, double q)
 {
     const double pos = (a.size() - 1) * q / 100.0;
     const size_t i = (size_t)std::floor(pos);
     const double f = pos - (double)i;
-    return (i + 1 < a.size()) ? a[i] + (a[i + 1] - a[i]) * f : a[i];
+    std::nth_element(a.begin(), a.begin() + i, a.end());
+    const float lo = a[i];
+    if (i + 1 >= a.size()) return lo;
+    const float hi = *std::min_element(a.begin() + i + 1, a.end());
+    return lo + (hi - lo) * f;
 }
 
 int dpe_acq_results(dpe_acq *h, dpe_acq_result *out, dpe_stream_t stream)
@@ -321,15 +417,14 @@ int dpe_acq_results(dpe_acq *h, dpe_acq_result *out, dpe_stream_t stream)
     DPE_REQUIRE(h && out && h->searched, "[Acquisition] results: no search yet");
     DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int M = h->M, B = h->B, P = h->P;
-    std::vector<float> mp((size_t)P * M), col(B);
+    std::vector<float> mp((size_t)P * M);
+    std::vector<int> pk(2 * (size_t)P);
     DPE_CHECK_HIP(hipMemcpy(mp.data(), h->mp_d, sizeof(float) * mp.size(), hipMemcpyDeviceToHost));
+    DPE_CHECK_HIP(hipMemcpy(pk.data(), h->peakIdx_d, sizeof(int) * pk.size(), hipMemcpyDeviceToHost));
     const double fs = h->cfg.samplingFrequency;
     for (int p = 0; p < P; ++p) {
         float *m = mp.data() + (size_t)p * M;
-        const int ci = (int)(std::max_element(m, m + M) - m);                      // first maximum, correlator.py:88
-        for (int b = 0; b < B; ++b)
-            DPE_CHECK_HIP(hipMemcpy(&col[b], h->surf_d + ((size_t)p * B + b) * M + ci, sizeof(float), hipMemcpyDeviceToHost));
-        const int di = (int)(std::max_element(col.begin(), col.end()) - col.begin());   // :89
+        const int ci = pk[p], di = pk[P + p];                                      // first maxima, correlator.py:88-89
         dpe_acq_result &r = out[p];
         r.prn = h->cfg.prn[p];
         r.maxCodeIdx = ci; r.maxDoppIdx = di;
@@ -341,8 +436,7 @@ int dpe_acq_results(dpe_acq *h, dpe_acq_result *out, dpe_stream_t stream)
         std::vector<float> a(m, m + M);
         for (int d = -maskS; d <= maskS; ++d) a[((ci + d) % M + M) % M] = 0.f;
         r.cppr = r.peak / *std::max_element(a.begin(), a.end());                   // :100
-        std::sort(a.begin(), a.end());
-        const double lo = percentile_sorted(a, 5.0), hi = percentile_sorted(a, 95.0);   // _trim_mean :546-564
+        const double lo = percentile_select(a, 5.0), hi = percentile_select(a, 95.0);   // _trim_mean :546-564
         double sum = 0;
         long long cnt = 0;
         for (float v : a)
