@@ -309,6 +309,190 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
 }
 
 // ------------------------------------------------------------------------------------------
+// Batch variant of bcs_bank_kernel for narrow lag windows (LH <= 8): one wave pass covers 1024 consecutive
+// samples, each lane 16 of them, so that a DPP row (16 lanes) is exactly one 256-sample moment sub-tile.
+// The arithmetic per sample is the dense kernel's; what changes is the amortisation -- index arithmetic,
+// carrier-phase seeds (two per lane, so a rotation chain is never longer than 7 steps), side bookkeeping and the
+// cross-lane moment sums (4 row-local DPP steps per 4 sub-tiles instead of 6 wave steps per sub-tile) are paid
+// once per 16 samples instead of once per 4.  Used when the batch offers enough passes to fill the chip
+// (dpe_bcs_update); single windows keep the 4-samples-per-lane kernel, whose blocks are 4x shorter.
+// Same partial / moment layouts, so bcs_finalize_kernel is shared.
+template <int LH, int kNMom, bool TABLE>
+__global__ __launch_bounds__(256) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
+                                                         int S, int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
+                                                         const BcsChanDev *__restrict__ chan,
+                                                         const long long *__restrict__ sums,
+                                                         const int8_t *__restrict__ chipTable,
+                                                         const double *__restrict__ tT,
+                                                         float2 *__restrict__ part, float2 *__restrict__ mom)
+{
+    constexpr int NL = 2 * LH + 1;       // lags
+    constexpr int kPass = 1024;          // samples per wave pass
+    constexpr int NREP = kPass + 2 * LH;  // replica entries per pass (with halo)
+    constexpr int NRR = 16 + 2 * LH;     // entries one lane touches
+    static_assert((8 + 2 * LH) % 4 == 0 && LH <= 8, "a segment's replica window is read as float4s");
+    __shared__ float sChips[2048];   // chips as +/-1.0f, periodically extended: sChips[i] = chip[i mod 1023]
+    __shared__ __align__(16) float sRep[4][NREP + 8];
+    __shared__ float2 sAcc[4][NL];
+
+    const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    (void)pb;
+    const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
+    for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
+    const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;   // chip span of one pass fits the extended table
+    float mRe, mIm;
+    window_mean(sums, w, nSumBlk, S, mRe, mIm);
+    const int16_t *x = iq + (size_t)w * winStride * 2;
+    const float xbase = (float)(16 * (lane & 15)) - 127.5f;      // moment abscissa of the lane's first sample
+    __syncthreads();
+
+    for (int side = 0; side < 2; ++side) {
+        f2 acc[NL];   // (re, im) pairs: packed fp32 FMAs against the real replica
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[j] = f2{0.f, 0.f};
+
+        for (int t = 0; t < tilesPerBlock; ++t) {
+            const int pass = (blk * tilesPerBlock + t) * 4 + wave;
+            const int c0 = pass * kPass;
+            const int lo = c0 - LH, hi = c0 + kPass - 1 + LH;
+            bool active = c0 < S;
+            if (active) {
+                if (!ch.hasFlip) active = (side == 0);
+                else if (lo >= 0 && hi < S) active = (side == 0) ? (lo < ch.idxNext) : (hi >= ch.idxNext);
+            }
+            const int n0 = c0 + 16 * lane;
+            if (active) {
+                // replica r[m] = chip[floor(t_m fc + rc) mod 1023] (BCS_ComputeCodeReplica :347-349), masked to this
+                // side of the nav-bit boundary (:352-367), m wrapped circularly -- as in bcs_bank_kernel
+                if (fastIdx && lo >= 0 && hi < S) {
+                    const int ci0 = (int)floor(code_phase<TABLE>(ch, tT, lo));
+                    const int shift = (ci0 % kLCA) - ci0;
+                    const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
+                    for (int e = lane; e < NREP; e += 64) {
+                        const int m = lo + e;
+                        const int ci = (int)floor(code_phase<TABLE>(ch, tT, m)) + shift;
+                        float r = sChips[ci];
+                        if (straddle) r = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
+                        sRep[wave][e] = r;
+                    }
+                } else {
+                    for (int e = lane; e < NREP; e += 64) {
+                        int m = lo + e;
+                        if (m < 0) m += S; else if (m >= S) m -= S;
+                        const double cph = code_phase<TABLE>(ch, tT, m);
+                        const int ci = ((int)floor(cph)) % kLCA;
+                        const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
+                        sRep[wave][e] = (sd == side) ? sChips[ci] : 0.f;
+                    }
+                }
+            }
+            // no barrier: sRep[wave] is private to this wave and a wave's DS operations complete in order
+            f2 M[kNMom];
+#pragma unroll
+            for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
+            if (active) {
+                // two segments of 8 samples, deliberately NOT unrolled: the live set stays at one segment's
+                // samples and replica window (occupancy), and each segment re-seeds the carrier phase
+#pragma unroll 1
+                for (int seg = 0; seg < 2; ++seg) {
+                    const int ns = n0 + 8 * seg;
+                    int raw[8];   // packed I/Q
+                    if (vecOK && ns + 7 < S) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int4 v = *reinterpret_cast<const int4 *>(x + 2 * (size_t)(ns + 4 * q));
+                            raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) raw[i] = (ns + i < S) ? *reinterpret_cast<const int *>(x + 2 * (size_t)(ns + i)) : 0;
+                    }
+                    float rr[8 + 2 * LH];
+#pragma unroll
+                    for (int q = 0; q < (8 + 2 * LH) / 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(&sRep[wave][16 * lane + 8 * seg + 4 * q]);
+                        rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
+                    }
+                    // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300): fp64 phase
+                    // seed, hardware sin/cos in revolutions, then 7 fp32 rotations
+                    double ph = carr_phase<TABLE>(ch, tT, ns < S ? ns : S - 1);   // lanes past the window carry zero samples
+                    ph -= floor(ph);
+                    const float f = (float)ph;
+                    float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
+                    const float xs = xbase + (float)(8 * seg);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float re = (float)(short)(raw[i] & 0xFFFF), im = (float)(raw[i] >> 16);
+                        // rawWiped = raw * wipe (BCS_BatchMultiply :402)
+                        const float br = re * wr - im * wi;
+                        const float bi = re * wi + im * wr;
+                        // sample n, lag l = j-LH uses replica index n-l -> rr[i - j + 2 LH]
+                        const f2 bb = f2{br, bi};
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) {
+                            const float r = rr[i + 2 * LH - j];
+                            acc[j] = __builtin_elementwise_fma(bb, f2{r, r}, acc[j]);
+                        }
+                        // carrier path: (raw - mean) * wipe * replica (:480, :440-448)
+                        const float r0 = (ns + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
+                        const float cr = (br - (mRe * wr - mIm * wi)) * r0;
+                        const float cim = (bi - (mRe * wi + mIm * wr)) * r0;
+                        f2 cp = f2{cr, cim};   // x^p * c, built up by one packed multiply per order
+                        const float xp = xs + (float)i;
+#pragma unroll
+                        for (int p = 0; p < kNMom; ++p) {
+                            M[p] += cp;
+                            cp *= xp;
+                        }
+                        const float nr = wr * ch.rotRe - wi * ch.rotIm;
+                        wi = wr * ch.rotIm + wi * ch.rotRe;
+                        wr = nr;
+                    }
+                }
+            }
+            {
+                // one moment set per DPP row = per 256-sample sub-tile
+                const int sub = pass * 4 + (lane >> 4);
+                float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
+                if (active) {
+                    float mm[2 * kNMom];
+#pragma unroll
+                    for (int p = 0; p < kNMom; ++p) { mm[2 * p] = M[p].x; mm[2 * p + 1] = M[p].y; }
+                    dpp_sum_rows(mm);
+                    if (sub < nSub && (lane & 15) == 15) {
+#pragma unroll
+                        for (int p = 0; p < kNMom; ++p) o[p] = make_float2(mm[2 * p], mm[2 * p + 1]);
+                    }
+                } else if (sub < nSub && (lane & 15) < kNMom) {
+                    o[lane & 15] = make_float2(0.f, 0.f);
+                }
+            }
+        }
+        // block partial of the lag sums, fixed reduction order
+        {
+            float aa[2 * NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { aa[2 * j] = acc[j].x; aa[2 * j + 1] = acc[j].y; }
+            dpp_sum_lane63(aa);
+            if (lane == 63) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) sAcc[wave][j] = make_float2(aa[2 * j], aa[2 * j + 1]);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < NL; j += 256) {
+            float2 s = sAcc[0][j];
+            s.x += sAcc[1][j].x; s.y += sAcc[1][j].y;
+            s.x += sAcc[2][j].x; s.y += sAcc[2][j].y;
+            s.x += sAcc[3][j].x; s.y += sAcc[3][j].y;
+            part[((((size_t)w * K + k) * nBlk + blk) * 2 + side) * NL + j] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Wide lag windows (|lag| <= 32, i.e. high sampling rates where a chip spans many samples): instead of
 // 65 dense multiply-accumulates per sample, use that the replica is piecewise constant:
 //     corr[l+1] - corr[l] = sum_m J[m] b[(m + l) mod S],   J[m] = r[m-1] - r[m]
@@ -680,7 +864,8 @@ struct dpe_bcs {
     dpe_bcs_config cfg;
     int LH;             // internal lag half width (4,8,16,32)
     int nSub, nBlk, tilesPerBlock, nMom;
-    bool wideAllowed = true;   // dpe_bcs_set_option("wide", 0) forces the dense kernel (A/B tests)
+    bool wideAllowed = true;     // DPE_BCS_NO_WIDE=1 in the environment at create: dense kernel only (A/B tests)
+    bool bank16Allowed = true;   // DPE_BCS_NO_BANK16=1: never the 16-samples-per-lane batch kernel (A/B tests)
     long long C;
     int8_t *chipTable_d = nullptr;
     double *tTable_d = nullptr;   // ns-rounded sample times (always allocated; used only when useTable)
@@ -781,6 +966,8 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
     DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
     h->idxNext_h.assign(W * K, 0);
+    h->wideAllowed = getenv("DPE_BCS_NO_WIDE") == nullptr;
+    h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
     *out = h;
     return 0;
 }
@@ -838,7 +1025,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->lastSumBlocks = sumBlocks;
     if (useGraph) {
         const int rc = h->graphs.begin({samples_dev, nullptr, (long long)windowStrideSamples, nWindows, nChan,
-                                        h->wideAllowed ? 1 : 0, stream}, stream);
+                                        (h->wideAllowed ? 1 : 0) | (h->bank16Allowed ? 2 : 0), stream}, stream);
         DPE_REQUIRE(rc >= 0, "[BatchCorrScores] Update: hipGraph capture/replay failed");
         if (rc == 1) return 0;
     }
@@ -855,10 +1042,26 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->prof.end(0, stream);
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     // tiles per block: amortise the end-of-block lag reduction while keeping >= ~4096 blocks in flight
-    const int nTiles = (h->nSub + 3) / 4;
-    int tpb = (int)(((long long)nTiles * nChan * nWindows) / 4096);
-    if (tpb < h->tilesPerBlock) tpb = h->tilesPerBlock;
-    if (tpb > 16) tpb = 16;
+    // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
+    // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else a dense kernel
+    const bool wide = h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
+    // narrow lag windows in batches: the 16-samples-per-lane kernel (tiles of 16 sub-tiles) once the batch
+    // offers >= 2048 of its tiles; fewer (a single window in particular) keep the short 4-sub-tile tiles
+    const int nTiles16 = (h->nSub + 15) / 16;
+    const bool use16 = !wide && h->LH <= 8 && h->bank16Allowed && (long long)nTiles16 * nChan * nWindows >= 2048;
+    const int nTiles = use16 ? nTiles16 : (h->nSub + 3) / 4;
+    int tpb;
+    if (use16) {
+        tpb = (int)(((long long)nTiles * nChan * nWindows) / 4096);
+        const int least = (nTiles + h->nBlk - 1) / h->nBlk;   // the partial buffer holds h->nBlk blocks per (window, SV)
+        if (tpb > 4) tpb = 4;
+        if (tpb < least) tpb = least;
+        if (tpb < 1) tpb = 1;
+    } else {
+        tpb = (int)(((long long)nTiles * nChan * nWindows) / 4096);
+        if (tpb < h->tilesPerBlock) tpb = h->tilesPerBlock;
+        if (tpb > 16) tpb = 16;
+    }
     const int nBlk = (nTiles + tpb - 1) / tpb;
     const dim3 grid(nBlk, nChan, nWindows), block(256);
 #define DPE_LAUNCH_BANK3(LHV, NM, TB)                                                                                   \
@@ -876,10 +1079,19 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         if (h->nMom == 4) DPE_LAUNCH_BANK2(LHV, 4); \
         else DPE_LAUNCH_BANK2(LHV, 6);  \
     } while (0)
-    // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
-    // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else the dense kernel
-    const bool wide = h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
-    if (wide) {
+    if (use16) {
+#define DPE_LAUNCH_B16(LHV, NM, TB)                                                                                    \
+    hipLaunchKernelGGL((bcs_bank16_kernel<LHV, NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
+#define DPE_LAUNCH_B16_2(LHV)                                                                           \
+    do {                                                                                                \
+        if (h->nMom == 4) { if (h->useTable) DPE_LAUNCH_B16(LHV, 4, true); else DPE_LAUNCH_B16(LHV, 4, false); } \
+        else { if (h->useTable) DPE_LAUNCH_B16(LHV, 6, true); else DPE_LAUNCH_B16(LHV, 6, false); }         \
+    } while (0)
+        if (h->LH == 4) DPE_LAUNCH_B16_2(4); else DPE_LAUNCH_B16_2(8);
+#undef DPE_LAUNCH_B16_2
+#undef DPE_LAUNCH_B16
+    } else if (wide) {
 #define DPE_LAUNCH_WIDE(NM, TB)                                                                                    \
     hipLaunchKernelGGL((bcs_bank_wide_kernel<NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)

@@ -75,6 +75,20 @@ __device__ __forceinline__ void dpp_sum_lane63(float (&v)[N])
 #undef DPE_DPP_STEP
 }
 
+// Sums within each DPP row (16 lanes): after the four row-local steps every lane of a row holds the row total.
+template <int N>
+__device__ __forceinline__ void dpp_sum_rows(float (&v)[N])
+{
+    static_assert(N >= 3, "the step-major interleave must cover the 2 wait states of a VALU->DPP hazard");
+#define DPE_DPP_STEP(mod) \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) asm volatile("v_add_f32_dpp %0, %0, %0 " mod : "+v"(v[i]));
+    DPE_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+    DPE_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+    DPE_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+    DPE_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+#undef DPE_DPP_STEP
+}
+
 // wave-uniform total of v (read back from lane 63)
 __device__ __forceinline__ float lane63(float v)
 {

@@ -427,3 +427,40 @@ def test_key_sets_stay_clean_across_changing_batch_sizes():
         assert got == update(b2, m2, n)
         m2.Stop(); b2.Stop()
     assert seq[0] == seq[2] == seq[4] and seq[1] == seq[0][:1] and seq[3] == seq[0][:2]
+
+
+@pytest.mark.parametrize("L,B,W", [(4, 20, 24), (8, 40, 24)])
+def test_batch_bank_kernel_matches_single_window_kernel(L, B, W):
+    """Batches large enough to fill the chip run stage 1 through bcs_bank16_kernel (16 samples per lane);
+    single windows use bcs_bank_kernel (4 per lane).  Same arithmetic per sample, different grouping of the
+    fp32 sums: banks agree to 1e-6 of the peak (each is within 3e-7 of the fp64 oracle, see the fixture
+    tests), DC mean / nav-bit index / replica choice are identical, and so is the fix.  S = 50000 is not a
+    multiple of the 1024-sample pass, every window holds a nav-bit edge, B = 40 selects the 6-moment variant."""
+    import torch
+    cfg = dpe.workload.CONFIG_R
+    iq, cs, ce, bw = dpe.workload.build_windows(W, cfg["fs"], cfg["S"], cfg["K"], seed=41, amp=cfg["amp"])
+    _, _, pos, vel, _ = dpe.workload.build_grids(6561)
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+
+    def run(wsel, maxw):
+        bcs = dpe.BatchCorrScores(cfg["fs"], samples_per_window=cfg["S"], lag_half_width=L, bin_half_width=B,
+                                  max_windows=maxw, max_channels=cfg["K"])
+        bcs.Start()
+        bcm = dpe.BatchCorrManifold(cfg["fs"], cfg["S"], bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B,
+                                    max_windows=maxw, max_channels=cfg["K"])
+        bcm.Start()
+        bcs.Update(iq_d[wsel], cs[wsel])
+        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw[wsel], ce[wsel])
+        res = bcm.results()
+        code, carr = bcs.read_banks()
+        info = bcs.read_info()
+        bcm.Stop(); bcs.Stop()
+        return code, carr, info, res
+
+    code, carr, info, res = run(slice(0, W), W)
+    for w in (0, 7, W - 1):
+        c1, f1, i1, r1 = run(slice(w, w + 1), 1)
+        assert np.abs(code[w] - c1[0]).max() <= 1e-6 * np.abs(c1[0]).max()
+        assert np.abs(carr[w] - f1[0]).max() <= 1e-6 * np.abs(f1[0]).max()
+        assert np.array_equal(info[0][w], i1[0][0]) and np.array_equal(info[1][w], i1[1][0]) and info[2][w] == i1[2][0]
+        assert res[w]["posIndex"] == r1[0]["posIndex"] and res[w]["velIndex"] == r1[0]["velIndex"]
