@@ -239,10 +239,19 @@ def main():
             out["pcie_inclusive_value"] = pcie_value
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
     bcm.Stop(); bcs.Stop()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes a version banner through C stdio on stdout; push it out first so that the JSON line is the
+    # last thing this process prints
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
