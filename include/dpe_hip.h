@@ -217,6 +217,24 @@ int dpe_chm_update(dpe_chanmgr *h, const double *xk1k1, const double *xkk1, cons
 int dpe_chm_outputs(dpe_chanmgr *h, dpe_chan_start *start, dpe_chan_end *end, dpe_bcm_window *win,
                     double *batchSatStates);
 
+/* ------------------------------------------------------------------ cuEKF ---- */
+/* The EnableEKF=true path of dsp::cuEKF (cudarecv/modules/src/cuekf.cu): 8-state Kalman filter, host fp64.
+ * The shipped flow disables it (dpeflow.cpp:90) and passes zVal through (EKF_PassMeas :147-159).
+ * All matrices ROW-major, 8 x 8. */
+typedef struct dpe_ekf dpe_ekf;
+typedef struct dpe_ekf_config {
+    double sampleLength;      /* T */
+    int32_t coupleVelocity;   /* 1: F = I + T on [i][i+4] (EKF_MakeDPERandomWalkFMatrix :111-143); 0: F = I (ekf.py:47) */
+    int32_t reserved;
+    double x0[8];             /* InitX */
+    double P0[64];            /* InitP (P_k-1|k-1; P_k|k-1 starts as I, cuekf.cu:464) */
+} dpe_ekf_config;
+int dpe_ekf_create(const dpe_ekf_config *cfg, dpe_ekf **out);
+int dpe_ekf_destroy(dpe_ekf *h);
+int dpe_ekf_step_update(dpe_ekf *h, const double *z /* [8] */, const double *R /* [64] */);   /* StepUpdate :660-721 */
+int dpe_ekf_step_predict(dpe_ekf *h);                                                        /* StepPredict :626-656 */
+int dpe_ekf_state(dpe_ekf *h, double *xk1k1, double *xkk1, double *Pk1k1, double *Pkk1, double *Q, double *K);
+
 /* ------------------------------------------------------------------ Acquisition ---- */
 /* Cold-start coarse acquisition.  Only the reference's Python twin implements it:
  * Correlator.coarse_acquisition, pygnss/pythonreceiver/scalar/correlator.py:53-103 (CUDARecv only

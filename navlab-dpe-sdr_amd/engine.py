@@ -25,6 +25,7 @@ EXPORTS = [
     "dpe_chm_update", "dpe_chm_outputs", "dpe_bcs_profile", "dpe_bcm_profile", "dpe_acq_create", "dpe_acq_destroy",
     "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface", "dpe_bcs_set_graph", "dpe_bcm_set_graph",
     "dpe_acq_fine", "dpe_acq_scalar_acquisition",
+    "dpe_ekf_create", "dpe_ekf_destroy", "dpe_ekf_step_update", "dpe_ekf_step_predict", "dpe_ekf_state",
 ]
 
 
@@ -535,6 +536,66 @@ class Acquisition:
             self._h = C.c_void_p(None)
 
     __del__ = close
+
+
+class EkfConfig(C.Structure):
+    _fields_ = [("sampleLength", C.c_double), ("coupleVelocity", C.c_int32), ("reserved", C.c_int32),
+                ("x0", C.c_double * 8), ("P0", C.c_double * 64)]
+
+
+class cuEKF:
+    """Module "cuEKF" (cudarecv/modules/src/cuekf.cu): EnableEKF=False passes zVal through (EKF_PassMeas :147-159,
+    the shipped flow); EnableEKF=True runs StepUpdate then StepPredict per Update (:560-599), host fp64."""
+
+    def __init__(self, InitX, InitP=None, SampleLength=0.02, EnableEKF=False, couple_velocity=True):
+        self.EnableEKF = bool(EnableEKF)
+        self.xCurrk1k1 = np.array(InitX, dtype=np.float64).copy()
+        self.xCurrkk1 = self.xCurrk1k1.copy()
+        self._h = C.c_void_p(None)
+        if self.EnableEKF:
+            cfg = EkfConfig()
+            cfg.sampleLength = float(SampleLength)
+            cfg.coupleVelocity = 1 if couple_velocity else 0
+            P0 = np.eye(8) if InitP is None else np.asarray(InitP, dtype=np.float64).reshape(8, 8)
+            for i in range(8):
+                cfg.x0[i] = float(self.xCurrk1k1[i])
+            for i in range(64):
+                cfg.P0[i] = float(P0.ravel()[i])
+            _check(lib().dpe_ekf_create(C.byref(cfg), C.byref(self._h)))
+
+    def Update(self, zVal, RVal=None):
+        z = np.ascontiguousarray(zVal, dtype=np.float64)
+        if not self.EnableEKF:
+            self.xCurrk1k1 = z.copy(); self.xCurrkk1 = z.copy()
+            return 0
+        R = np.ascontiguousarray(np.eye(8) if RVal is None else RVal, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _check(lib().dpe_ekf_step_update(self._h, z.ctypes.data_as(dp), R.ctypes.data_as(dp)))
+        _check(lib().dpe_ekf_step_predict(self._h))
+        st = self.state()
+        self.xCurrk1k1, self.xCurrkk1 = st["xk1k1"], st["xkk1"]
+        return 0
+
+    def step_update(self, zVal, RVal):
+        z = np.ascontiguousarray(zVal, dtype=np.float64); R = np.ascontiguousarray(RVal, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _check(lib().dpe_ekf_step_update(self._h, z.ctypes.data_as(dp), R.ctypes.data_as(dp)))
+
+    def step_predict(self):
+        _check(lib().dpe_ekf_step_predict(self._h))
+
+    def state(self):
+        a = {k: np.zeros(n) for k, n in (("xk1k1", 8), ("xkk1", 8), ("Pk1k1", 64), ("Pkk1", 64), ("Q", 64), ("K", 64))}
+        dp = C.POINTER(C.c_double)
+        _check(lib().dpe_ekf_state(self._h, *[a[k].ctypes.data_as(dp) for k in ("xk1k1", "xkk1", "Pk1k1", "Pkk1", "Q", "K")]))
+        return {k: (v if v.size == 8 else v.reshape(8, 8)) for k, v in a.items()}
+
+    def Stop(self):
+        if self._h:
+            lib().dpe_ekf_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    __del__ = Stop
 
 
 class HipEventTimer:

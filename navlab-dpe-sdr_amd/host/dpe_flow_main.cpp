@@ -27,7 +27,7 @@ int main(int argc, char **argv)
     std::string samples, handoff, out = "XFile.csv", loadGrid;
     double fs = 2.5e6, T = 0.02;
     int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
-    bool useGraph = false, timing = false;
+    bool useGraph = false, timing = false, enableEkf = false;
     float spacing = 1.0f, delta[4] = {0, 0, 0, 0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -59,6 +59,7 @@ int main(int argc, char **argv)
         else if (a == "--lpower") { lpower = std::atoi(next()); ++i; }
         else if (a == "--graph") { useGraph = true; }
         else if (a == "--timing") { timing = true; }
+        else if (a == "--ekf") { enableEkf = true; }
         else if (a == "--init-delta") { next(4); for (int j = 0; j < 4; ++j) delta[j] = (float)std::atof(argv[i + 1 + j]); i += 4; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -108,7 +109,7 @@ int main(int argc, char **argv)
     CHECK(flow.SetModParam("BatchCorrManifold", "GridType", gridType));
     CHECK(flow.SetModParam("BatchCorrManifold", "LPower", lpower));
     CHECK(flow.SetModParam("cuChanMgr", "DopplerSign", 1));
-    CHECK(flow.SetModParam("cuEKF", "EnableEKF", false));
+    CHECK(flow.SetModParam("cuEKF", "EnableEKF", enableEkf));   // dpeflow.cpp:90 ships false
     CHECK(flow.SetModParam("XECEFLogger", "Filename", out.c_str()));
     CHECK(flow.SetModParam("XECEFLogger", "CSV", true));
     if (!loadGrid.empty()) {
@@ -120,10 +121,12 @@ int main(int argc, char **argv)
     CHECK(flow.SetModParam("BatchCorrScores", "UseGraph", useGraph));
     CHECK(flow.SetModParam("BatchCorrManifold", "UseGraph", useGraph));
 
-    // port table, dpeflow.cpp:140-213 (InitP / InitK belong to the disabled EKF and are dropped)
+    // port table, dpeflow.cpp:140-213 
     static const char *wires[][4] = {
         {"DPInit", "StartByte", "SampleBlock", "StartByte"},
         {"DPInit", "InitX", "cuEKF", "InitX"},
+        {"DPInit", "InitP", "cuEKF", "InitP"},
+        {"DPInit", "InitK", "cuEKF", "InitK"},
         {"DPInit", "InitEph", "cuChanMgr", "InitEph"},
         {"DPInit", "InitPRN", "cuChanMgr", "InitPRN"},
         {"DPInit", "InitCodePhase", "cuChanMgr", "InitCodePhase"},

@@ -44,7 +44,7 @@ class DPInit : public Module {
     DPInit()
     {
         ModuleName = "DPInit";
-        AllocateOutputs(12);
+        AllocateOutputs(14);
         InsertParam("HandoffFilename", handoffFilename, CHAR_t, sizeof(handoffFilename), 0);
         InsertParam("InitDeltaX", &delta[0], FLOAT_t, sizeof(float), sizeof(float));
         InsertParam("InitDeltaY", &delta[1], FLOAT_t, sizeof(float), sizeof(float));
@@ -57,6 +57,8 @@ class DPInit : public Module {
         const DataType_t dt[12] = {INT_t, DOUBLE_t, CHAR_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, INT_t, INT_t, INT_t, DOUBLE_t, UNDEFINED_t};
         const ValueType_t vt[12] = {VALUE, STATE, VALUE, VALUE, VALUE, FREQUENCY_HZ, FREQUENCY_HZ, VALUE, VALUE, VALUE, VALUE, EPHEMS};
         for (int i = 0; i < 12; ++i) ConfigOutput(i, names[i], dt[i], vt[i], HOST, 1, nullptr, 0);
+        ConfigOutput(12, "InitP", DOUBLE_t, COVARIANCE, HOST, 64, initP, 0);   // dpinit.cpp:85,162: identity
+        ConfigOutput(13, "InitK", INT_t, VALUE, HOST, 1, &initK, 0);           // dpinit.cpp:86,164: 0
     }
     int Start(void *) override
     {
@@ -98,6 +100,7 @@ class DPInit : public Module {
         void *data[12] = {&startByte, X, prn.data(), rc.data(), ri.data(), fc.data(), fi.data(), cp.data(), cpRef.data(), tow.data(), &rxTime, eph.data()};
         const uint32_t len[12] = {1, 8, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, 1, (uint32_t)K};
         for (int i = 0; i < 12; ++i) UpdateOutput(i, len[i], data[i], 0);
+        for (int i = 0; i < 64; ++i) initP[i] = (i % 9 == 0) ? 1.0 : 0.0;
         loop = 0;
         return 0;
     }
@@ -108,7 +111,8 @@ class DPInit : public Module {
     float delta[4] = {0, 0, 0, 0};
     int maxIter = 3000, loop = 0, K = 0;
     long long startByte = 0;
-    double rxTime = 0, X[8] = {};
+    double rxTime = 0, X[8] = {}, initP[64] = {};
+    int initK = 0;
     std::vector<uint8_t> prn;
     std::vector<double> rc, ri, fc, fi, eph;
     std::vector<int> cp, cpRef, tow;
@@ -432,39 +436,67 @@ class BatchCorrManifold : public Module {
 };
 
 // ------------------------------------------------------------------------------------------------
-class cuEKF : public Module {   // EnableEKF=false path only: EKF_PassMeas copies zVal to both state ports
+class cuEKF : public Module {   // EnableEKF=false: EKF_PassMeas copies zVal to both state ports; true: the filter
   public:
     cuEKF()
     {
         ModuleName = "cuEKF";
-        AllocateInputs(3);
-        AllocateOutputs(2);
-        ConfigExpectedInput(0, "InitX", DOUBLE_t, STATE, VECTORLENGTH_ANY);
+        AllocateInputs(5);
+        AllocateOutputs(3);
+        ConfigExpectedInput(0, "InitX", DOUBLE_t, STATE, VECTORLENGTH_ANY);         // cuekf.cu:238-244
         ConfigExpectedInput(1, "zVal", DOUBLE_t, STATE, VECTORLENGTH_ANY);
         ConfigExpectedInput(2, "RVal", DOUBLE_t, COVARIANCE, VECTORLENGTH_ANY);
-        ConfigOutput(0, "xCurrk1k1", DOUBLE_t, STATE, HOST, 8, xk1k1, 0);
+        ConfigExpectedInput(3, "InitP", DOUBLE_t, COVARIANCE, VECTORLENGTH_ANY);
+        ConfigExpectedInput(4, "InitK", INT_t, VALUE, 1);
+        ConfigOutput(0, "xCurrk1k1", DOUBLE_t, STATE, HOST, 8, xk1k1, 0);           // :277-279 (host memory here)
         ConfigOutput(1, "xCurrkk1", DOUBLE_t, STATE, HOST, 8, xkk1, 0);
+        ConfigOutput(2, "PCurrkk1", DOUBLE_t, COVARIANCE, HOST, 64, Pkk1, 0);
         InsertParam("EnableEKF", &enable, BOOL_t, sizeof(bool), sizeof(bool));
         InsertParam("SampleLength", &T, DOUBLE_t, sizeof(double), sizeof(double));
     }
+    ~cuEKF() override { Stop(); }
     int Start(void *) override
     {
-        if (enable) DPE_MOD_FAIL("Start: EnableEKF=true is outside the hot path (the shipped flow disables it, dpeflow.cpp:90)");
         if (!inputs[0]) DPE_MOD_FAIL("Start: InitX not connected");
+        if (inputs[0]->VectorLength != 8) DPE_MOD_FAIL("Start: the filter is built for the 8-state DPE model");
         std::memcpy(xk1k1, inputs[0]->Data, sizeof(xk1k1));   // cuekf.cu:338-344
         std::memcpy(xkk1, inputs[0]->Data, sizeof(xkk1));
+        for (int i = 0; i < 64; ++i) Pkk1[i] = (i % 9 == 0) ? 1.0 : 0.0;
+        if (enable) {
+            dpe_ekf_config cfg = {};
+            cfg.sampleLength = T;
+            cfg.coupleVelocity = 1;                            // EKF_MakeDPERandomWalkFMatrix, :460
+            std::memcpy(cfg.x0, xk1k1, sizeof(cfg.x0));
+            if (inputs[3]) std::memcpy(cfg.P0, inputs[3]->Data, sizeof(cfg.P0));   // :352
+            else for (int i = 0; i < 64; ++i) cfg.P0[i] = (i % 9 == 0) ? 1.0 : 0.0;
+            if (dpe_ekf_create(&cfg, &h)) return -1;
+        }
         return 0;
     }
     int Update(void *) override
     {
-        std::memcpy(xk1k1, inputs[1]->Data, sizeof(xk1k1));   // EKF_PassMeas, cuekf.cu:147-159
-        std::memcpy(xkk1, inputs[1]->Data, sizeof(xkk1));
+        if (!enable) {
+            std::memcpy(xk1k1, inputs[1]->Data, sizeof(xk1k1));   // EKF_PassMeas, cuekf.cu:147-159
+            std::memcpy(xkk1, inputs[1]->Data, sizeof(xkk1));
+            return 0;
+        }
+        if (!h) DPE_MOD_FAIL("Error: Update() Failed due to EKF not initialized");
+        // StepUpdate, then StepPredict once per new measurement (:575-588)
+        if (dpe_ekf_step_update(h, (const double *)inputs[1]->Data, (const double *)inputs[2]->Data)) return -1;
+        if (dpe_ekf_step_predict(h)) return -1;
+        return dpe_ekf_state(h, xk1k1, xkk1, nullptr, Pkk1, nullptr, nullptr);
+    }
+    int Stop() override
+    {
+        if (h) dpe_ekf_destroy(h);
+        h = nullptr;
         return 0;
     }
 
   private:
+    dpe_ekf *h = nullptr;
     bool enable = false;
-    double T = 0.02, xk1k1[8] = {}, xkk1[8] = {};
+    double T = 0.02, xk1k1[8] = {}, xkk1[8] = {}, Pkk1[64] = {};
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -398,3 +398,43 @@ def scalar_acquisition(iq_two_windows, fs, prn_list, doppler_sign=1.0):
         else:                                                                  # :507
             final.append((a["rc"], a["ri"], a["fc"], a["fi"]))
     return wins, np.array(final)
+
+
+class Ekf8:
+    """numpy restatement of the 8-state Kalman filter (cuekf.cu:626-742 / ekf.py:58-177, the `_m5` methods).
+    couple_velocity: F = I + T on [i][i+4] (CUDARecv, cuekf.cu:111-143) or F = I (PyGNSS as shipped, ekf.py:47)."""
+    Q_CLOCK_DRIFT = ((2.5e-10) * CONST_C) ** 2.0                                 # ekf.py:69, cuekf.h:28
+
+    def __init__(self, x0, P0=None, T=0.02, couple_velocity=True):
+        self.F = np.eye(8)
+        if couple_velocity:
+            for j in range(4):
+                self.F[j, j + 4] = T
+        self.H = np.eye(8)
+        self.x = np.array(x0, dtype=np.float64).reshape(8)        # x_k|k (after update) or x_k|k-1 (after predict)
+        self.P = np.eye(8) if P0 is None else np.array(P0, dtype=np.float64).reshape(8, 8)
+        self.Q = np.eye(8)
+        self.K = np.eye(8)
+        self.lpf = [0.0] * 20                                      # filters.RunningAverageFilter(20)
+
+    def predict(self):                                             # _time_update_m5, ekf.py:171-178
+        self.x = self.F @ self.x
+        v = float(np.linalg.norm(self.x[4:7]))
+        self.lpf.pop(0); self.lpf.append(v)
+        vbar = sum(self.lpf) / 20.0
+        q = 1.0 + 250.0 / min(max(vbar ** 2.0, 50.0), 125.0)       # :62
+        Q = np.zeros((8, 8))
+        Q[4, 4] = Q[5, 5] = Q[6, 6] = q
+        Q[7, 7] = self.Q_CLOCK_DRIFT
+        self.Q = self.F @ Q @ self.F.T                             # :70
+        self.P = self.F @ self.P @ self.F.T + self.Q               # :77
+        return self.x
+
+    def update(self, z, R=None):                                   # _measurement_update_m5, ekf.py:160-169
+        R = np.eye(8) if R is None else np.asarray(R, dtype=np.float64)
+        e = np.asarray(z, dtype=np.float64).reshape(8) - self.H @ self.x
+        S_inv = np.linalg.inv(self.H @ self.P @ self.H.T + R)      # :82
+        self.K = self.P @ self.H.T @ S_inv                         # :84
+        self.x = self.x + self.K @ e
+        self.P = (np.eye(8) - self.K @ self.H) @ self.P            # :117
+        return self.x

@@ -17,6 +17,7 @@ reference callables that the CUDA authors used as their oracle (SURVEY.md sectio
   O6 NavigationGuesses.generate_spread_grid      receiver.py:995-1026
   O7 Receiver.dp_track internals (one iteration) receiver.py:205-397, channel.py:194-245
   O8 Correlator.coarse_acquisition               correlator.py:53-103
+  O10 ExtendedKalmanFilter._time_update_m5 / _measurement_update_m5 (the real filter, vector/ekf.py:160-178)
   O9 Correlator.search_signal (coarse + fine_frequency_acquisition) on two consecutive windows and
      Receiver.scalar_acquisition's keep-the-better rule   correlator.py:38-51,105-133; receiver.py:452-520
 
@@ -127,10 +128,45 @@ def make_o9(pg):
     rf.close_rawfile()
 
 
+def make_o10(pg):
+    """O10: the reference's own Kalman-filter steps (`_m5` methods, i.e. the filter that its `_l5` pass-through
+    stands in for) over 40 windows of a synthetic moving fix; F = I as shipped and F = I + T as in CUDARecv."""
+    rng = np.random.default_rng(1010)
+    x0 = np.array([-2.7e6, -4.29e6, 3.85e6, 120.0, 3.0, -4.0, 1.5, 0.2])
+    T = 0.02
+    out = {}
+    for tag, couple in (("fI", False), ("fT", True)):
+        kf = pg.ekf.ExtendedKalmanFilter(np.matrix(x0).T, T=T)
+        if couple:   # CUDARecv's transition matrix (cuekf.cu:111-143); a plain parameter of the PyGNSS class
+            F = np.eye(8)
+            for j in range(4):
+                F[j, j + 4] = T
+            kf.F = np.asmatrix(F)
+        xs, Ps, Qs, Ks, zs, xp, Pp = [], [], [], [], [], [], []
+        truth = x0.copy()
+        rng2 = np.random.default_rng(7)
+        for it in range(40):
+            kf._time_update_m5()
+            xp.append(np.asarray(kf.X_ECEF).ravel().copy()); Pp.append(np.asarray(kf.Sigma).copy()); Qs.append(np.asarray(kf.Q).copy())
+            truth[:4] += truth[4:] * T
+            truth[4:7] += rng2.normal(0, 0.3, 3) * (1 + it / 10.0)           # speed sweeps through the Q clamp range
+            z = truth + rng2.normal(0, [1, 1, 1, 2, 0.5, 0.5, 0.5, 0.1])
+            zs.append(z.copy())
+            e = np.matrix(z).T - kf.H * kf.X_ECEF
+            kf._measurement_update_m5(e)
+            xs.append(np.asarray(kf.X_ECEF).ravel().copy()); Ps.append(np.asarray(kf.Sigma).copy()); Ks.append(np.asarray(kf.K).copy())
+        for k, v in (("x_upd", xs), ("P_upd", Ps), ("Q", Qs), ("K", Ks), ("z", zs), ("x_pred", xp), ("P_pred", Pp)):
+            out[tag + "_" + k] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "o10_ekf.npz"), x0=x0, T=T, **out)
+
+
 def main():
     pg = import_pygnss()
     if "--only-o9" in sys.argv:
         make_o9(pg)
+        return
+    if "--only-o10" in sys.argv:
+        make_o10(pg)
         return
     ho = dpe.handoff.read_handoff(os.path.join(REF, "demofiles", "handoff_params_usrp6.csv"))
     prns = [int(p) for p in ho["prn_list"]]
@@ -278,6 +314,7 @@ def main():
                         ncases=len(cases))
     rf.close_rawfile()
     make_o9(pg)
+    make_o10(pg)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

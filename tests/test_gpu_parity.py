@@ -216,6 +216,15 @@ def test_cpp_flow_matches_python_closed_loop(tmp_path):
     assert np.abs(rows - fixes).max() < 1e-6                       # %f rows vs doubles
     assert np.abs(fixes[:, :3] - ho["X_ECEF"][:3]).max() < 1.0     # position fix within 1 m of truth
     assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res)
+    # EnableEKF=true (the reference ships it off, dpeflow.cpp:90): the fix goes through the 8-state filter
+    # (dpe_ekf_*, StepUpdate + StepPredict per window) before it is fed back; a static receiver stays on the truth
+    out2 = str(tmp_path / "X_ekf.csv")
+    subprocess.check_call([exe, "--samples", dat, "--handoff", ho_path, "--out", out2, "--iters", str(W), "--grid-dim", "9",
+                           "--spacing", "1.0", "--ekf"])
+    rows2 = np.loadtxt(out2, delimiter=",")
+    assert rows2.shape == (W, 8)
+    assert np.abs(rows2[:, :3] - ho["X_ECEF"][:3]).max() < 1.5
+    assert np.abs(rows2[:, 4:7]).max() < 1.5                        # velocity estimate of a static receiver
 
 
 @pytest.mark.parametrize("kw,L,B", [
