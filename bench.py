@@ -153,12 +153,26 @@ def main():
             loc_p = torch.as_tensor(_CaiS(bcm.PosScores), device=dev)
             loc_v = torch.as_tensor(_CaiS(bcm.VelScores), device=dev)
 
+    pending = [None]   # the previous step's arg-max exchange, still in flight
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()            # stream-level wait: the compute stream continues after the collective
+            pending[0] = None
+
     def step():
-        bcs.Update(iq_d, cs, stream=stream)
+        bcs.Update(iq_d, cs, stream=stream)     # stage 1 overlaps the previous step's exchange
+        drain()                                 # ... which must be done before the scan clears that key set
         bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce, stream=stream)
         if use_dist:
             if args.exchange == "keys":
-                dpe.sharding.allreduce_argmax(keys_tensor(), dist)
+                # in-order exchange by default; DPE_BENCH_EXCH_MODE=async overlaps it with the next step's stage 1
+                # (measured SLOWER on one MI355X: the collective's kernel then competes with the correlator)
+                mode = os.environ.get("DPE_BENCH_EXCH_MODE", "sync")
+                if mode == "async":
+                    _, pending[0] = dpe.sharding.allreduce_argmax(keys_tensor(), dist, async_op=True)
+                elif mode == "sync":
+                    dpe.sharding.allreduce_argmax(keys_tensor(), dist)
             else:
                 glob_p.zero_(); glob_v.zero_()
                 glob_p[:, off:off + G].copy_(loc_p); glob_v[:, off:off + G].copy_(loc_v)
@@ -167,6 +181,7 @@ def main():
                 torch.argmax(glob_p, dim=1); torch.argmax(glob_v, dim=1)
 
     def fence():
+        drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

@@ -115,7 +115,10 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
     // wave-uniform address -> scalar loads; inl: this manifold's coefficients come from pb.s[SECOND ? 0 : 1]
     const BcmSvDev *svw = params_ptr(sd.sv + (size_t)w * maxK, inl) + ((inl && !SECOND) ? DPE_MAX_CHAN : 0);
     const long long nTiles = (G + kPtsPerBlock - 1) / kPtsPerBlock;
-    unsigned long long best = 0ull;
+    // per-lane running maximum as (score, index): a lane visits its points in increasing index order, so a strict
+    // "greater" keeps the first maximum; the packed 64-bit key is built once, after the tile loop
+    float bestSc = -1.f;          // scores are >= 0
+    unsigned int bestIdx = 0u;
     unsigned int nOob = 0;
     // "Method 1" weighted-mean estimator (optional: wsum != nullptr): sum s, sum s*{x,y,z,t}, pair-packed fp32
     f2 w0 = f2{0.f, 0.f}, w1 = w0, w2 = w0, w3 = w0, w4 = w0;
@@ -129,11 +132,16 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
             q[p] = dx[p] * dx[p] + dy[p] * dy[p] + dz[p] * dz[p];
             score[p] = f2{0.f, 0.f};
         }
-        {   // prefetch the next tile of this block
+        {   // prefetch the next tile of this block (whole lane in range: plain loads, no per-point predicate)
             const long long b1 = base + (long long)nBlkX * kPtsPerBlock;
+            if (b1 + (kPtsPerThread - 1) * 256 < G) {
 #pragma unroll
-            for (int it = 0; it < kPtsPerThread; ++it)
-                nxt[it] = (b1 + it * 256 < G) ? grid[b1 + it * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int it = 0; it < kPtsPerThread; ++it) nxt[it] = grid[b1 + it * 256];
+            } else {
+#pragma unroll
+                for (int it = 0; it < kPtsPerThread; ++it)
+                    nxt[it] = (b1 + it * 256 < G) ? grid[b1 + it * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         unsigned emax = 0;
 #pragma unroll DPE_SV_UNROLL
@@ -206,18 +214,31 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
                 w4 = __builtin_elementwise_fma(sc, dw[p], w4);
             }
         }
+        const unsigned int gi0 = (unsigned int)(base + indexOffset);   // global index of the lane's first point (< 2^32, checked at create)
+        if (base + (kPtsPerThread - 1) * 256 < G) {
+            // whole lane inside the grid (every tile but the last): no per-point bounds checks, one store address
+            float *srow = scores ? scores + (size_t)w * G + base : nullptr;
 #pragma unroll
-        for (int it = 0; it < kPtsPerThread; ++it) {
-            const long long i = base + it * 256;
-            if (i < G) {
+            for (int it = 0; it < kPtsPerThread; ++it) {
                 const float sc = score[it >> 1][it & 1];
-                if (scores) scores[(size_t)w * G + i] = sc;
-                const unsigned long long key = ((unsigned long long)__float_as_uint(sc) << 32) |
-                                               (unsigned long long)(0xFFFFFFFFu - (unsigned int)(i + indexOffset));
-                best = key > best ? key : best;
+                if (scores) srow[it * 256] = sc;
+                if (sc > bestSc) { bestSc = sc; bestIdx = gi0 + it * 256; }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < kPtsPerThread; ++it) {
+                const long long i = base + it * 256;
+                if (i < G) {
+                    const float sc = score[it >> 1][it & 1];
+                    if (scores) scores[(size_t)w * G + i] = sc;
+                    if (sc > bestSc) { bestSc = sc; bestIdx = gi0 + it * 256; }
+                }
             }
         }
     }
+    unsigned long long best = bestSc < 0.f ? 0ull
+                                           : (((unsigned long long)__float_as_uint(bestSc) << 32) |
+                                              (unsigned long long)(0xFFFFFFFFu - bestIdx));
     // block arg-max: larger score wins, ties -> smaller global index (thrust::max_element, :2589)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -560,15 +581,19 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     h->lastSplit[1] = scan_split(h->cfg.velGridSize, nWindows);
     // Two key / counter sets alternate between Updates: this call reduces into set `cur` (zero since it
     // was cleared by the previous call's position scan, or by create) and clears the other one.
-    h->cur ^= 1;
-    unsigned long long *keys = h->keys_d + (size_t)h->cur * 4 * W, *oob = keys + 2 * W;
-    unsigned long long *other = h->keys_d + (size_t)(h->cur ^ 1) * 4 * W;
+    // (h->cur only advances once the launch is enqueued: a call that fails earlier must not skip a clearing)
+    const int use = h->cur ^ 1;
+    unsigned long long *keys = h->keys_d + (size_t)use * 4 * W, *oob = keys + 2 * W;
+    unsigned long long *other = h->keys_d + (size_t)(use ^ 1) * 4 * W;
     GraphCache::Guard graphGuard{h->graphs, stream};
     if (h->graphs.enabled && !h->prof.enabled) {
         const int rc = h->graphs.begin({codeBank_dev, carrBank_dev, 0, nWindows, nChan,
-                                        (posInside ? 1 : 0) | (velInside ? 2 : 0) | (h->cur << 2), stream}, stream);
+                                        (posInside ? 1 : 0) | (velInside ? 2 : 0) | (use << 2), stream}, stream);
         DPE_REQUIRE(rc >= 0, "[BatchCorrManifold] Update: hipGraph capture/replay failed");
-        if (rc == 1) return 0;
+        if (rc == 1) {
+            h->cur = use;
+            return 0;
+        }
     }
     // one window: coefficients as kernel arguments of the scans (a captured graph would freeze them, so
     // that path copies); batches: one copy covers both manifolds' coefficient blocks
@@ -601,6 +626,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     h->prof.end(0, stream);
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrManifold] Update: hipGraph instantiate/launch failed");
     DPE_CHECK_HIP(hipGetLastError());
+    h->cur = use;
     return 0;
 }
 

@@ -30,11 +30,16 @@ def unpack_key(key):
     return float(score), int(0xFFFFFFFF - (int(key) & 0xFFFFFFFF))
 
 
-def allreduce_argmax(local_keys, dist, device=None):
+def allreduce_argmax(local_keys, dist, device=None, async_op=False):
     """local_keys: int64 array/tensor of this rank's best key per (window, manifold).  Returns the
-    global best keys on every rank (one collective per call)."""
+    global best keys on every rank (one collective per call).  async_op=True returns (tensor, work): the caller
+    waits on `work` only before the keys are needed or their buffer is reused -- with the two alternating key
+    sets of BatchCorrManifold that is just before the NEXT manifold scan, so the collective hides behind the next
+    step's correlator kernels."""
     import torch
     t = local_keys if isinstance(local_keys, torch.Tensor) else torch.as_tensor(np.asarray(local_keys), device=device)
+    if async_op:
+        return t, dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 

@@ -29,6 +29,10 @@ def _worker(rank, world, port, scores, out):
     # what bcm_scan_kernel leaves in dpe_bcm_keys(): best key of the local shard per window
     keys = np.stack([dpe.sharding.pack_keys(local[w], b).max() for w in range(W)])
     best = dpe.sharding.allreduce_argmax(keys, dist).numpy()
+    # the overlapped form bench.py uses: collective in flight while the next step's stage 1 is enqueued
+    t, work = dpe.sharding.allreduce_argmax(keys.copy(), dist, async_op=True)
+    work.wait()
+    assert np.array_equal(t.numpy(), best)
     glob = dpe.sharding.allreduce_scores(local, b, G, dist).numpy()
     if rank == 0:
         out["idx"] = [dpe.sharding.unpack_key(k)[1] for k in best]
