@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
 // (dpe_bcs_update); single windows keep the 4-samples-per-lane kernel, whose blocks are 4x shorter.
 // Same partial / moment layouts, so bcs_finalize_kernel is shared.
 template <int LH, int kNMom, bool TABLE>
-__global__ __launch_bounds__(256) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
+__global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
                                                          int S, int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                          const BcsChanDev *__restrict__ chan,
                                                          const long long *__restrict__ sums,
@@ -366,12 +366,13 @@ __global__ __launch_bounds__(256) void bcs_bank16_kernel(BcsParamBlock pb, int i
                 // replica r[m] = chip[floor(t_m fc + rc) mod 1023] (BCS_ComputeCodeReplica :347-349), masked to this
                 // side of the nav-bit boundary (:352-367), m wrapped circularly -- as in bcs_bank_kernel
                 if (fastIdx && lo >= 0 && hi < S) {
-                    const int ci0 = (int)floor(code_phase<TABLE>(ch, tT, lo));
+                    // (phases are >= 0 here -- rc >= 0, lo >= 0 -- so the truncating conversion IS the floor)
+                    const int ci0 = (int)code_phase<TABLE>(ch, tT, lo);
                     const int shift = (ci0 % kLCA) - ci0;
                     const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
                     for (int e = lane; e < NREP; e += 64) {
                         const int m = lo + e;
-                        const int ci = (int)floor(code_phase<TABLE>(ch, tT, m)) + shift;
+                        const int ci = (int)code_phase<TABLE>(ch, tT, m) + shift;
                         float r = sChips[ci];
                         if (straddle) r = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
                         sRep[wave][e] = r;
