@@ -473,3 +473,18 @@ def test_batch_bank_kernel_matches_single_window_kernel(L, B, W):
         assert np.abs(carr[w] - f1[0]).max() <= 1e-6 * np.abs(f1[0]).max()
         assert np.array_equal(info[0][w], i1[0][0]) and np.array_equal(info[1][w], i1[1][0]) and info[2][w] == i1[2][0]
         assert res[w]["posIndex"] == r1[0]["posIndex"] and res[w]["velIndex"] == r1[0]["velIndex"]
+
+
+@pytest.mark.parametrize("pos_out,vel_out,wmean", [(False, True, False), (True, True, True), (False, False, False)])
+def test_clamp_variants_of_the_fused_scan(pos_out, vel_out, wmean):
+    """The fused scan is instantiated per manifold with or without the range clamp (chosen by a host-side proof that
+    every index stays inside the bank).  All combinations against the oracle: scores, arg-max, out-of-window counts."""
+    case = helpers.make_case(seed=19, S=12500, K=4, G=3000, amp=200.0, W=2)
+    if pos_out:
+        case["pos"][:, 3] *= 20.0        # clock offsets of +-2.6 km -> beyond +-4 lags
+    if vel_out:
+        case["vel"][:, 3] *= 40.0        # clock-drift offsets far beyond +-32 bins
+    out = helpers.run_gpu(case, 4, 32, weighted_mean=wmean)
+    ref = helpers.run_oracle(case, 4, 32)
+    assert (ref["res"][0]["posOutOfWindow"] > 0) == pos_out and (ref["res"][0]["velOutOfWindow"] > 0) == vel_out
+    helpers.assert_parity(out, ref, tol=TOL)
