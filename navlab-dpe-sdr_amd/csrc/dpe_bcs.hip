@@ -709,7 +709,12 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     // A single window keeps only a few of these blocks in flight, so the kernel is a chain of memory
     // latencies: every stage issues ALL of its loads before consuming any.  Doppler blocks fetch their
     // first chunk of moments up front, under the partial-sum stage.
-    const bool carrBlk = blockIdx.x != 0;
+    // Two launch shapes: gridDim.x = 1 + nBinBlk (block 0: code bank, block 1+g: Doppler bins 16g..16g+15) for a few
+    // windows, where more blocks mean a shorter latency chain; gridDim.x = 1 ("fat": one block per (window, SV)
+    // does the code bank and then ALL bin groups from one staging of the moments) for batches, where the
+    // redundant partial sums / moment reads of the split shape cost more than they hide.
+    const bool fat = gridDim.x == 1;
+    const bool carrBlk = fat || blockIdx.x != 0;
     const float2 *m0 = mom + (((size_t)w * K + k) * 2) * nSub * kNMom;
     const float2 *m1 = m0 + (size_t)nSub * kNMom;
     float2 r0[kNMom], r1[kNMom];
@@ -771,33 +776,42 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     const int noFlip = (!ch.hasFlip) || (nr0 * nr0 + ni0 * ni0 > fr0 * fr0 + fi0 * fi0);
     const float sgn = noFlip ? 1.f : -1.f;
 
-    if (!carrBlk) {
+    if (blockIdx.x == 0) {
         if (tid == 0) info[w * K + k] = noFlip;
         for (int j = tid; j < 2 * L + 1; j += 256) {
             const int jj = j + (LH - L);
             const float2 X = sXY[jj], Y = sXY[NL + jj];
             codeBank[((size_t)w * maxK + k) * (2 * L + 1) + j] = make_float2(X.x + sgn * Y.x, X.y + sgn * Y.y);
         }
-        return;
+        if (!fat) return;
     }
     // ---- Doppler bins: F[b] = sum_sub tw(sub,b) * sum_p (-j theta)^p / p! * M_p[sub]
-    // 16 bins per block, 16 thread groups striding the sub-tiles
-    const int bi = (blockIdx.x - 1) * 16 + (tid & 15);  // bank entry
+    // 16 bins per group, 16 thread groups striding the sub-tiles; a fat block walks all bin groups per chunk
+    constexpr int kMaxFatGroups = 4;
+    const int nGroups = (2 * B + 1 + 15) / 16;
+    const int gFirst = fat ? 0 : (int)blockIdx.x - 1, gCount = fat ? nGroups : 1;   // host: fat only if nGroups <= kMaxFatGroups
     const int grp = tid >> 4;
-    const int b = bi - B;
-    const bool live = bi < 2 * B + 1;
-    float2 F = make_float2(0.f, 0.f);
-    const float theta = (float)(6.283185307179586476925286766559 * (double)b / (double)C);
     const float invC = 1.0f / (float)C;  // C is a power of two: exact
-    // centre twiddle exp(-j 2 pi n_c b / C), n_c = 256 sub + 127.5: exact (integer-reduced phase +
-    // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 4096 b / C) between
-    float stepS = 0.f, stepC = 1.f;
-    if (live) {
-        long long ts = ((long long)8192 * (long long)b) % (2 * C);   // 2 * (16 * 256) b  (phase unit: pi / C)
-        if (ts < 0) ts += 2 * C;
-        sincospif((float)ts * invC, &stepS, &stepC);
+    float2 F[kMaxFatGroups];
+    float theta[kMaxFatGroups], stepS[kMaxFatGroups], stepC[kMaxFatGroups], sn[kMaxFatGroups], cs[kMaxFatGroups];
+    bool live[kMaxFatGroups];
+    int bb[kMaxFatGroups];
+#pragma unroll
+    for (int g = 0; g < kMaxFatGroups; ++g) {
+        const int bi = (gFirst + g) * 16 + (tid & 15);  // bank entry
+        bb[g] = bi - B;
+        live[g] = g < gCount && bi < 2 * B + 1;
+        F[g] = make_float2(0.f, 0.f);
+        theta[g] = (float)(6.283185307179586476925286766559 * (double)bb[g] / (double)C);
+        // centre twiddle exp(-j 2 pi n_c b / C), n_c = 256 sub + 127.5: exact (integer-reduced phase +
+        // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 4096 b / C) between
+        stepS[g] = 0.f; stepC[g] = 1.f; sn[g] = 0.f; cs[g] = 1.f;
+        if (live[g]) {
+            long long ts = ((long long)8192 * (long long)bb[g]) % (2 * C);   // 2 * (16 * 256) b  (phase unit: pi / C)
+            if (ts < 0) ts += 2 * C;
+            sincospif((float)ts * invC, &stepS[g], &stepC[g]);
+        }
     }
-    float sn = 0.f, cs = 1.f;
     int it = 0;
     for (int c0 = 0; c0 < nSub; c0 += kChunk) {
         if (c0) {
@@ -808,41 +822,48 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
         for (int i = 0; i < kNMom; ++i)
             sMom[tid + 256 * i] = make_float2(r0[i].x + sgn * r1[i].x, r0[i].y + sgn * r1[i].y);
         __syncthreads();
-        if (live) {
-            const int cEnd = nSub - c0 < kChunk ? nSub - c0 : kChunk;
-            for (int sl = grp; sl < cEnd; sl += 16, ++it) {   // kChunk is a multiple of 16: the stride continues across chunks
-                const int sub = c0 + sl;
-                const float2 *a = sMom + sl * kNMom;
+        const int cEnd = nSub - c0 < kChunk ? nSub - c0 : kChunk;
+        for (int sl = grp; sl < cEnd; sl += 16, ++it) {   // kChunk is a multiple of 16: the stride continues across chunks
+            const int sub = c0 + sl;
+            const float2 *a = sMom + sl * kNMom;
+#pragma unroll
+            for (int g = 0; g < kMaxFatGroups; ++g) {
+                if (!live[g]) continue;
                 float ar = a[kNMom - 1].x, ai = a[kNMom - 1].y;
 #pragma unroll
                 for (int p = kNMom - 1; p >= 1; --p) {
-                    const float sc = theta / (float)p;
+                    const float sc = theta[g] / (float)p;
                     const float mr = a[p - 1].x, mi = a[p - 1].y;
                     const float nr = fmaf(sc, ai, mr);
                     ai = fmaf(-sc, ar, mi);
                     ar = nr;
                 }
                 if ((it & 7) == 0) {
-                    long long tt = ((long long)(512 * sub + 255) * (long long)b) % (2 * C);
+                    long long tt = ((long long)(512 * sub + 255) * (long long)bb[g]) % (2 * C);
                     if (tt < 0) tt += 2 * C;
-                    sincospif((float)tt * invC, &sn, &cs);  // angle = pi * tt / C
+                    sincospif((float)tt * invC, &sn[g], &cs[g]);  // angle = pi * tt / C
                 } else {
-                    const float nc = cs * stepC - sn * stepS;
-                    sn = sn * stepC + cs * stepS;
-                    cs = nc;
+                    const float nc = cs[g] * stepC[g] - sn[g] * stepS[g];
+                    sn[g] = sn[g] * stepC[g] + cs[g] * stepS[g];
+                    cs[g] = nc;
                 }
                 // (cs - j sn) * (ar + j ai)
-                F.x += cs * ar + sn * ai;
-                F.y += cs * ai - sn * ar;
+                F[g].x += cs[g] * ar + sn[g] * ai;
+                F[g].y += cs[g] * ai - sn[g] * ar;
             }
         }
     }
-    sRed[grp][tid & 15] = F;
-    __syncthreads();
-    if (grp == 0 && live) {
-        float2 t = sRed[0][tid];
-        for (int q = 1; q < 16; ++q) { t.x += sRed[q][tid].x; t.y += sRed[q][tid].y; }
-        carrBank[((size_t)w * maxK + k) * (2 * B + 1) + bi] = t;
+#pragma unroll
+    for (int g = 0; g < kMaxFatGroups; ++g) {
+        if (g >= gCount) break;   // block-uniform
+        if (g) __syncthreads();
+        sRed[grp][tid & 15] = F[g];
+        __syncthreads();
+        if (grp == 0 && live[g]) {
+            float2 t = sRed[0][tid];
+            for (int q = 1; q < 16; ++q) { t.x += sRed[q][tid].x; t.y += sRed[q][tid].y; }
+            carrBank[((size_t)w * maxK + k) * (2 * B + 1) + (gFirst + g) * 16 + tid] = t;
+        }
     }
 }
 
@@ -1112,12 +1133,15 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->prof.end(1, stream);
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
+    // batches: one fat block per (window, SV); few windows: 1 + nBinBlk short blocks (see the kernel)
+    const bool fatFinalize = nBinBlk <= 4 && (long long)nChan * nWindows >= 512;
+    const dim3 fgrid(fatFinalize ? 1 : 1 + nBinBlk, nChan, nWindows);
     if (h->nMom == 4)
-        hipLaunchKernelGGL(bcs_finalize_kernel<4>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
+        hipLaunchKernelGGL(bcs_finalize_kernel<4>, fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
                            nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     else
-        hipLaunchKernelGGL(bcs_finalize_kernel<6>, dim3(1 + nBinBlk, nChan, nWindows), dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
+        hipLaunchKernelGGL(bcs_finalize_kernel<6>, fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
                            nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);

@@ -488,3 +488,29 @@ def test_clamp_variants_of_the_fused_scan(pos_out, vel_out, wmean):
     ref = helpers.run_oracle(case, 4, 32)
     assert (ref["res"][0]["posOutOfWindow"] > 0) == pos_out and (ref["res"][0]["velOutOfWindow"] > 0) == vel_out
     helpers.assert_parity(out, ref, tol=TOL)
+
+
+def test_fat_finalize_shape_is_bit_identical_to_the_split_shape(monkeypatch):
+    """Batches launch bcs_finalize_kernel with one block per (window, SV) doing the code bank and every Doppler-bin
+    group; few windows launch 1 + nBinBlk short blocks.  Same arithmetic in the same order: with stage 1 pinned to
+    one kernel (DPE_BCS_NO_BANK16) and one tile partition, a 64-window batch reproduces single-window calls bit for bit."""
+    import torch
+    monkeypatch.setenv("DPE_BCS_NO_BANK16", "1")
+    fs, S, K, W, L, B = 2.5e6, 12500, 8, 64, 4, 24
+    iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=53, amp=60.0)
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+
+    def run(wsel, maxw):
+        bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=maxw, max_channels=K)
+        bcs.Start()
+        bcs.Update(iq_d[wsel], cs[wsel])
+        code, carr = bcs.read_banks()
+        info = bcs.read_info()
+        bcs.Stop()
+        return code, carr, info
+
+    code, carr, info = run(slice(0, W), W)
+    for w in (0, 31, W - 1):
+        c1, f1, i1 = run(slice(w, w + 1), 1)
+        assert np.array_equal(code[w], c1[0]) and np.array_equal(carr[w], f1[0])
+        assert np.array_equal(info[1][w], i1[1][0])
