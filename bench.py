@@ -189,14 +189,23 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    bcs.profile(True); bcm.profile(True)
+    # Inside the timed region only the dominant kernel (the fused scan, `roofline`) carries HIP events: a pair of
+    # events around every kernel costs ~2 % of the step (measured: 0.948 vs 0.928 ms).  The other kernels are timed
+    # in a short extra pass afterwards (`kernels_ms_per_step`, informational).
+    bcm.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     kern = {}
-    kern.update(bcs.profile(False)); kern.update(bcm.profile(False))
+    kern.update(bcm.profile(False))
+    extra = max(5, min(20, args.steps))
+    bcs.profile(True)
+    for _ in range(extra):
+        step()
+    fence()
+    kern_extra = bcs.profile(False)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -248,7 +257,8 @@ def main():
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(W) if world == 1 else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": ms_scan / n_scan if n_scan else None},
-            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in kern.items()},
+            "kernels_ms_per_step": dict({k: v[0] / args.steps for k, v in kern.items()},
+                                        **{k: v[0] / max(v[1], 1) for k, v in kern_extra.items()}),
         }
         if pcie_value is not None:
             out["pcie_inclusive_value"] = pcie_value
