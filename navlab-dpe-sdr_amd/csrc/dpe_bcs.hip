@@ -1063,7 +1063,6 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
                        (long long)windowStrideSamples, S, h->sums_d);
     h->prof.end(0, stream);
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
-    // tiles per block: amortise the end-of-block lag reduction while keeping >= ~4096 blocks in flight
     // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
     // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else a dense kernel
     const bool wide = h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
@@ -1072,7 +1071,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int nTiles16 = (h->nSub + 15) / 16;
     const bool use16 = !wide && h->LH <= 8 && h->bank16Allowed && (long long)nTiles16 * nChan * nWindows >= 2048;
     const int nTiles = use16 ? nTiles16 : (h->nSub + 3) / 4;
-    int tpb;
+    int tpb;   // tiles per block: amortise the end-of-block lag reduction while keeping >= ~4096 blocks in flight
     if (use16) {
         tpb = (int)(((long long)nTiles * nChan * nWindows) / 4096);
         const int least = (nTiles + h->nBlk - 1) / h->nBlk;   // the partial buffer holds h->nBlk blocks per (window, SV)
