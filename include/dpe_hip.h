@@ -60,7 +60,7 @@ int dpe_stream_synchronize(dpe_stream_t stream);
 /* ------------------------------------------------------------------ BatchCorrScores - */
 typedef struct dpe_bcs_config {
     int32_t samplesPerWindow;   /* S  = SamplingFrequency*SampleLength (sampleblock.cu:169) */
-    int32_t lagHalfWidth;       /* L: code lags [-L,+L] kept about the fftshift centre S/2 */
+    int32_t lagHalfWidth;       /* L: code lags [-L,+L] kept about the fftshift centre S/2; 1..292 (beyond 32: chunks of 65 lags) */
     int32_t binHalfWidth;       /* B: Doppler bins [-B,+B] kept about C/2 */
     int32_t maxWindows;         /* windows per dpe_bcs_update call (>=1) */
     int32_t maxChannels;        /* <= DPE_MAX_CHAN */

@@ -136,7 +136,7 @@ __device__ __forceinline__ void window_mean(const long long *__restrict__ sums, 
 // ------------------------------------------------------------------------------------------
 template <int LH, int kNMom, bool TABLE>
 __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride, int S,
-                                                       int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
+                                                       int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk, int lagShift,
                                                        const BcsChanDev *__restrict__ chan,
                                                        const long long *__restrict__ sums,
                                                        const int8_t *__restrict__ chipTable,
@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
         for (int t = 0; t < tilesPerBlock; ++t) {
             const int sub = (blk * tilesPerBlock + t) * 4 + wave;
             const int sub0 = sub * kSub;
-            const int lo = sub0 - LH, hi = sub0 + kSub - 1 + LH;
+            // lagShift: this launch produces the lags [lagShift - LH, lagShift + LH] -- the same sums against the
+            // replica delayed by lagShift samples, i.e. every replica index below is taken lagShift earlier
+            const int lo = sub0 - LH - lagShift, hi = sub0 + kSub - 1 + LH - lagShift;
             bool active = sub < nSub;
             if (active) {
                 if (!ch.hasFlip) active = (side == 0);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                     wr = nr;
                 }
             }
-            if (sub < nSub) {
+            if (sub < nSub && lagShift == 0) {   // the Doppler path belongs to the unshifted replica only
                 float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
                 if (active) {
                     float mm[2 * kNMom];
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
 // part layout per (block, side): [0] = corr[-32], [1 + i] = D[-32 + i], i = 0..63  (65 entries, as NL).
 template <int kNMom, bool TABLE>
 __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride, int S,
-                                                            int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
+                                                            int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk, int lagShift,
                                                             const BcsChanDev *__restrict__ chan,
                                                             const long long *__restrict__ sums,
                                                             const int8_t *__restrict__ chipTable,
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
         for (int t = 0; t < tilesPerBlock; ++t) {
             const int sub = (blk * tilesPerBlock + t) * 4 + wave;
             const int sub0 = sub * kSub;
-            const int lo = sub0 - 1, hi = sub0 + kSub - 1 + LH;   // replica index range
+            const int lo = sub0 - 1 - lagShift, hi = sub0 + kSub - 1 + LH - lagShift;   // replica index range (see lagShift in bcs_bank_kernel)
             bool active = sub < nSub;
             if (active) {
                 if (!ch.hasFlip) active = (side == 0);
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
                     }
                 }
             }
-            if (sub < nSub) {
+            if (sub < nSub && lagShift == 0) {
                 float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
                 if (active) {
                     float mm[2 * kNMom];
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
 // ------------------------------------------------------------------------------------------
 // blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
 template <int kNMom>
-__global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide,
+__global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide, int lagShift,
                                                            long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
                                                            const float2 *__restrict__ mom,
@@ -713,8 +715,10 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     // windows, where more blocks mean a shorter latency chain; gridDim.x = 1 ("fat": one block per (window, SV)
     // does the code bank and then ALL bin groups from one staging of the moments) for batches, where the
     // redundant partial sums / moment reads of the split shape cost more than they hide.
-    const bool fat = gridDim.x == 1;
-    const bool carrBlk = fat || blockIdx.x != 0;
+    // lagShift != 0: a further chunk of a lag window wider than +-32 (one block per (window, SV): partial sums and
+    // code-bank entries only; the replica choice was made by the lagShift == 0 launch and is read back from info[])
+    const bool fat = gridDim.x == 1 && lagShift == 0;
+    const bool carrBlk = lagShift == 0 && (fat || blockIdx.x != 0);
     const float2 *m0 = mom + (((size_t)w * K + k) * 2) * nSub * kNMom;
     const float2 *m1 = m0 + (size_t)nSub * kNMom;
     float2 r0[kNMom], r1[kNMom];
@@ -773,15 +777,16 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     // BCS_ChooseCodeCorr :512-516 -- decision at lag 0 only
     const float2 X0 = sXY[LH], Y0 = sXY[NL + LH];
     const float nr0 = X0.x + Y0.x, ni0 = X0.y + Y0.y, fr0 = X0.x - Y0.x, fi0 = X0.y - Y0.y;
-    const int noFlip = (!ch.hasFlip) || (nr0 * nr0 + ni0 * ni0 > fr0 * fr0 + fi0 * fi0);
+    const int noFlip = lagShift == 0 ? ((!ch.hasFlip) || (nr0 * nr0 + ni0 * ni0 > fr0 * fr0 + fi0 * fi0)) : info[w * K + k];
     const float sgn = noFlip ? 1.f : -1.f;
 
     if (blockIdx.x == 0) {
-        if (tid == 0) info[w * K + k] = noFlip;
-        for (int j = tid; j < 2 * L + 1; j += 256) {
-            const int jj = j + (LH - L);
+        if (tid == 0 && lagShift == 0) info[w * K + k] = noFlip;
+        for (int jj = tid; jj < NL; jj += 256) {
+            const int lag = lagShift + jj - LH;        // this chunk holds the lags lagShift - LH .. lagShift + LH
+            if (lag < -L || lag > L) continue;
             const float2 X = sXY[jj], Y = sXY[NL + jj];
-            codeBank[((size_t)w * maxK + k) * (2 * L + 1) + j] = make_float2(X.x + sgn * Y.x, X.y + sgn * Y.y);
+            codeBank[((size_t)w * maxK + k) * (2 * L + 1) + lag + L] = make_float2(X.x + sgn * Y.x, X.y + sgn * Y.y);
         }
         if (!fat) return;
     }
@@ -914,6 +919,9 @@ static int sum_blocks(int S, int nWindows)
     return want > dpe::kSumSlots ? dpe::kSumSlots : want;
 }
 
+// widest supported lag window: the centre chunk (+-32) plus 4 chunks of 65 lags on each side
+static constexpr int kMaxLagHalfWidth = 32 + 4 * 65;
+
 static long long next_pow2(long long x)
 {
     long long p = 1;
@@ -931,8 +939,10 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     DPE_REQUIRE(cfg->samplingFrequency > 0, "[BatchCorrScores] create: bad samplingFrequency");
     DPE_REQUIRE(cfg->maxWindows >= 1 && cfg->maxChannels >= 1 && cfg->maxChannels <= DPE_MAX_CHAN,
                 "[BatchCorrScores] create: maxWindows/maxChannels out of range");
-    DPE_REQUIRE(cfg->lagHalfWidth >= 1 && cfg->lagHalfWidth <= 32,
-                "[BatchCorrScores] create: lagHalfWidth %d not in [1,32]", cfg->lagHalfWidth);
+    DPE_REQUIRE(cfg->lagHalfWidth >= 1 && cfg->lagHalfWidth <= kMaxLagHalfWidth,
+                "[BatchCorrScores] create: lagHalfWidth %d not in [1,%d]", cfg->lagHalfWidth, kMaxLagHalfWidth);
+    DPE_REQUIRE(cfg->lagHalfWidth + 32 + dpe::kSub < cfg->samplesPerWindow,
+                "[BatchCorrScores] create: lagHalfWidth %d too wide for %d samples per window", cfg->lagHalfWidth, cfg->samplesPerWindow);
     DPE_REQUIRE(cfg->binHalfWidth >= 1, "[BatchCorrScores] create: binHalfWidth < 1");
     const int S = cfg->samplesPerWindow;
     const long long C = 8 * next_pow2(S);  // batchcorrscores.cu:761
@@ -1087,13 +1097,19 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const dim3 grid(nBlk, nChan, nWindows), block(256);
 #define DPE_LAUNCH_BANK3(LHV, NM, TB)                                                                                   \
     hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
-                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, \
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, lagShift, h->chan_d, h->sums_d, h->chipTable_d, \
                        h->tTable_d, h->part_d, h->mom_d)
 #define DPE_LAUNCH_BANK2(LHV, NM)                           \
     do {                                                    \
         if (h->useTable) DPE_LAUNCH_BANK3(LHV, NM, true);   \
         else DPE_LAUNCH_BANK3(LHV, NM, false);              \
     } while (0)
+    // Lag windows wider than +-32: further chunks of 65 lags, centred 65 samples apart -- the same kernels run
+    // against the replica delayed by lagShift samples (centre chunk first: it makes the replica choice and the
+    // Doppler bank).  One chunk when L <= 32.
+    const int nSideChunks = h->cfg.lagHalfWidth > 32 ? (h->cfg.lagHalfWidth - 32 + 64) / 65 : 0;
+    for (int chunk = 0; chunk <= 2 * nSideChunks; ++chunk) {
+    const int lagShift = chunk == 0 ? 0 : ((chunk + 1) / 2) * 65 * ((chunk & 1) ? 1 : -1);
     h->prof.begin(1, stream);
 #define DPE_LAUNCH_BANK(LHV)            \
     do {                                \
@@ -1115,7 +1131,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     } else if (wide) {
 #define DPE_LAUNCH_WIDE(NM, TB)                                                                                    \
     hipLaunchKernelGGL((bcs_bank_wide_kernel<NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
-                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
+                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, lagShift, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
         if (h->nMom == 4) { if (h->useTable) DPE_LAUNCH_WIDE(4, true); else DPE_LAUNCH_WIDE(4, false); }
         else { if (h->useTable) DPE_LAUNCH_WIDE(6, true); else DPE_LAUNCH_WIDE(6, false); }
 #undef DPE_LAUNCH_WIDE
@@ -1132,18 +1148,20 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->prof.end(1, stream);
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
-    // batches: one fat block per (window, SV); few windows: 1 + nBinBlk short blocks (see the kernel)
+    // batches: one fat block per (window, SV); few windows: 1 + nBinBlk short blocks (see the kernel);
+    // side chunks of a wide lag window: one block per (window, SV), code-bank entries only
     const bool fatFinalize = nBinBlk <= 4 && (long long)nChan * nWindows >= 512;
-    const dim3 fgrid(fatFinalize ? 1 : 1 + nBinBlk, nChan, nWindows);
+    const dim3 fgrid((fatFinalize || lagShift != 0) ? 1 : 1 + nBinBlk, nChan, nWindows);
     if (h->nMom == 4)
         hipLaunchKernelGGL(bcs_finalize_kernel<4>, fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
-                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
+                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     else
         hipLaunchKernelGGL(bcs_finalize_kernel<6>, fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
-                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, h->C, h->chan_d, h->part_d, h->mom_d,
+                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, h->C, h->chan_d, h->part_d, h->mom_d,
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);
+    }   // chunk
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrScores] Update: hipGraph instantiate/launch failed");
     DPE_CHECK_HIP(hipGetLastError());
     return 0;

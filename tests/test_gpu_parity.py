@@ -287,7 +287,7 @@ def test_argument_errors_are_reported():
     import torch
     e = dpe.engine
     with pytest.raises(dpe.DpeError, match="lagHalfWidth"):
-        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, lag_half_width=40).Start()
+        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, lag_half_width=400).Start()
     with pytest.raises(dpe.DpeError, match="too wide"):
         dpe.BatchCorrScores(2.5e6, samples_per_window=50000, bin_half_width=400).Start()
     bcs = dpe.BatchCorrScores(2.5e6, samples_per_window=50000, max_channels=4)
@@ -514,3 +514,19 @@ def test_fat_finalize_shape_is_bit_identical_to_the_split_shape(monkeypatch):
         c1, f1, i1 = run(slice(w, w + 1), 1)
         assert np.array_equal(code[w], c1[0]) and np.array_equal(carr[w], f1[0])
         assert np.array_equal(info[1][w], i1[1][0])
+
+
+@pytest.mark.parametrize("fs,S,L,scale", [(25e6, 125000, 100, 7.0), (2.5e6, 25000, 48, 38.0)])
+def test_lag_windows_wider_than_32_samples(fs, S, L, scale):
+    """Lag windows beyond +-32 are produced in chunks of 65 lags (the stage-1 kernels re-run against the replica
+    delayed by 65 j samples); 25 Msps goes through the boundary-difference kernel, 2.5 Msps through the dense one.
+    Banks over the whole window, manifold scores of a grid that really reaches the outer chunks, and the arg-max
+    against the oracle."""
+    case = helpers.make_case(seed=61, fs=fs, S=S, K=4, G=3000, amp=200.0)
+    case["pos"][:, 3] *= scale            # clock-bias offsets that spread the code-lag index over most of +-L
+    out = helpers.run_gpu(case, L, 16)
+    ref = helpers.run_oracle(case, L, 16)
+    assert ref["res"][0]["posOutOfWindow"] == 0
+    g = fs * 1.023e6 / (1.023e6 * 299792458.0)
+    assert np.abs(case["pos"][:, 3]).max() * g > 40            # the grid reaches beyond the centre chunk
+    helpers.assert_parity(out, ref, tol=TOL)
