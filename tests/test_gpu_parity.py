@@ -438,15 +438,17 @@ def test_key_sets_stay_clean_across_changing_batch_sizes():
     assert seq[0] == seq[2] == seq[4] and seq[1] == seq[0][:1] and seq[3] == seq[0][:2]
 
 
-@pytest.mark.parametrize("L,B,W", [(4, 20, 24), (8, 40, 24)])
-def test_batch_bank_kernel_matches_single_window_kernel(L, B, W):
+@pytest.mark.parametrize("L,B,W,fs,S", [(4, 20, 24, 2.5e6, 50000), (8, 40, 24, 2.5e6, 50000), (4, 12, 128, 2.046e6, 8184)])
+def test_batch_bank_kernel_matches_single_window_kernel(L, B, W, fs, S):
     """Batches large enough to fill the chip run stage 1 through bcs_bank16_kernel (16 samples per lane);
     single windows use bcs_bank_kernel (4 per lane).  Same arithmetic per sample, different grouping of the
     fp32 sums: banks agree to 1e-6 of the peak (each is within 3e-7 of the fp64 oracle, see the fixture
     tests), DC mean / nav-bit index / replica choice are identical, and so is the fix.  S = 50000 is not a
-    multiple of the 1024-sample pass, every window holds a nav-bit edge, B = 40 selects the 6-moment variant."""
+    multiple of the 1024-sample pass, every window holds a nav-bit edge, B = 40 selects the 6-moment variant, and
+    2.046 Msps (sampling period not a whole number of ns) the time-table variant."""
     import torch
     cfg = dpe.workload.CONFIG_R
+    cfg = dict(cfg, fs=fs, S=S)
     iq, cs, ce, bw = dpe.workload.build_windows(W, cfg["fs"], cfg["S"], cfg["K"], seed=41, amp=cfg["amp"])
     _, _, pos, vel, _ = dpe.workload.build_grids(6561)
     iq_d = torch.from_numpy(iq).to("cuda:0")
