@@ -43,7 +43,8 @@ int dpe_gen_ca_code(int8_t *chips /* [37*1023] host */);
 /* ------------------------------------------------------------------ SampleBlock ---- */
 /* Replaces the device side of dsp::SampleBlock (sampleblock.cu:356-410,465-515): copies one
  * block of interleaved little-endian int16 I/Q (4 bytes/sample) from host to a device
- * buffer on `stream`.  hostPinned: 1 if `src` is page-locked (reference: cudaMallocHost). */
+ * buffer on `stream` (asynchronous when `src` is page-locked, e.g. from dpe_host_alloc_pinned;
+ * reference: cudaMallocHost). */
 int dpe_sampleblock_upload(int16_t *dst_dev, const int16_t *src_host, int64_t nSamples,
                            dpe_stream_t stream);
 int dpe_host_alloc_pinned(void **ptr, int64_t bytes);
@@ -84,8 +85,10 @@ typedef struct dpe_chan_start {
 int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out);     /* BatchCorrScores::Start  :710-886 */
 int dpe_bcs_destroy(dpe_bcs *h);                                   /* BatchCorrScores::Stop   :888-973 */
 /* BatchCorrScores::Update :975-1208.  samples_dev: nWindows blocks of 2*S int16, block w at
- * samples_dev + w*windowStrideSamples*2.  chan_host: [nWindows][nChan].  Asynchronous on
- * `stream`; outputs are valid once the stream is synchronised. */
+ * samples_dev + w*windowStrideSamples*2.  chan_host: [nWindows][nChan], consumed before the call returns.
+ * Asynchronous on `stream`; outputs are valid once the stream is synchronised.  Calls may be issued back to
+ * back: parameters of up to DPE_MAX_CHAN (window, channel) pairs travel as kernel arguments, larger batches
+ * through a pinned staging block that the next call waits for. */
 int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples,
                    int32_t nWindows, int32_t nChan, const dpe_chan_start *chan_host,
                    dpe_stream_t stream);

@@ -338,6 +338,7 @@ struct dpe_bcm {
     float4 *posGrid_d = nullptr, *velGrid_d = nullptr;
     float *posScores_d = nullptr, *velScores_d = nullptr;
     dpe::BcmSvDev *sv_d = nullptr, *sv_h = nullptr;  // [2][W][maxK]  (manifold-major)
+    hipEvent_t stagingFree = nullptr;   // recorded after the batch path's H2D copy of sv_h
     unsigned long long *keys_d = nullptr;  // [2 sets][{keys [W][2], counts [W][2]}], alternating between Updates
     int cur = 1;                           // set of the latest Update
     unsigned int *done_d = nullptr;        // finished-block ticket of the scan kernel (returns to 0 by itself)
@@ -492,6 +493,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
     h->oob_h = h->keys_h + 2 * W;
+    DPE_CHECK_HIP(hipEventCreateWithFlags(&h->stagingFree, hipEventDisableTiming));
     DPE_CHECK_HIP(hipMemset(h->keys_d, 0, 8 * W * sizeof(unsigned long long)));
     h->done_d = dev_alloc<unsigned int>(1);
     DPE_REQUIRE(h->done_d, "[BatchCorrManifold] create: device allocation failed");
@@ -509,6 +511,7 @@ int dpe_bcm_destroy(dpe_bcm *h)
     for (void *b : bufs) (void)hipFree(b);
     if (h->sv_h) (void)hipHostFree(h->sv_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
+    if (h->stagingFree) (void)hipEventDestroy(h->stagingFree);
     h->graphs.clear();
     delete h;
     return 0;
@@ -526,6 +529,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     const int maxK = h->cfg.maxChannels, W = h->cfg.maxWindows;
     const double fs = h->cfg.samplingFrequency, Cf = (double)h->cfg.numFFTPoints;
     bool posInside = true, velInside = true;   // every index provably inside the banks?
+    DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree));   // a previous batch Update may still be copying sv_h
     for (int w = 0; w < nWindows; ++w) {
         const dpe_bcm_window &win = win_host[w];
         DPE_REQUIRE(win.dopplerSign == 1 || win.dopplerSign == -1, "[BatchCorrManifold] Update: dopplerSign must be +/-1");
@@ -604,6 +608,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         memcpy(pb.s[1], h->sv_h + (size_t)W * maxK, sizeof(BcmSvDev) * nChan);
     } else {
         DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
+        if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree, stream));
     }
     const int nLag = 2 * L + 1, nBin = 2 * B + 1;
     ScanLaunch a;

@@ -900,6 +900,7 @@ struct dpe_bcs {
     long long *sums_d = nullptr;
     dpe::BcsChanDev *chan_d = nullptr;
     dpe::BcsChanDev *chan_h = nullptr;  // pinned staging
+    hipEvent_t stagingFree = nullptr;   // recorded after the batch path's H2D copy of chan_h: the next Update may refill it
     float2 *part_d = nullptr, *mom_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
     int *info_d = nullptr;
     int lastW = 0, lastK = 0, lastSumBlocks = 1;
@@ -998,6 +999,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
     DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
     h->idxNext_h.assign(W * K, 0);
+    DPE_CHECK_HIP(hipEventCreateWithFlags(&h->stagingFree, hipEventDisableTiming));
     h->wideAllowed = getenv("DPE_BCS_NO_WIDE") == nullptr;
     h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
     *out = h;
@@ -1010,6 +1012,7 @@ int dpe_bcs_destroy(dpe_bcs *h)
     void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->codeBank_d, h->carrBank_d, h->info_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chan_h) (void)hipHostFree(h->chan_h);
+    if (h->stagingFree) (void)hipEventDestroy(h->stagingFree);
     h->graphs.clear();
     delete h;
     return 0;
@@ -1026,6 +1029,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     DPE_REQUIRE(nWindows == 1 || windowStrideSamples >= S, "[BatchCorrScores] Update: window stride < S");
     hipStream_t stream = (hipStream_t)stream_;
     const double fs = h->cfg.samplingFrequency;
+    // a previous batch Update may still be copying the pinned staging block (no-op when it has finished / never ran)
+    DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree));
     for (int i = 0; i < nWindows * nChan; ++i) {
         const dpe_chan_start &c = chan_host[i];
         DPE_REQUIRE(c.prn >= 1 && c.prn <= kPrnMax, "[BatchCorrScores] Update: PRN %d out of range", c.prn);
@@ -1067,7 +1072,10 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int inl = (!h->graphs.capturing && nWindows * nChan <= DPE_MAX_CHAN) ? 1 : 0;
     BcsParamBlock pb{};
     if (inl) memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
-    else DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+    else {
+        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree, stream));
+    }
     h->prof.begin(0, stream);
     hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
                        (long long)windowStrideSamples, S, h->sums_d);
