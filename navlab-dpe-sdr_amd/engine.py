@@ -92,6 +92,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DpeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
                            % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 with the same SONAME as the system one
+        # this library links against.  Whichever is loaded first serves both; loading the system runtime first leaves
+        # torch with "No HIP GPUs are available".  So torch (when present) goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.dpe_last_error.restype = C.c_char_p
         for name in EXPORTS:

@@ -16,9 +16,10 @@ def bank_half_widths(pos_grid, vel_grid, fs, nfft):
 
 
 def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), init_delta=(0, 0, 0, 0), K=None,
-                    lpower=1):
+                    lpower=1, enable_ekf=False):
     """iq_windows: int16 [W, 2S] (host).  Returns fixes [W, 8] (= xCurrk1k1 per window) and the raw
-    per-window result dicts.  One window per Update, fix fed back to the channel manager."""
+    per-window result dicts.  One window per Update, fix fed back to the channel manager.
+    enable_ekf: route the fix through cuEKF's real filter (EnableEKF=true) instead of the shipped pass-through."""
     import torch
     iq_windows = np.ascontiguousarray(iq_windows)
     W, S2 = iq_windows.shape
@@ -36,15 +37,19 @@ def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
     x[:4] += np.asarray(init_delta, dtype=np.float64)
     iq_d = torch.from_numpy(iq_windows).to("cuda:0")
     fixes, results = np.zeros((W, 8)), []
+    ekf = engine.cuEKF(x, SampleLength=S / fs, EnableEKF=enable_ekf)
+    xk1k1, xkk1 = x, x
     for w in range(W):
-        (cm.Start if w == 0 else cm.Update)(x, x, time_grid)
+        (cm.Start if w == 0 else cm.Update)(xk1k1, xkk1, time_grid)
         cs, ce, bw = cm.outputs()
         bcs.Update(iq_d[w], cs)
         bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
         r = bcm.results()[0]
-        x = r["zVal"].copy()            # EKF_PassMeas: the ML point is the new state
-        fixes[w] = x
+        ekf.Update(r["zVal"], r["RVal"])    # EKF_PassMeas (the ML point is the new state) or the filter
+        xk1k1, xkk1 = ekf.xCurrk1k1.copy(), ekf.xCurrkk1.copy()
+        fixes[w] = xk1k1
         results.append(r)
+    ekf.Stop()
     cm.Stop()
     bcm.Stop()
     bcs.Stop()

@@ -87,16 +87,24 @@ def extend_handoff(ho, K_total, elev_min_deg=10.0):
     return out
 
 
-def build_windows(W, fs, S, K, seed=0, amp=48.0):
-    """-> iq int16 [W, 2S], chan_start [W,K], chan_end [W,K], bcm_window [W]."""
+def build_windows(W, fs, S, K, seed=0, amp=48.0, velocity=None, truth_out=None):
+    """-> iq int16 [W, 2S], chan_start [W,K], chan_end [W,K], bcm_window [W].
+    velocity: ECEF velocity (m/s, 3-vector) of the simulated receiver; None = static at the handoff position.
+    truth_out: optional list that receives the true state [8] at the START of every window."""
     ho = extend_handoff(handoff.read_handoff(HANDOFF_CSV), K)
     cm = engine.ChanMgr.from_handoff(ho, S / fs, K)
-    X = ho["X_ECEF"]
+    X0 = np.array(ho["X_ECEF"], dtype=np.float64)
     iq = np.empty((W, 2 * S), dtype=np.int16)
     cs = np.zeros((W, K), dtype=engine.CHAN_START_DTYPE)
     ce = np.zeros((W, K), dtype=engine.CHAN_END_DTYPE)
     bw = np.zeros(W, dtype=engine.BCM_WINDOW_DTYPE)
     for w in range(W):
+        X = X0.copy()
+        if velocity is not None:
+            X[:3] += np.asarray(velocity, dtype=np.float64) * (S / fs) * w
+            X[4:7] = velocity
+        if truth_out is not None:
+            truth_out.append(X.copy())
         (cm.Start if w == 0 else cm.Update)(X, X, (0.0,))
         s, e, win = cm.outputs()
         cs[w], ce[w], bw[w] = s, e, win[0]

@@ -532,3 +532,33 @@ def test_lag_windows_wider_than_32_samples(fs, S, L, scale):
     g = fs * 1.023e6 / (1.023e6 * 299792458.0)
     assert np.abs(case["pos"][:, 3]).max() * g > 40            # the grid reaches beyond the centre chunk
     helpers.assert_parity(out, ref, tol=TOL)
+
+
+@pytest.mark.parametrize("enable_ekf", [False, True])
+def test_closed_loop_with_a_moving_receiver(enable_ekf):
+    """System check of the loop the path lives in: a receiver moving at (5, -3, 2) m/s ECEF, samples synthesised from
+    the true trajectory, the estimator starting at the handoff position with ZERO velocity.
+    * The velocity manifold pulls the velocity state onto the truth within a few windows (to the 2 m/s grid).
+    * Position: at 2.5 Msps one sample is 120 m and the reference's score interpolates LINEARLY between integer lags,
+      so a sampled correlation triangle peaks at an integer lag for any sub-sample shift -- metre-level motion is
+      invisible to the position manifold (a property of the reference algorithm, reproduced by the oracle).  With the
+      shipped pass-through the position therefore stays put; with cuEKF's real filter (EnableEKF=true) the velocity
+      estimate carries it along through the F matrix."""
+    fs, S, K, W = 2.5e6, 50000, 8, 40
+    v = np.array([5.0, -3.0, 2.0])
+    truth = []
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=71, amp=200.0, velocity=v, truth_out=truth)
+    ho = dpe.workload.extend_handoff(dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV), K)
+    pos = dpe.synth.uniform_grid(9, 1.0)
+    vel = dpe.synth.uniform_grid(9, 2.0)
+    fixes, res = dpe.pipeline.run_closed_loop(iq, ho, fs, pos, vel, time_grid=np.unique(pos[:, 3]), K=K, enable_ekf=enable_ekf)
+    T = S / fs
+    end_truth = np.array(truth)[:, :3] + v * T              # the fix refers to the end of its window
+    perr = np.linalg.norm(fixes[:, :3] - end_truth, axis=1)
+    verr = np.linalg.norm(fixes[:, 4:7] - v, axis=1)
+    assert verr[0] > 5.0 and verr[15:].max() < 2.0, verr    # starts 6.2 m/s off, ends within the grid quantisation
+    if enable_ekf:
+        assert perr.max() < 2.0, perr                       # carried along by the velocity estimate
+    else:
+        assert abs(perr[-1] - np.linalg.norm(v) * T * W) < 0.5, perr   # pass-through: the position state does not move
+    assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res[5:])
