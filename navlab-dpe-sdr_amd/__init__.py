@@ -4,7 +4,7 @@ Python side = thin ctypes host layer over the C-ABI in csrc/ (include/dpe_hip.h)
 synthetic-input and file-format utilities.  Imported as `navlab_dpe_sdr_amd` through the
 root-level shim navlab_dpe_sdr_amd.py (the directory name carries a hyphen).
 """
-from . import engine, handoff, pipeline, sharding, synth, workload  # noqa: F401
+from . import engine, handoff, pipeline, rinex, sharding, synth, workload  # noqa: F401
 from .engine import Acquisition, BatchCorrManifold, BatchCorrScores, ChanMgr, DpeError, cuEKF  # noqa: F401
 
-__all__ = ["engine", "handoff", "pipeline", "sharding", "synth", "workload", "BatchCorrScores", "BatchCorrManifold", "ChanMgr", "Acquisition", "DpeError", "cuEKF"]
+__all__ = ["engine", "handoff", "pipeline", "rinex", "sharding", "synth", "workload", "BatchCorrScores", "BatchCorrManifold", "ChanMgr", "Acquisition", "DpeError", "cuEKF"]

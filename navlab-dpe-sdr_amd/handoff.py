@@ -11,7 +11,9 @@ EPH_FIELDS = ["sqrt_A", "e", "i_0", "OMEGA_0", "omega", "M_0", "delta_n", "OMEGA
               "a_f0", "a_f1", "a_f2", "T_GD"]
 
 
-def read_handoff(path):
+def read_handoff(path, rinex_path=None):
+    """Handoff CSV -> dict.  rinex_path: take the ephemerides from a RINEX nav file instead of the handoff rows, chosen
+    as the reference does (DPInit + cuChanMgr, see rinex.py)."""
     rows = {}
     with open(path, "r") as f:
         for line in f:
@@ -32,6 +34,10 @@ def read_handoff(path):
     out["cp_timestamp"] = np.array([int(float(v)) for v in rows["cp_timestamp"]], dtype=np.int32)
     out["TOW"] = np.array([int(float(v)) for v in rows["TOW"]], dtype=np.int32)
     K = out["prn_list"].size
+    if rinex_path is not None:
+        from . import rinex
+        out["eph"] = rinex.select_ephemerides(rinex.read_rinex_nav(rinex_path), out["prn_list"], out["rxTime"])
+        return out
     eph = np.zeros((K, len(EPH_FIELDS)))
     for j, name in enumerate(EPH_FIELDS):
         eph[:, j] = [float(v) for v in rows[name]]

@@ -24,7 +24,7 @@
 
 int main(int argc, char **argv)
 {
-    std::string samples, handoff, out = "XFile.csv", loadGrid;
+    std::string samples, handoff, out = "XFile.csv", loadGrid, rinex;
     double fs = 2.5e6, T = 0.02;
     int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
     bool useGraph = false, timing = false, enableEkf = false;
@@ -46,7 +46,24 @@ int main(int argc, char **argv)
             std::fwrite(tg.data(), sizeof(double), tg.size(), f);
             std::fclose(f);
             return 0;
+        } else if (a == "--dump-eph") {   // --dump-eph <rinex nav file> <seconds of week> <prn> [<prn> ...]: the ephemerides DPInit would pick (no GPU)
+            next(3);
+            std::vector<dsp::utils::RinexNavRecord> nav;
+            std::string err;
+            if (dsp::utils::read_rinex_nav(argv[i + 1], nav, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            std::vector<int> prns;
+            for (int j = i + 3; j < argc; ++j) prns.push_back(std::atoi(argv[j]));
+            std::vector<double> eph;
+            if (dsp::utils::select_ephemerides(nav, prns, std::atof(argv[i + 2]), eph, err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+            std::printf("%zu records\n", nav.size());
+            for (size_t p = 0; p < prns.size(); ++p) {
+                std::printf("%d", prns[p]);
+                for (int j = 0; j < 21; ++j) std::printf(",%.17g", eph[p * 21 + j]);
+                std::printf("\n");
+            }
+            return 0;
         } else if (a == "--samples") { samples = next(); ++i; }
+        else if (a == "--rinex") { rinex = next(); ++i; }
         else if (a == "--handoff") { handoff = next(); ++i; }
         else if (a == "--out") { out = next(); ++i; }
         else if (a == "--load-grid") { loadGrid = next(); ++i; }
@@ -96,6 +113,7 @@ int main(int argc, char **argv)
     CHECK(flow.SetModParam("SampleBlock", "RunLive", false));
     CHECK(flow.SetModParam("SampleBlock", "Filename", samples.c_str()));
     CHECK(flow.SetModParam("DPInit", "HandoffFilename", handoff.c_str()));
+    if (!rinex.empty()) CHECK(flow.SetModParam("DPInit", "RINEXFilename", rinex.c_str()));   // dpeflow.cpp:41-45,131
     CHECK(flow.SetModParam("DPInit", "InitDeltaX", delta[0]));
     CHECK(flow.SetModParam("DPInit", "InitDeltaY", delta[1]));
     CHECK(flow.SetModParam("DPInit", "InitDeltaZ", delta[2]));

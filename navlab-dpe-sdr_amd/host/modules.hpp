@@ -27,6 +27,7 @@
 #include "../../include/dpe_hip.h"
 #include "dsp.hpp"
 #include "grids.hpp"
+#include "rinex.hpp"
 
 namespace dsp {
 
@@ -46,6 +47,7 @@ class DPInit : public Module {
         ModuleName = "DPInit";
         AllocateOutputs(14);
         InsertParam("HandoffFilename", handoffFilename, CHAR_t, sizeof(handoffFilename), 0);
+        InsertParam("RINEXFilename", rinexFilename, CHAR_t, sizeof(rinexFilename), 0);   // dpinit.cpp:95
         InsertParam("InitDeltaX", &delta[0], FLOAT_t, sizeof(float), sizeof(float));
         InsertParam("InitDeltaY", &delta[1], FLOAT_t, sizeof(float), sizeof(float));
         InsertParam("InitDeltaZ", &delta[2], FLOAT_t, sizeof(float), sizeof(float));
@@ -92,10 +94,22 @@ class DPInit : public Module {
             fc[k] = std::atof(rows["fc"][k].c_str()); fi[k] = std::atof(rows["fi"][k].c_str());
             cp[k] = (int)std::atof(rows["cp"][k].c_str()); cpRef[k] = (int)std::atof(rows["cp_timestamp"][k].c_str());
             tow[k] = (int)std::atof(rows["TOW"][k].c_str());
-            for (int j = 0; j < DPE_EPH_N; ++j) {
+            for (int j = 0; j < DPE_EPH_N && !rinexFilename[0]; ++j) {   // with a RINEX file the rows are not needed
                 if (rows.find(ephKeys[j]) == rows.end() || (int)rows[ephKeys[j]].size() < K) DPE_MOD_FAIL("handoff file lacks ephemeris row " << ephKeys[j]);
                 eph[(size_t)k * DPE_EPH_N + j] = std::atof(rows[ephKeys[j]][k].c_str());
             }
+        }
+        // Ephemerides: the reference takes them from a RINEX nav file (dpinit.cpp:130-144) and lets cuChanMgr pick the set
+        // closest in toe (cuchanmgr.cu:269-299); PyGNSS' handoff file carries the same broadcast values as rows.  With a
+        // RINEXFilename set the RINEX data win (checked against the handoff rows to 1e-11 on the reference's demofiles).
+        if (rinexFilename[0]) {
+            std::vector<dsp::utils::RinexNavRecord> nav;
+            std::string err;
+            if (dsp::utils::read_rinex_nav(rinexFilename, nav, err)) DPE_MOD_FAIL(err);
+            std::vector<int> prns(prn.begin(), prn.end());
+            std::vector<double> sel;
+            if (dsp::utils::select_ephemerides(nav, prns, rxTime, sel, err)) DPE_MOD_FAIL(err);
+            eph = sel;
         }
         void *data[12] = {&startByte, X, prn.data(), rc.data(), ri.data(), fc.data(), fi.data(), cp.data(), cpRef.data(), tow.data(), &rxTime, eph.data()};
         const uint32_t len[12] = {1, 8, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, (uint32_t)K, 1, (uint32_t)K};
@@ -107,7 +121,7 @@ class DPInit : public Module {
     int Update(void *) override { return (++loop >= maxIter) ? -1 : 0; }   // dpinit.cpp:224-235 (3000 there)
 
   private:
-    char handoffFilename[512] = "";
+    char handoffFilename[512] = "", rinexFilename[512] = "";
     float delta[4] = {0, 0, 0, 0};
     int maxIter = 3000, loop = 0, K = 0;
     long long startByte = 0;

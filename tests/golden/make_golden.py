@@ -17,6 +17,7 @@ reference callables that the CUDA authors used as their oracle (SURVEY.md sectio
   O6 NavigationGuesses.generate_spread_grid      receiver.py:995-1026
   O7 Receiver.dp_track internals (one iteration) receiver.py:205-397, channel.py:194-245
   O8 Correlator.coarse_acquisition               correlator.py:53-103
+  O11 libgnss/rinex.py parse_rinex on an excerpt of the reference's demofiles/nist1860.18n (data file)
   O10 ExtendedKalmanFilter._time_update_m5 / _measurement_update_m5 (the real filter, vector/ekf.py:160-178)
   O9 Correlator.search_signal (coarse + fine_frequency_acquisition) on two consecutive windows and
      Receiver.scalar_acquisition's keep-the-better rule   correlator.py:38-51,105-133; receiver.py:452-520
@@ -160,8 +161,38 @@ def make_o10(pg):
     np.savez_compressed(os.path.join(HERE, "o10_ekf.npz"), x0=x0, T=T, **out)
 
 
+def make_o11(pg):
+    """O11: an excerpt of the reference's RINEX navigation DATA file (header, the stale 2015 record it starts with,
+    and every record of the handoff PRNs) + what the reference's Python parser returns for each of those PRNs
+    (its rule: the FIRST record of the PRN in the file)."""
+    from pythonreceiver.libgnss import rinex as pr
+    src = os.path.join(REF, "demofiles", "nist1860.18n")
+    ho = dpe.handoff.read_handoff(os.path.join(REF, "demofiles", "handoff_params_usrp6.csv"))
+    keep = set(int(p) for p in ho["prn_list"]) | {4}
+    with open(src) as f:
+        lines = f.read().splitlines()
+    h = next(i for i, l in enumerate(lines) if "END OF HEADER" in l) + 1
+    out = lines[:h]
+    for i in range(h, len(lines) - 7, 8):
+        if int(lines[i][0:2]) in keep:
+            out += lines[i:i + 8]
+    dst = os.path.join(HERE, "o11_nist1860_excerpt.18n")
+    with open(dst, "w") as f:
+        f.write("\n".join(out) + "\n")
+    prns = sorted(keep)
+    exp = np.zeros((len(prns), len(dpe.handoff.EPH_FIELDS)))
+    for k, p in enumerate(prns):
+        e = pr.parse_rinex(dst, p)
+        exp[k] = [float(getattr(e, name)) for name in dpe.handoff.EPH_FIELDS]
+    np.savez_compressed(os.path.join(HERE, "o11_rinex.npz"), prns=np.array(prns), eph_first=exp,
+                        handoff_prns=ho["prn_list"], handoff_eph=ho["eph"], handoff_rxTime=ho["rxTime"])
+
+
 def main():
     pg = import_pygnss()
+    if "--only-o11" in sys.argv:
+        make_o11(pg)
+        return
     if "--only-o9" in sys.argv:
         make_o9(pg)
         return
@@ -315,6 +346,7 @@ def main():
     rf.close_rawfile()
     make_o9(pg)
     make_o10(pg)
+    make_o11(pg)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

@@ -216,6 +216,13 @@ def test_cpp_flow_matches_python_closed_loop(tmp_path):
     assert np.abs(rows - fixes).max() < 1e-6                       # %f rows vs doubles
     assert np.abs(fixes[:, :3] - ho["X_ECEF"][:3]).max() < 1.0     # position fix within 1 m of truth
     assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res)
+    # RINEXFilename set (what the reference's DPInit requires, dpinit.cpp:130-144): ephemerides from the nav file,
+    # closest toe; the same broadcast values as the handoff rows to 12 digits -> the same fixes
+    rnx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "o11_nist1860_excerpt.18n")
+    out3 = str(tmp_path / "X_rinex.csv")
+    subprocess.check_call([exe, "--samples", dat, "--handoff", ho_path, "--out", out3, "--iters", str(W), "--grid-dim", "9",
+                           "--spacing", "1.0", "--rinex", rnx])
+    assert np.abs(np.loadtxt(out3, delimiter=",") - rows).max() < 1e-5
     # EnableEKF=true (the reference ships it off, dpeflow.cpp:90): the fix goes through the 8-state filter
     # (dpe_ekf_*, StepUpdate + StepPredict per window) before it is fed back; a static receiver stays on the truth
     out2 = str(tmp_path / "X_ekf.csv")
