@@ -170,7 +170,10 @@ typedef struct dpe_bcm_result {
 
 int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out);     /* BatchCorrManifold::Start :2315-2463 */
 int dpe_bcm_destroy(dpe_bcm *h);                                   /* ::Stop :2467-2498 */
-/* BatchCorrManifold::Update :2502-2635 for nWindows windows.  Asynchronous on `stream`. */
+/* BatchCorrManifold::Update :2502-2635 for nWindows windows.  Asynchronous on `stream`; win_host / chan_host are
+ * consumed before the call returns.  One launch scores both manifolds; its last block writes the arg-max keys and
+ * out-of-window counts into pinned host memory, so dpe_bcm_results only synchronises.  A handle serves ONE stream at a
+ * time (its key sets, ticket counter and result mirror are per handle): give concurrent streams their own handles. */
 int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev,
                    int32_t nWindows, int32_t nChan, const dpe_bcm_window *win_host,
                    const dpe_chan_end *chan_host, dpe_stream_t stream);
