@@ -94,3 +94,13 @@ def test_host_grid_builders_match_oracle(built, oracle, tmp_path, gtype, dim, sp
     assert np.array_equal(raw[:4 * G].reshape(G, 4), og) and np.array_equal(raw[4 * G:], otg)
     if gtype == 0:
         assert np.array_equal(og, dpe.synth.uniform_grid(dim, sp))
+
+
+def test_host_module_and_flow_interface(built):
+    """C++ mirror of dsp::Module / dsp::Flow (host/dsp.hpp, host/modules.hpp): parameter typing, port validation by
+    ValueType + VectorLength, wiring by names, Start roll-back, Update-before-Start -- the reference's rules
+    (module.cpp:21-63,284-320; flow.cu:28-87,212-324).  host/test_modules.cpp, no GPU work."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "test_modules")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
