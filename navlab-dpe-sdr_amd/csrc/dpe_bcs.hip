@@ -26,6 +26,19 @@ constexpr int kSub = 256;   // samples per wave sub-tile (4 per lane) == moment 
 constexpr int kNMomMax = 6;  // power moments 0..5 at most; 4 when the bin window is narrow (chosen at create)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Complex product {a.x b.x - a.y b.y, a.x b.y + a.y b.x} in TWO packed instructions.  The compiler's own lowering of
+// the same expression is pk_mul + two pk_fma (one per sign) + a v_mov to stitch the halves; the operand-select and
+// lane-negate modifiers of v_pk_fma_f32 do it directly:  t = a.x * b;  r = {-a.y, a.y} * {b.y, b.x} + t.
+__device__ __forceinline__ f2 cmul(f2 a, f2 b)
+{
+    f2 t, r;
+    // (s_nop: the inputs may come straight from v_sin/v_cos or an SDWA convert; the compiler's hazard recogniser does
+    //  not look inside inline asm, so the wait states those producers need are spelled out here)
+    asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+
 struct BcsChanDev {
     double rc;        // code phase at sample 0 (chips)
     double codeStep;  // chips per sample  = fc / fs
@@ -345,6 +358,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
     const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;   // chip span of one pass fits the extended table
     float mRe, mIm;
     window_mean(sums, w, nSumBlk, S, mRe, mIm);
+    const f2 meanv = f2{mRe, mIm}, rotv = f2{ch.rotRe, ch.rotIm};
     const int16_t *x = iq + (size_t)w * winStride * 2;
     const float xbase = (float)(16 * (lane & 15)) - 127.5f;      // moment abscissa of the lane's first sample
     __syncthreads();
@@ -418,39 +432,33 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                         rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
                     }
                     // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300): fp64 phase
-                    // seed, hardware sin/cos in revolutions, then 7 fp32 rotations
+                    // seed, hardware sin/cos in revolutions, then 7 fp32 rotations -- complex products through cmul()
                     double ph = carr_phase<TABLE>(ch, tT, ns < S ? ns : S - 1);   // lanes past the window carry zero samples
                     ph -= floor(ph);
                     const float f = (float)ph;
-                    float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
+                    f2 wv = f2{__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f)};
                     const float xs = xbase + (float)(8 * seg);
+                    const bool inside = ns + 7 < S;   // false only for lanes of the window's last pass
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const float re = (float)(short)(raw[i] & 0xFFFF), im = (float)(raw[i] >> 16);
-                        // rawWiped = raw * wipe (BCS_BatchMultiply :402)
-                        const float br = re * wr - im * wi;
-                        const float bi = re * wi + im * wr;
+                        const f2 rawv = f2{(float)(short)(raw[i] & 0xFFFF), (float)(raw[i] >> 16)};
+                        const f2 bb = cmul(rawv, wv);                      // rawWiped = raw * wipe (BCS_BatchMultiply :402)
                         // sample n, lag l = j-LH uses replica index n-l -> rr[i - j + 2 LH]
-                        const f2 bb = f2{br, bi};
 #pragma unroll
                         for (int j = 0; j < NL; ++j) {
                             const float r = rr[i + 2 * LH - j];
                             acc[j] = __builtin_elementwise_fma(bb, f2{r, r}, acc[j]);
                         }
                         // carrier path: (raw - mean) * wipe * replica (:480, :440-448)
-                        const float r0 = (ns + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
-                        const float cr = (br - (mRe * wr - mIm * wi)) * r0;
-                        const float cim = (bi - (mRe * wi + mIm * wr)) * r0;
-                        f2 cp = f2{cr, cim};   // x^p * c, built up by one packed multiply per order
+                        const float r0 = (inside || ns + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
+                        f2 cp = (bb - cmul(meanv, wv)) * r0;               // x^p * c, built up by one packed multiply per order
                         const float xp = xs + (float)i;
 #pragma unroll
                         for (int p = 0; p < kNMom; ++p) {
                             M[p] += cp;
                             cp *= xp;
                         }
-                        const float nr = wr * ch.rotRe - wi * ch.rotIm;
-                        wi = wr * ch.rotIm + wi * ch.rotRe;
-                        wr = nr;
+                        wv = cmul(wv, rotv);
                     }
                 }
             }
