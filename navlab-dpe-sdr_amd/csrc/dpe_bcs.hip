@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                 double ph = carr_phase<TABLE>(ch, tT, n0 < S ? n0 : S - 1);   // lanes past the window carry zero samples
                 ph -= floor(ph);
                 const float f = (float)ph;
-                float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
+                f2 wv = f2{__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f)};
+                const f2 meanv = f2{mRe, mIm}, rotv = f2{ch.rotRe, ch.rotIm};
                 float rr[NRR];
 #pragma unroll
                 for (int q = 0; q < NRR / 4; ++q) {
@@ -259,11 +260,9 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    // rawWiped = raw * wipe (BCS_BatchMultiply :402)
-                    const float br = re[i] * wr - im[i] * wi;
-                    const float bi = re[i] * wi + im[i] * wr;
+                    // rawWiped = raw * wipe (BCS_BatchMultiply :402); complex products through cmul()
+                    const f2 bb = cmul(f2{re[i], im[i]}, wv);
                     // sample n, lag l = j-LH uses replica index n-l -> rr[i - j + 2 LH]
-                    const f2 bb = f2{br, bi};
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
                         const float r = rr[i + 2 * LH - j];
@@ -271,17 +270,13 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                     }
                     // carrier path: (raw - mean) * wipe * replica (:480, :440-448)
                     const float r0 = (n0 + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
-                    const float cr = (br - (mRe * wr - mIm * wi)) * r0;
-                    const float cim = (bi - (mRe * wi + mIm * wr)) * r0;
-                    f2 cp = f2{cr, cim};   // x^p * c, built up by one packed multiply per order
+                    f2 cp = (bb - cmul(meanv, wv)) * r0;   // x^p * c, built up by one packed multiply per order
 #pragma unroll
                     for (int p = 0; p < kNMom; ++p) {
                         M[p] += cp;
                         cp *= xp[i];
                     }
-                    const float nr = wr * ch.rotRe - wi * ch.rotIm;
-                    wi = wr * ch.rotIm + wi * ch.rotRe;
-                    wr = nr;
+                    wv = cmul(wv, rotv);
                 }
             }
             if (sub < nSub && lagShift == 0) {   // the Doppler path belongs to the unshifted replica only
@@ -603,19 +598,18 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
                     double ph = carr_phase<TABLE>(ch, tT, nn);
                     ph -= floor(ph);
                     const float f = (float)ph;
-                    float wr = __builtin_amdgcn_cosf(f), wi = -__builtin_amdgcn_sinf(f);
+                    f2 wv = f2{__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f)};
+                    const f2 rotv = f2{ch.rotRe, ch.rotIm};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (n0 + i == S) {   // phase restarts where the circular continuation begins
                             double p2 = ch.ri - floor(ch.ri);
-                            wr = __builtin_amdgcn_cosf((float)p2); wi = -__builtin_amdgcn_sinf((float)p2);
+                            wv = f2{__builtin_amdgcn_cosf((float)p2), -__builtin_amdgcn_sinf((float)p2)};
                         }
-                        wown[i] = f2{wr, wi};
-                        bown[i] = f2{re[i] * wr - im[i] * wi, re[i] * wi + im[i] * wr};
+                        wown[i] = wv;
+                        bown[i] = cmul(f2{re[i], im[i]}, wv);
                         sB[wave][LH + 4 * lane + i] = make_float2(bown[i].x, bown[i].y);
-                        const float nr = wr * ch.rotRe - wi * ch.rotIm;
-                        wi = wr * ch.rotIm + wi * ch.rotRe;
-                        wr = nr;
+                        wv = cmul(wv, rotv);
                     }
                 }
                 {   // halo: lanes 0..31 -> n = sub0-LH+lane ; lanes 32..63 -> n = sub0+256+(lane-32)
@@ -637,9 +631,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
                     const float rl = real ? sRep[wave][4 * lane + i + 1 + LH] : 0.f;   // r[n + LH]
                     acc0 = __builtin_elementwise_fma(bown[i], f2{rl, rl}, acc0);
                     const float r0 = real ? sRep[wave][4 * lane + i + 1] : 0.f;        // r[n]
-                    const float cr = (bown[i].x - (mRe * wown[i].x - mIm * wown[i].y)) * r0;
-                    const float cim = (bown[i].y - (mRe * wown[i].y + mIm * wown[i].x)) * r0;
-                    f2 cp = f2{cr, cim};
+                    f2 cp = (bown[i] - cmul(f2{mRe, mIm}, wown[i])) * r0;
 #pragma unroll
                     for (int p = 0; p < kNMom; ++p) {
                         M[p] += cp;
