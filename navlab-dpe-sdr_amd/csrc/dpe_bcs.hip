@@ -18,6 +18,8 @@
 // chip table int8 [37][1024] -> LDS per block; replica +/-1 (nav-bit side masked) per wave
 // sub-tile in LDS; per-block partial lag sums and per-sub-tile moments in global scratch,
 // reduced in fixed order (no float atomics: bit-reproducible run to run).
+#include <type_traits>
+
 #include "dpe_common.h"
 
 namespace dpe {
@@ -29,14 +31,22 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // Complex product {a.x b.x - a.y b.y, a.x b.y + a.y b.x} in TWO packed instructions.  The compiler's own lowering of
 // the same expression is pk_mul + two pk_fma (one per sign) + a v_mov to stitch the halves; the operand-select and
 // lane-negate modifiers of v_pk_fma_f32 do it directly:  t = a.x * b;  r = {-a.y, a.y} * {b.y, b.x} + t.
+// Inline asm is opaque to the compiler's hazard recogniser: operands that come straight from a transcendental
+// (v_sin / v_cos need one wait state before a VALU consumer on gfx94x/95x) must go through wipe_seed() first.
 __device__ __forceinline__ f2 cmul(f2 a, f2 b)
 {
     f2 t, r;
-    // (s_nop: the inputs may come straight from v_sin/v_cos or an SDWA convert; the compiler's hazard recogniser does
-    //  not look inside inline asm, so the wait states those producers need are spelled out here)
-    asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
     return r;
+}
+
+// conj(exp(j 2 pi f)) from the hardware sin/cos (argument in revolutions), safe to feed into cmul()
+__device__ __forceinline__ f2 wipe_seed(float f)
+{
+    f2 w = f2{__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f)};
+    asm volatile("s_nop 1" : "+v"(w));   // covers the trans -> VALU forwarding hazard for the asm consumers
+    return w;
 }
 
 struct BcsChanDev {
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                 double ph = carr_phase<TABLE>(ch, tT, n0 < S ? n0 : S - 1);   // lanes past the window carry zero samples
                 ph -= floor(ph);
                 const float f = (float)ph;
-                f2 wv = f2{__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f)};
+                f2 wv = wipe_seed(f);
                 const f2 meanv = f2{mRe, mIm}, rotv = f2{ch.rotRe, ch.rotIm};
                 float rr[NRR];
 #pragma unroll
@@ -430,8 +440,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                     // seed, hardware sin/cos in revolutions, then 7 fp32 rotations -- complex products through cmul()
                     double ph = carr_phase<TABLE>(ch, tT, ns < S ? ns : S - 1);   // lanes past the window carry zero samples
                     ph -= floor(ph);
-                    const float f = (float)ph;
-                    f2 wv = f2{__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f)};
+                    f2 wv = wipe_seed((float)ph);
                     const float xs = xbase + (float)(8 * seg);
                     const bool inside = ns + 7 < S;   // false only for lanes of the window's last pass
 #pragma unroll
@@ -598,13 +607,13 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
                     double ph = carr_phase<TABLE>(ch, tT, nn);
                     ph -= floor(ph);
                     const float f = (float)ph;
-                    f2 wv = f2{__builtin_amdgcn_cosf(f), -__builtin_amdgcn_sinf(f)};
+                    f2 wv = wipe_seed(f);
                     const f2 rotv = f2{ch.rotRe, ch.rotIm};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (n0 + i == S) {   // phase restarts where the circular continuation begins
                             double p2 = ch.ri - floor(ch.ri);
-                            wv = f2{__builtin_amdgcn_cosf((float)p2), -__builtin_amdgcn_sinf((float)p2)};
+                            wv = wipe_seed((float)p2);
                         }
                         wown[i] = wv;
                         bown[i] = cmul(f2{re[i], im[i]}, wv);
