@@ -189,10 +189,21 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # Inside the timed region only the dominant kernel (the fused scan, `roofline`) carries HIP events: a pair of
-    # events around every kernel costs ~2 % of the step (measured: 0.948 vs 0.928 ms).  The other kernels are timed
-    # in a short extra pass afterwards (`kernels_ms_per_step`, informational).
+    # Untimed side pass: per-kernel HIP events on every kernel, for `kernels_ms_per_step` (informational).  It runs
+    # BEFORE the timed region so that it also serves as clock warm-up (the first ~20 launches of a fresh process run
+    # 5-10 % slower; rocprofv3 per-launch trace, profiles/README.md).
+    extra = max(5, min(20, args.steps))
+    bcs.profile(True); bcm.profile(True)
+    for _ in range(extra):
+        step()
+    fence()
+    kern_extra = bcs.profile(False)
+    bcm.profile(False)
+    # Timed region: only the dominant kernel (the fused scan, `roofline`) carries HIP events -- a pair of events
+    # around every kernel costs ~2 % of the step (measured: 0.948 vs 0.928 ms).
     bcm.profile(True)
+    if os.environ.get("DPE_BENCH_EVENTS") == "all":   # experiment: events around every kernel inside the timed region
+        bcs.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -200,12 +211,8 @@ def main():
     dt = time.perf_counter() - t0
     kern = {}
     kern.update(bcm.profile(False))
-    extra = max(5, min(20, args.steps))
-    bcs.profile(True)
-    for _ in range(extra):
-        step()
-    fence()
-    kern_extra = bcs.profile(False)
+    if os.environ.get("DPE_BENCH_EVENTS") == "all":
+        bcs.profile(False)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

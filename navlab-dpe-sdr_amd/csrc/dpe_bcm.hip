@@ -337,8 +337,12 @@ struct dpe_bcm {
     std::vector<double> posGrid_h, velGrid_h;  // local shard, fp64 (for zVal)
     float4 *posGrid_d = nullptr, *velGrid_d = nullptr;
     float *posScores_d = nullptr, *velScores_d = nullptr;
-    dpe::BcmSvDev *sv_d = nullptr, *sv_h = nullptr;  // [2][W][maxK]  (manifold-major)
-    hipEvent_t stagingFree = nullptr;   // recorded after the batch path's H2D copy of sv_h
+    dpe::BcmSvDev *sv_d = nullptr;  // [2][W][maxK]  (manifold-major)
+    // pinned staging ring (see dpe_bcs): Updates may be issued kStaging - 1 deep without waiting
+    static constexpr int kStaging = 4;
+    dpe::BcmSvDev *svBase_h = nullptr, *sv_h = nullptr;
+    hipEvent_t stagingFree[kStaging] = {};
+    int slot = 0;
     unsigned long long *keys_d = nullptr;  // [2 sets][{keys [W][2], counts [W][2]}], alternating between Updates
     int cur = 1;                           // set of the latest Update
     unsigned int *done_d = nullptr;        // finished-block ticket of the scan kernel (returns to 0 by itself)
@@ -481,7 +485,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->wsumHalf = (size_t)(dpe_bcm::kMaxSplit + 8 * W) * 5;   // >= nWindows * blocks-per-window of any launch
     h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
     if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->wsum_d ||
-        hipHostMalloc((void **)&h->sv_h, 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->svBase_h, dpe_bcm::kStaging * 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->keys_h, 4 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
         dpe_bcm_destroy(h);
@@ -493,7 +497,8 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
     h->oob_h = h->keys_h + 2 * W;
-    DPE_CHECK_HIP(hipEventCreateWithFlags(&h->stagingFree, hipEventDisableTiming));
+    h->sv_h = h->svBase_h;
+    for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     DPE_CHECK_HIP(hipMemset(h->keys_d, 0, 8 * W * sizeof(unsigned long long)));
     h->done_d = dev_alloc<unsigned int>(1);
     DPE_REQUIRE(h->done_d, "[BatchCorrManifold] create: device allocation failed");
@@ -509,9 +514,10 @@ int dpe_bcm_destroy(dpe_bcm *h)
     if (!h) return 0;
     void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d, h->done_d};
     for (void *b : bufs) (void)hipFree(b);
-    if (h->sv_h) (void)hipHostFree(h->sv_h);
+    if (h->svBase_h) (void)hipHostFree(h->svBase_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
-    if (h->stagingFree) (void)hipEventDestroy(h->stagingFree);
+    for (hipEvent_t e : h->stagingFree)
+        if (e) (void)hipEventDestroy(e);
     h->graphs.clear();
     delete h;
     return 0;
@@ -529,7 +535,9 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     const int maxK = h->cfg.maxChannels, W = h->cfg.maxWindows;
     const double fs = h->cfg.samplingFrequency, Cf = (double)h->cfg.numFFTPoints;
     bool posInside = true, velInside = true;   // every index provably inside the banks?
-    DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree));   // a previous batch Update may still be copying sv_h
+    h->slot = (h->slot + 1) % dpe_bcm::kStaging;          // next staging block; an Update kStaging calls ago may still be copying it
+    DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree[h->slot]));
+    h->sv_h = h->svBase_h + (size_t)h->slot * 2 * h->cfg.maxWindows * h->cfg.maxChannels;
     for (int w = 0; w < nWindows; ++w) {
         const dpe_bcm_window &win = win_host[w];
         DPE_REQUIRE(win.dopplerSign == 1 || win.dopplerSign == -1, "[BatchCorrManifold] Update: dopplerSign must be +/-1");
@@ -592,9 +600,10 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     GraphCache::Guard graphGuard{h->graphs, stream};
     if (h->graphs.enabled && !h->prof.enabled) {
         const int rc = h->graphs.begin({codeBank_dev, carrBank_dev, 0, nWindows, nChan,
-                                        (posInside ? 1 : 0) | (velInside ? 2 : 0) | (use << 2), stream}, stream);
+                                        (posInside ? 1 : 0) | (velInside ? 2 : 0) | (use << 2) | (h->slot << 8), stream}, stream);
         DPE_REQUIRE(rc >= 0, "[BatchCorrManifold] Update: hipGraph capture/replay failed");
         if (rc == 1) {
+            DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));   // the replayed graph reads this slot
             h->cur = use;
             return 0;
         }
@@ -608,7 +617,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         memcpy(pb.s[1], h->sv_h + (size_t)W * maxK, sizeof(BcmSvDev) * nChan);
     } else {
         DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
-        if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree, stream));
+        if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     }
     const int nLag = 2 * L + 1, nBin = 2 * B + 1;
     ScanLaunch a;
@@ -629,7 +638,9 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     h->prof.begin(0, stream);
     launch_scan(!posInside, !velInside, h->cfg.weightedMean != 0, a);
     h->prof.end(0, stream);
+    const bool captured = h->graphs.capturing;
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrManifold] Update: hipGraph instantiate/launch failed");
+    if (captured) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     DPE_CHECK_HIP(hipGetLastError());
     h->cur = use;
     return 0;

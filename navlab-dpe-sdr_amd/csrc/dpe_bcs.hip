@@ -908,8 +908,12 @@ struct dpe_bcs {
     bool useTable = false;
     long long *sums_d = nullptr;
     dpe::BcsChanDev *chan_d = nullptr;
-    dpe::BcsChanDev *chan_h = nullptr;  // pinned staging
-    hipEvent_t stagingFree = nullptr;   // recorded after the batch path's H2D copy of chan_h: the next Update may refill it
+    // pinned parameter staging: a ring of kStaging blocks, each guarded by an event recorded once its H2D copy (or the
+    // graph that contains it) has been enqueued -- Updates may be issued kStaging - 1 deep without waiting
+    static constexpr int kStaging = 4;
+    dpe::BcsChanDev *chanBase_h = nullptr, *chan_h = nullptr;
+    hipEvent_t stagingFree[kStaging] = {};
+    int slot = 0;
     float2 *part_d = nullptr, *mom_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
     int *info_d = nullptr;
     int lastW = 0, lastK = 0, lastSumBlocks = 1;
@@ -999,7 +1003,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
     h->info_d = dev_alloc<int>(W * K);
     if (!h->tTable_d || !h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->codeBank_d || !h->carrBank_d ||
-        !h->info_d || hipHostMalloc((void **)&h->chan_h, W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
+        !h->info_d || hipHostMalloc((void **)&h->chanBase_h, dpe_bcs::kStaging * W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrScores] create: device allocation failed");
         dpe_bcs_destroy(h);
         return -1;
@@ -1008,7 +1012,8 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
     DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
     h->idxNext_h.assign(W * K, 0);
-    DPE_CHECK_HIP(hipEventCreateWithFlags(&h->stagingFree, hipEventDisableTiming));
+    h->chan_h = h->chanBase_h;
+    for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->wideAllowed = getenv("DPE_BCS_NO_WIDE") == nullptr;
     h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
     *out = h;
@@ -1020,8 +1025,9 @@ int dpe_bcs_destroy(dpe_bcs *h)
     if (!h) return 0;
     void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->codeBank_d, h->carrBank_d, h->info_d};
     for (void *b : bufs) (void)hipFree(b);
-    if (h->chan_h) (void)hipHostFree(h->chan_h);
-    if (h->stagingFree) (void)hipEventDestroy(h->stagingFree);
+    if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
+    for (hipEvent_t e : h->stagingFree)
+        if (e) (void)hipEventDestroy(e);
     h->graphs.clear();
     delete h;
     return 0;
@@ -1038,8 +1044,10 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     DPE_REQUIRE(nWindows == 1 || windowStrideSamples >= S, "[BatchCorrScores] Update: window stride < S");
     hipStream_t stream = (hipStream_t)stream_;
     const double fs = h->cfg.samplingFrequency;
-    // a previous batch Update may still be copying the pinned staging block (no-op when it has finished / never ran)
-    DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree));
+    // next staging block of the ring; an Update issued kStaging calls ago may still be copying it (no-op otherwise)
+    h->slot = (h->slot + 1) % dpe_bcs::kStaging;
+    DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree[h->slot]));
+    h->chan_h = h->chanBase_h + (size_t)h->slot * h->cfg.maxWindows * h->cfg.maxChannels;
     for (int i = 0; i < nWindows * nChan; ++i) {
         const dpe_chan_start &c = chan_host[i];
         DPE_REQUIRE(c.prn >= 1 && c.prn <= kPrnMax, "[BatchCorrScores] Update: PRN %d out of range", c.prn);
@@ -1071,9 +1079,12 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->lastSumBlocks = sumBlocks;
     if (useGraph) {
         const int rc = h->graphs.begin({samples_dev, nullptr, (long long)windowStrideSamples, nWindows, nChan,
-                                        (h->wideAllowed ? 1 : 0) | (h->bank16Allowed ? 2 : 0), stream}, stream);
+                                        (h->wideAllowed ? 1 : 0) | (h->bank16Allowed ? 2 : 0) | (h->slot << 8), stream}, stream);
         DPE_REQUIRE(rc >= 0, "[BatchCorrScores] Update: hipGraph capture/replay failed");
-        if (rc == 1) return 0;
+        if (rc == 1) {
+            DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));   // the replayed graph reads this slot
+            return 0;
+        }
     }
     // few channels (the per-window call of a running receiver): parameters travel as kernel arguments of
     // the bank / finalize kernels; batches go through one H2D copy from the pinned staging block.  A
@@ -1083,7 +1094,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     if (inl) memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
     else {
         DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
-        if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree, stream));
+        if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     }
     h->prof.begin(0, stream);
     hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
@@ -1179,7 +1190,9 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
                            h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
     h->prof.end(2, stream);
     }   // chunk
+    const bool captured = h->graphs.capturing;
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrScores] Update: hipGraph instantiate/launch failed");
+    if (captured) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     DPE_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --no-cpu-baseline \
     > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err
 cp $OUT/${TAG}_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
