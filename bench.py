@@ -192,7 +192,7 @@ def main():
     # Untimed side pass: per-kernel HIP events on every kernel, for `kernels_ms_per_step` (informational).  It runs
     # BEFORE the timed region so that it also serves as clock warm-up (the first ~20 launches of a fresh process run
     # 5-10 % slower; rocprofv3 per-launch trace, profiles/README.md).
-    extra = max(5, min(20, args.steps))
+    extra = 24   # ~22 ms: enough for the clocks to settle whatever --warmup / --steps are
     bcs.profile(True); bcm.profile(True)
     for _ in range(extra):
         step()
