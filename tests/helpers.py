@@ -108,7 +108,7 @@ def pack_gpu_inputs(case):
     return iq, cs, ce, bw
 
 
-def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True):
+def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True, repeats=1):
     import torch
     iq, cs, ce, bw = pack_gpu_inputs(case)
     W, K = cs.shape
@@ -121,8 +121,9 @@ def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True):
                                 lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K,
                                 write_scores=write_scores, weighted_mean=weighted_mean)
     bcm.Start()
-    bcs.Update(iq_d, cs)
-    bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+    for _ in range(repeats):          # same handles, back-to-back Updates (staging ring, alternating key sets)
+        bcs.Update(iq_d, cs)
+        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
     res = bcm.results()
     code, carr = bcs.read_banks()
     idx_next, no_flip, mean = bcs.read_info()

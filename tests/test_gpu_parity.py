@@ -572,3 +572,13 @@ def test_closed_loop_with_a_moving_receiver(enable_ekf):
     else:
         assert abs(perr[-1] - np.linalg.norm(v) * T * W) < 0.5, perr   # pass-through: the position state does not move
     assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res[5:])
+
+
+def test_parameter_copy_path_for_small_batches():
+    """W x K = 2 x 20 = 40 (window, channel) pairs: just above the 37 that travel as kernel arguments, so the
+    parameters go through the pinned staging ring + H2D copy with the few-window kernel shapes; repeated Updates
+    cycle through all staging slots."""
+    case = helpers.make_case(seed=83, S=12500, K=20, G=2048, amp=120.0, W=2)
+    ref = helpers.run_oracle(case, 8, 32)
+    out = helpers.run_gpu(case, 8, 32, repeats=6)   # more back-to-back calls on one handle than staging slots
+    helpers.assert_parity(out, ref, tol=TOL)
