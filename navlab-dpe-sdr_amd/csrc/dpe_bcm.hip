@@ -680,19 +680,23 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
     DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int W = h->lastW;
     const unsigned long long *keys = h->keys_h, *oob = h->oob_h;
-    std::vector<double> ws(2 * h->wsumHalf, 0.0);
-    if (h->cfg.weightedMean)
+    std::vector<double> ws;   // per-block weighted sums: fetched only when the estimator is on (this call sits on the
+                              // closed loop's critical path: no 300 KB of scratch per window otherwise)
+    if (h->cfg.weightedMean) {
+        ws.resize(2 * h->wsumHalf);
         DPE_CHECK_HIP(hipMemcpy(ws.data(), h->wsum_d, sizeof(double) * 2 * h->wsumHalf, hipMemcpyDeviceToHost));
+    }
     for (int w = 0; w < W; ++w) {
         dpe_bcm_result &r = results[w];
         // "Method 1" score-weighted mean of the manifold (BCM_PosMeasReduction / BCM_ReduceAndPosMeas,
         // batchcorrmanifold.cu:816-1056,1365-1510; PyGNSS receiver.py:317-318): LOCAL shard only
-        double m[2][5];
+        double m[2][5] = {};
         for (int slot = 0; slot < 2; ++slot) {
-            for (int j = 0; j < 5; ++j) m[slot][j] = 0.0;
-            const double *base = ws.data() + slot * h->wsumHalf + (size_t)w * h->lastSplit[slot] * 5;
-            for (unsigned b = 0; b < h->lastSplit[slot]; ++b)
-                for (int j = 0; j < 5; ++j) m[slot][j] += base[(size_t)b * 5 + j];
+            if (h->cfg.weightedMean) {
+                const double *base = ws.data() + slot * h->wsumHalf + (size_t)w * h->lastSplit[slot] * 5;
+                for (unsigned b = 0; b < h->lastSplit[slot]; ++b)
+                    for (int j = 0; j < 5; ++j) m[slot][j] += base[(size_t)b * 5 + j];
+            }
             for (int j = 0; j < 5; ++j) r.weightedSums[slot][j] = m[slot][j];
         }
         if (!h->cfg.weightedMean) {
