@@ -106,6 +106,14 @@ def lib():
     return _lib
 
 
+def _quiet(fn):
+    """Finaliser helper: at interpreter shutdown module globals may already be gone."""
+    try:
+        fn()
+    except Exception:
+        pass
+
+
 def _check(rc):
     if rc != 0:
         raise DpeError(lib().dpe_last_error().decode("utf-8", "replace"))
@@ -257,7 +265,8 @@ class BatchCorrScores:
             self.Started = False
         return 0
 
-    __del__ = Stop
+    def __del__(self):
+        _quiet(self.Stop)
 
     # ---- host-side readers (tests / diagnostics)
     def read_banks(self, stream=None):
@@ -384,7 +393,8 @@ class BatchCorrManifold:
             self.Started = False
         return 0
 
-    __del__ = Stop
+    def __del__(self):
+        _quiet(self.Stop)
 
 
 class ChmConfig(C.Structure):
@@ -449,7 +459,8 @@ class ChanMgr:
             self._h = C.c_void_p(None)
         return 0
 
-    __del__ = Stop
+    def __del__(self):
+        _quiet(self.Stop)
 
 
 class AcqConfig(C.Structure):
@@ -542,7 +553,8 @@ class Acquisition:
             lib().dpe_acq_destroy(self._h)
             self._h = C.c_void_p(None)
 
-    __del__ = close
+    def __del__(self):
+        _quiet(self.close)
 
 
 class EkfConfig(C.Structure):
@@ -602,7 +614,8 @@ class cuEKF:
             lib().dpe_ekf_destroy(self._h)
             self._h = C.c_void_p(None)
 
-    __del__ = Stop
+    def __del__(self):
+        _quiet(self.Stop)
 
 
 class HipEventTimer:
