@@ -582,3 +582,29 @@ def test_parameter_copy_path_for_small_batches():
     ref = helpers.run_oracle(case, 8, 32)
     out = helpers.run_gpu(case, 8, 32, repeats=6)   # more back-to-back calls on one handle than staging slots
     helpers.assert_parity(out, ref, tol=TOL)
+
+
+def test_repeated_updates_are_reproducible():
+    """3000 single-window Updates cycling through 4 windows on one pair of handles (kernel-argument parameters,
+    alternating key sets, last-block result publishing, no fences): every result equals the first pass bit for bit.
+    (A 150 000-iteration run of the same loop was clean when the publishing scheme was introduced.)"""
+    import torch
+    cfg = dpe.workload.CONFIG_R
+    fs, S, K, L, B, W = cfg["fs"], cfg["S"], cfg["K"], 3, 40, 4
+    iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=9, amp=cfg["amp"])
+    g = dpe.synth.uniform_grid(9, 1.0)
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+    bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=1, max_channels=K)
+    bcs.Start()
+    bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, g, g, lag_half_width=L, bin_half_width=B, max_windows=1, max_channels=K)
+    bcm.Start()
+
+    def one(w):
+        bcs.Update(iq_d[w], cs[w])
+        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw[w:w + 1], ce[w])
+        r = bcm.results()[0]
+        return r["posIndex"], r["velIndex"], r["posScore"], r["velScore"], r["posOutOfWindow"], r["velOutOfWindow"]
+
+    ref = [one(w) for w in range(W)]
+    assert all(one(i % W) == ref[i % W] for i in range(3000))
+    bcm.Stop(); bcs.Stop()
