@@ -157,14 +157,19 @@ __device__ __forceinline__ void window_mean(const long long *__restrict__ sums, 
 }
 
 // ------------------------------------------------------------------------------------------
-template <int LH, int kNMom, bool TABLE>
+// FUSE (single windows, closed loop): the DC sum rides along instead of running as a kernel of its own.  The mean only
+// enters the Doppler moments, and linearly: M_p[(raw - mean) w r] = M_p[raw w r] - mean * M_p[w r].  So this kernel
+// accumulates both moment sets and the k = 0 blocks also write the int64 sample sums of their tiles (one slot per
+// block); bcs_finalize_kernel forms the mean from the slots and combines.  One launch and ~4 us less per window.
+template <int LH, int kNMom, bool TABLE, bool FUSE>
 __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride, int S,
                                                        int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk, int lagShift,
                                                        const BcsChanDev *__restrict__ chan,
                                                        const long long *__restrict__ sums,
                                                        const int8_t *__restrict__ chipTable,
                                                        const double *__restrict__ tT,
-                                                       float2 *__restrict__ part, float2 *__restrict__ mom)
+                                                       float2 *__restrict__ part, float2 *__restrict__ mom,
+                                                       float2 *__restrict__ momRep, long long *__restrict__ sumSlots)
 {
     constexpr int NL = 2 * LH + 1;      // lags
     constexpr int NREP = kSub + 2 * LH;  // replica entries per sub-tile (with halo)
@@ -179,8 +184,10 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
     const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
     for (int i = tid; i < 2048; i += 256) sChips[i] = (float)chipTable[(ch.prn - 1) * 1024 + (i >= kLCA ? i - kLCA : i) % kLCA];
     const bool fastIdx = (double)NREP * ch.codeStep < 1000.0;   // chip span of one sub-tile fits the extended table
-    float mRe, mIm;
-    window_mean(sums, w, nSumBlk, S, mRe, mIm);
+    float mRe = 0.f, mIm = 0.f;
+    if (!FUSE) window_mean(sums, w, nSumBlk, S, mRe, mIm);
+    int sumI = 0, sumQ = 0;   // FUSE, k == 0: exact sums of this lane's samples (< 64k samples per lane: no overflow)
+    __shared__ int sSum[4][2];
     const int16_t *x = iq + (size_t)w * winStride * 2;
     float xp[4];
 #pragma unroll
@@ -206,21 +213,21 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
             // samples first: the global-load latency is covered by the replica build below
             const int n0 = sub0 + 4 * lane;
             float re[4], im[4];
-            if (active) {
+            const bool countRaw = FUSE && k == 0 && side == 0 && sub < nSub;   // every sample of the window exactly once
+            if (active || countRaw) {
+                int rawv[4];
                 if (vecOK && n0 + 3 < S) {
                     const int4 v = *reinterpret_cast<const int4 *>(x + 2 * (size_t)n0);
-                    re[0] = (float)(short)(v.x & 0xFFFF); im[0] = (float)(v.x >> 16);
-                    re[1] = (float)(short)(v.y & 0xFFFF); im[1] = (float)(v.y >> 16);
-                    re[2] = (float)(short)(v.z & 0xFFFF); im[2] = (float)(v.z >> 16);
-                    re[3] = (float)(short)(v.w & 0xFFFF); im[3] = (float)(v.w >> 16);
+                    rawv[0] = v.x; rawv[1] = v.y; rawv[2] = v.z; rawv[3] = v.w;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int v = 0;
-                        if (n0 + i < S) v = *reinterpret_cast<const int *>(x + 2 * (size_t)(n0 + i));
-                        re[i] = (float)(short)(v & 0xFFFF);
-                        im[i] = (float)(v >> 16);
-                    }
+                    for (int i = 0; i < 4; ++i) rawv[i] = (n0 + i < S) ? *reinterpret_cast<const int *>(x + 2 * (size_t)(n0 + i)) : 0;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    re[i] = (float)(short)(rawv[i] & 0xFFFF);
+                    im[i] = (float)(rawv[i] >> 16);
+                    if (countRaw) { sumI += (short)(rawv[i] & 0xFFFF); sumQ += rawv[i] >> 16; }
                 }
             }
             if (active) {
@@ -251,9 +258,11 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                 }
             }
             // no barrier: sRep[wave] is private to this wave and a wave's DS operations complete in order
-            f2 M[kNMom];
+            f2 M[kNMom], Mq[FUSE ? kNMom : 1];
 #pragma unroll
             for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < (FUSE ? kNMom : 1); ++p) Mq[p] = f2{0.f, 0.f};
             if (active) {
                 // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300):
                 // fp64 phase seed per lane, hardware sin/cos in revolutions, 3 fp32 rotations.
@@ -280,17 +289,27 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                     }
                     // carrier path: (raw - mean) * wipe * replica (:480, :440-448)
                     const float r0 = (n0 + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
-                    f2 cp = (bb - cmul(meanv, wv)) * r0;   // x^p * c, built up by one packed multiply per order
+                    if (FUSE) {
+                        f2 cp = bb * r0, cq = wv * r0;         // raw w r and w r: the mean is applied in the finalize kernel
 #pragma unroll
-                    for (int p = 0; p < kNMom; ++p) {
-                        M[p] += cp;
-                        cp *= xp[i];
+                        for (int p = 0; p < kNMom; ++p) {
+                            M[p] += cp; Mq[p] += cq;
+                            cp *= xp[i]; cq *= xp[i];
+                        }
+                    } else {
+                        f2 cp = (bb - cmul(meanv, wv)) * r0;   // x^p * c, built up by one packed multiply per order
+#pragma unroll
+                        for (int p = 0; p < kNMom; ++p) {
+                            M[p] += cp;
+                            cp *= xp[i];
+                        }
                     }
                     wv = cmul(wv, rotv);
                 }
             }
             if (sub < nSub && lagShift == 0) {   // the Doppler path belongs to the unshifted replica only
-                float2 *o = mom + ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
+                const size_t mo = ((((size_t)w * K + k) * 2 + side) * nSub + sub) * kNMom;
+                float2 *o = mom + mo;
                 if (active) {
                     float mm[2 * kNMom];
 #pragma unroll
@@ -300,8 +319,18 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
 #pragma unroll
                         for (int p = 0; p < kNMom; ++p) o[p] = make_float2(mm[2 * p], mm[2 * p + 1]);
                     }
+                    if (FUSE) {
+#pragma unroll
+                        for (int p = 0; p < kNMom; ++p) { mm[2 * p] = Mq[p].x; mm[2 * p + 1] = Mq[p].y; }
+                        dpp_sum_lane63(mm);
+                        if (lane == 63) {
+#pragma unroll
+                            for (int p = 0; p < kNMom; ++p) momRep[mo + p] = make_float2(mm[2 * p], mm[2 * p + 1]);
+                        }
+                    }
                 } else if (lane < kNMom) {
                     o[lane] = make_float2(0.f, 0.f);
+                    if (FUSE) momRep[mo + lane] = make_float2(0.f, 0.f);
                 }
             }
         }
@@ -316,7 +345,18 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                 for (int j = 0; j < NL; ++j) sAcc[wave][j] = make_float2(aa[2 * j], aa[2 * j + 1]);
             }
         }
+        if (FUSE && k == 0 && side == 0) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                sumI += __shfl_xor(sumI, off, 64);   // per-wave totals stay far below 2^31 (<= 16 tiles x 256 x 32767)
+                sumQ += __shfl_xor(sumQ, off, 64);
+            }
+            if (lane == 0) { sSum[wave][0] = sumI; sSum[wave][1] = sumQ; }
+        }
         __syncthreads();
+        if (FUSE && k == 0 && side == 0 && tid < 2)
+            sumSlots[((size_t)w * kSumSlots + blk) * 2 + tid] =
+                (long long)sSum[0][tid] + (long long)sSum[1][tid] + (long long)sSum[2][tid] + (long long)sSum[3][tid];
         for (int j = tid; j < NL; j += 256) {
             float2 s = sAcc[0][j];
             s.x += sAcc[1][j].x; s.y += sAcc[1][j].y;
@@ -699,13 +739,15 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
 
 // ------------------------------------------------------------------------------------------
 // blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
-template <int kNMom>
+template <int kNMom, bool FUSE>
 __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide, int lagShift,
                                                            long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
                                                            const float2 *__restrict__ mom,
                                                            float2 *__restrict__ codeBank, float2 *__restrict__ carrBank,
-                                                           int *__restrict__ info, int maxK)
+                                                           int *__restrict__ info, int maxK,
+                                                           const float2 *__restrict__ momRep,     // fuse: moments of wipe x replica
+                                                           const long long *__restrict__ sums, int nSumBlk)
 {
     const int k = blockIdx.y, w = blockIdx.z, tid = threadIdx.x;
     const int NL = 2 * LH + 1;
@@ -730,7 +772,13 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     const bool carrBlk = lagShift == 0 && (fat || blockIdx.x != 0);
     const float2 *m0 = mom + (((size_t)w * K + k) * 2) * nSub * kNMom;
     const float2 *m1 = m0 + (size_t)nSub * kNMom;
-    float2 r0[kNMom], r1[kNMom];
+    // fuse (single windows): the stage-1 kernel stored M_p[raw w r] in mom and M_p[w r] in momRep; the DC mean comes
+    // from the per-block sample sums it left in `sums`:  M_p[(raw - mean) w r] = M_p[raw w r] - mean * M_p[w r]
+    const float2 *q0 = momRep + (((size_t)w * K + k) * 2) * nSub * kNMom;
+    const float2 *q1 = q0 + (size_t)nSub * kNMom;
+    float mRe = 0.f, mIm = 0.f;
+    if (FUSE) window_mean(sums, w, nSumBlk, S, mRe, mIm);
+    float2 r0[kNMom], r1[kNMom], s0[FUSE ? kNMom : 1], s1[FUSE ? kNMom : 1];
     auto load_chunk = [&](int c0) {
         const int n = (nSub - c0 < kChunk ? nSub - c0 : kChunk) * kNMom;
 #pragma unroll
@@ -739,6 +787,10 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
             const bool ok = idx < n;
             r0[i] = ok ? m0[(size_t)c0 * kNMom + idx] : make_float2(0.f, 0.f);
             r1[i] = ok ? m1[(size_t)c0 * kNMom + idx] : make_float2(0.f, 0.f);
+            if (FUSE) {
+                s0[i] = ok ? q0[(size_t)c0 * kNMom + idx] : make_float2(0.f, 0.f);
+                s1[i] = ok ? q1[(size_t)c0 * kNMom + idx] : make_float2(0.f, 0.f);
+            }
         }
     };
     if (carrBlk) load_chunk(0);
@@ -833,8 +885,15 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
             load_chunk(c0);
         }
 #pragma unroll
-        for (int i = 0; i < kNMom; ++i)
-            sMom[tid + 256 * i] = make_float2(r0[i].x + sgn * r1[i].x, r0[i].y + sgn * r1[i].y);
+        for (int i = 0; i < kNMom; ++i) {
+            float ax = r0[i].x + sgn * r1[i].x, ay = r0[i].y + sgn * r1[i].y;
+            if (FUSE) {
+                const float qx = s0[i].x + sgn * s1[i].x, qy = s0[i].y + sgn * s1[i].y;
+                ax -= mRe * qx - mIm * qy;
+                ay -= mRe * qy + mIm * qx;
+            }
+            sMom[tid + 256 * i] = make_float2(ax, ay);
+        }
         __syncthreads();
         const int cEnd = nSub - c0 < kChunk ? nSub - c0 : kChunk;
         for (int sl = grp; sl < cEnd; sl += 16, ++it) {   // kChunk is a multiple of 16: the stride continues across chunks
@@ -902,6 +961,7 @@ struct dpe_bcs {
     int nSub, nBlk, tilesPerBlock, nMom;
     bool wideAllowed = true;     // DPE_BCS_NO_WIDE=1 in the environment at create: dense kernel only (A/B tests)
     bool bank16Allowed = true;   // DPE_BCS_NO_BANK16=1: never the 16-samples-per-lane batch kernel (A/B tests)
+    bool fuseAllowed = true;     // DPE_BCS_NO_FUSE=1: always the separate DC-sum kernel (A/B tests)
     long long C;
     int8_t *chipTable_d = nullptr;
     double *tTable_d = nullptr;   // ns-rounded sample times (always allocated; used only when useTable)
@@ -914,7 +974,7 @@ struct dpe_bcs {
     dpe::BcsChanDev *chanBase_h = nullptr, *chan_h = nullptr;
     hipEvent_t stagingFree[kStaging] = {};
     int slot = 0;
-    float2 *part_d = nullptr, *mom_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
+    float2 *part_d = nullptr, *mom_d = nullptr, *momRep_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
     int *info_d = nullptr;
     int lastW = 0, lastK = 0, lastSumBlocks = 1;
     std::vector<int32_t> idxNext_h;
@@ -999,10 +1059,11 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     h->part_d = dev_alloc<float2>(W * K * h->nBlk * 2 * (2 * h->LH + 1));
     h->mom_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMomMax);
+    h->momRep_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMomMax);
     h->codeBank_d = dev_alloc<float2>(W * K * (2 * cfg->lagHalfWidth + 1));
     h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
     h->info_d = dev_alloc<int>(W * K);
-    if (!h->tTable_d || !h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->codeBank_d || !h->carrBank_d ||
+    if (!h->tTable_d || !h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
         !h->info_d || hipHostMalloc((void **)&h->chanBase_h, dpe_bcs::kStaging * W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrScores] create: device allocation failed");
         dpe_bcs_destroy(h);
@@ -1016,6 +1077,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->wideAllowed = getenv("DPE_BCS_NO_WIDE") == nullptr;
     h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
+    h->fuseAllowed = getenv("DPE_BCS_NO_FUSE") == nullptr;
     *out = h;
     return 0;
 }
@@ -1023,7 +1085,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
 int dpe_bcs_destroy(dpe_bcs *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->codeBank_d, h->carrBank_d, h->info_d};
+    void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
     for (hipEvent_t e : h->stagingFree)
@@ -1076,7 +1138,6 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const bool useGraph = h->graphs.enabled && !h->prof.enabled;
     GraphCache::Guard graphGuard{h->graphs, stream};
     const int sumBlocks = sum_blocks(S, nWindows);
-    h->lastSumBlocks = sumBlocks;
     if (useGraph) {
         const int rc = h->graphs.begin({samples_dev, nullptr, (long long)windowStrideSamples, nWindows, nChan,
                                         (h->wideAllowed ? 1 : 0) | (h->bank16Allowed ? 2 : 0) | (h->slot << 8), stream}, stream);
@@ -1096,10 +1157,6 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
         if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     }
-    h->prof.begin(0, stream);
-    hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
-                       (long long)windowStrideSamples, S, h->sums_d);
-    h->prof.end(0, stream);
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
     // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else a dense kernel
@@ -1123,10 +1180,26 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     }
     const int nBlk = (nTiles + tpb - 1) / tpb;
     const dim3 grid(nBlk, nChan, nWindows), block(256);
-#define DPE_LAUNCH_BANK3(LHV, NM, TB)                                                                                   \
-    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
+    // single windows (<= 37 (window, channel) pairs) with a dense stage-1 kernel: no separate DC-sum launch, the
+    // sums ride along in the bank kernel (FUSE) and the finalize kernel applies the mean
+    const bool fuse = nWindows * nChan <= DPE_MAX_CHAN && !use16 && !wide && h->LH <= 16 && h->cfg.lagHalfWidth <= 32 && h->fuseAllowed;
+    const int sumSlotsUsed = fuse ? nBlk : sumBlocks;
+    h->lastSumBlocks = sumSlotsUsed;
+    if (!fuse) {
+        h->prof.begin(0, stream);
+        hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
+                           (long long)windowStrideSamples, S, h->sums_d);
+        h->prof.end(0, stream);
+    }
+#define DPE_LAUNCH_BANK4(LHV, NM, TB, FS)                                                                               \
+    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB, FS>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, lagShift, h->chan_d, h->sums_d, h->chipTable_d, \
-                       h->tTable_d, h->part_d, h->mom_d)
+                       h->tTable_d, h->part_d, h->mom_d, h->momRep_d, h->sums_d)
+#define DPE_LAUNCH_BANK3(LHV, NM, TB)                                        \
+    do {                                                                     \
+        if (fuse && LHV <= 16) DPE_LAUNCH_BANK4(LHV <= 16 ? LHV : 16, NM, TB, true);   \
+        else DPE_LAUNCH_BANK4(LHV, NM, TB, false);                           \
+    } while (0)
 #define DPE_LAUNCH_BANK2(LHV, NM)                           \
     do {                                                    \
         if (h->useTable) DPE_LAUNCH_BANK3(LHV, NM, true);   \
@@ -1173,6 +1246,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
 #undef DPE_LAUNCH_BANK
 #undef DPE_LAUNCH_BANK2
 #undef DPE_LAUNCH_BANK3
+#undef DPE_LAUNCH_BANK4
     h->prof.end(1, stream);
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
@@ -1180,14 +1254,14 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     // side chunks of a wide lag window: one block per (window, SV), code-bank entries only
     const bool fatFinalize = nBinBlk <= 4 && (long long)nChan * nWindows >= 512;
     const dim3 fgrid((fatFinalize || lagShift != 0) ? 1 : 1 + nBinBlk, nChan, nWindows);
-    if (h->nMom == 4)
-        hipLaunchKernelGGL(bcs_finalize_kernel<4>, fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
-                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, h->C, h->chan_d, h->part_d, h->mom_d,
-                           h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
-    else
-        hipLaunchKernelGGL(bcs_finalize_kernel<6>, fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub,
-                           nBlk, h->LH, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, h->C, h->chan_d, h->part_d, h->mom_d,
-                           h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels);
+#define DPE_LAUNCH_FIN(NM, FS)                                                                                          \
+    hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub, nBlk, h->LH,       \
+                       h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, h->C, h->chan_d, h->part_d, h->mom_d,  \
+                       h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels, h->momRep_d, h->sums_d, sumSlotsUsed)
+    const bool fuseFin = fuse && lagShift == 0;
+    if (h->nMom == 4) { if (fuseFin) DPE_LAUNCH_FIN(4, true); else DPE_LAUNCH_FIN(4, false); }
+    else { if (fuseFin) DPE_LAUNCH_FIN(6, true); else DPE_LAUNCH_FIN(6, false); }
+#undef DPE_LAUNCH_FIN
     h->prof.end(2, stream);
     }   // chunk
     const bool captured = h->graphs.capturing;

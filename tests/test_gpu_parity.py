@@ -505,9 +505,10 @@ def test_clamp_variants_of_the_fused_scan(pos_out, vel_out, wmean):
 def test_fat_finalize_shape_is_bit_identical_to_the_split_shape(monkeypatch):
     """Batches launch bcs_finalize_kernel with one block per (window, SV) doing the code bank and every Doppler-bin
     group; few windows launch 1 + nBinBlk short blocks.  Same arithmetic in the same order: with stage 1 pinned to
-    one kernel (DPE_BCS_NO_BANK16) and one tile partition, a 64-window batch reproduces single-window calls bit for bit."""
+    one kernel (DPE_BCS_NO_BANK16, DPE_BCS_NO_FUSE) and one tile partition, a 64-window batch reproduces single-window calls bit for bit."""
     import torch
     monkeypatch.setenv("DPE_BCS_NO_BANK16", "1")
+    monkeypatch.setenv("DPE_BCS_NO_FUSE", "1")     # single windows would otherwise take the fused DC-sum form of stage 1
     fs, S, K, W, L, B = 2.5e6, 12500, 8, 64, 4, 24
     iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=53, amp=60.0)
     iq_d = torch.from_numpy(iq).to("cuda:0")
