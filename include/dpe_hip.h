@@ -295,7 +295,8 @@ int dpe_acq_surface(dpe_acq *h, const float **surface_dev, const float **maxPerC
 
 /* Per-kernel timing (HIP events recorded on the launch stream around each kernel).  Returns and
  * resets the totals accumulated since the previous call, then sets the enable flag.
- * BCS slots: 0 DC-sum, 1 bank, 2 finalize (ms[3], count[3]); BCM slots: 0 pos scan, 1 vel scan. */
+ * BCS slots: 0 DC-sum (not launched for single windows, where the bank kernel carries the sums), 1 bank (one launch per
+ * 65-lag chunk), 2 finalize (ms[3], count[3]); BCM: slot 0 = the fused position + velocity scan (slot 1 unused). */
 int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count);
 int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count);
 
