@@ -16,6 +16,8 @@
 //
 // HBM traffic per window per manifold: 16 B/point grid read (float4, coalesced) + 4 B/point score
 // write; banks (K x (2L+1) float4 pairs) and SV coefficients live in LDS.
+#include <atomic>
+
 #include "dpe_common.h"
 
 namespace dpe {
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
                                                        unsigned long long *__restrict__ clearPtr, int clearN,
                                                        unsigned int *__restrict__ done,
                                                        unsigned long long *__restrict__ hostKeys,
-                                                       unsigned long long *__restrict__ hostOob)
+                                                       unsigned long long *__restrict__ hostOob,
+                                                       unsigned long long seqValue)
 {
     (void)pb;
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
@@ -320,11 +323,30 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
     __syncthreads();
     if (sLast) {
         const int n = 2 * (int)gridDim.y;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const unsigned long long kv = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long ov = __hip_atomic_load(&oob[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&hostKeys[i], kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&hostOob[i], ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (gridDim.y == 1) {
+            // One window: keys, counts and a sequence word share one 64-byte line of the host mirror and are written by
+            // ONE lane in program order (same line -> same memory channel -> they arrive in that order), the sequence
+            // word last.  The host may poll it instead of waiting on the stream (dpe_bcm_results).
+            if (threadIdx.x == 0) {
+                unsigned long long v[4];
+                v[0] = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[1] = __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[2] = __hip_atomic_load(&oob[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[3] = __hip_atomic_load(&oob[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&hostKeys[0], v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&hostKeys[1], v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&hostOob[0], v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&hostOob[1], v[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&hostOob[2], seqValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // sequence word
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const unsigned long long kv = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long ov = __hip_atomic_load(&oob[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&hostKeys[i], kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&hostOob[i], ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -347,6 +369,8 @@ struct dpe_bcm {
     int cur = 1;                           // set of the latest Update
     unsigned int *done_d = nullptr;        // finished-block ticket of the scan kernel (returns to 0 by itself)
     unsigned long long *keys_hd = nullptr; // device view of the pinned mirror keys_h
+    unsigned long long seq = 0;            // single-window Updates: sequence number the kernel writes behind the results
+    bool pollable = false, pollAllowed = true;   // last Update was a single eager window; DPE_BCM_NO_POLL=1 disables
     double *wsum_d = nullptr;   // [W][2][split][5] per-block weighted sums
     unsigned long long *keys_h = nullptr, *oob_h = nullptr;   // pinned mirrors, filled by async copies at the end of Update
     unsigned lastSplit[2] = {0, 0};
@@ -391,7 +415,7 @@ struct ScanLaunch {
     unsigned long long *keys, *oob, *clr;
     int clrN;
     unsigned int *done;
-    unsigned long long *hostKeys, *hostOob;
+    unsigned long long *hostKeys, *hostOob, seq;
     dim3 grid;
     size_t lds;
     hipStream_t st;
@@ -401,7 +425,7 @@ template <int LP, bool CP, bool CV, bool WM>
 static void launch_scan4(const ScanLaunch &a)
 {
     hipLaunchKernelGGL((dpe::bcm_scan_kernel<LP, CP, CV, WM>), a.grid, dim3(256), a.lds, a.st, a.pb, a.inl, a.sp, a.sv, a.K, a.maxK,
-                       a.lp, a.keys, a.oob, a.clr, a.clrN, a.done, a.hostKeys, a.hostOob);
+                       a.lp, a.keys, a.oob, a.clr, a.clrN, a.done, a.hostKeys, a.hostOob, a.seq);
 }
 
 template <bool CP, bool CV, bool WM>
@@ -486,7 +510,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
     if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->wsum_d ||
         hipHostMalloc((void **)&h->svBase_h, dpe_bcm::kStaging * 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&h->keys_h, 4 * W * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&h->keys_h, (4 * W + 8) * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
         dpe_bcm_destroy(h);
         return -1;
@@ -497,6 +521,8 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
     h->oob_h = h->keys_h + 2 * W;
+    for (size_t i = 0; i < 4 * W + 8; ++i) h->keys_h[i] = 0ull;
+    h->pollAllowed = getenv("DPE_BCM_NO_POLL") == nullptr;
     h->sv_h = h->svBase_h;
     for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     DPE_CHECK_HIP(hipMemset(h->keys_d, 0, 8 * W * sizeof(unsigned long long)));
@@ -605,6 +631,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         if (rc == 1) {
             DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));   // the replayed graph reads this slot
             h->cur = use;
+            h->pollable = false;
             return 0;
         }
     }
@@ -630,6 +657,10 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
                     (int)h->lastSplit[1]};
     a.keys = keys; a.oob = oob; a.clr = other; a.clrN = 4 * W;
     a.done = h->done_d; a.hostKeys = h->keys_hd; a.hostOob = h->keys_hd + 2 * W;
+    a.seq = ++h->seq;
+    // (a replayed graph carries a stale sequence argument: polling only for eager single-window launches whose mirror
+    //  has the sequence word right behind the results, i.e. maxWindows == 1)
+    h->pollable = nWindows == 1 && W == 1 && !h->graphs.capturing && h->pollAllowed;
     a.grid = dim3(h->lastSplit[0] > h->lastSplit[1] ? h->lastSplit[0] : h->lastSplit[1], nWindows, 2);
     a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * 16;
     a.st = stream;
@@ -677,7 +708,16 @@ static void decode_key(unsigned long long key, float *score, int64_t *index)
 int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
 {
     DPE_REQUIRE(h && results && h->lastW > 0, "[BatchCorrManifold] results: no update yet");
-    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    // Single-window Updates: the scan's last block writes a sequence word right behind the results in the pinned
+    // mirror.  Polling it returns the fix as soon as it lands, without the stream-wait wake-up (a few us of a ~58 us
+    // closed-loop window); anything unexpected falls back to the stream wait.
+    bool arrived = false;
+    if (h->pollable) {
+        const volatile unsigned long long *seqWord = h->oob_h + 2;
+        for (int spin = 0; spin < 200000 && !arrived; ++spin) arrived = (*seqWord == h->seq);
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!arrived) DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int W = h->lastW;
     const unsigned long long *keys = h->keys_h, *oob = h->oob_h;
     std::vector<double> ws;   // per-block weighted sums: fetched only when the estimator is on (this call sits on the
