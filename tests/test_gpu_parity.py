@@ -609,3 +609,22 @@ def test_repeated_updates_are_reproducible():
     ref = [one(w) for w in range(W)]
     assert all(one(i % W) == ref[i % W] for i in range(3000))
     bcm.Stop(); bcs.Stop()
+
+
+@pytest.mark.parametrize("W", [1, 2])
+def test_large_dc_offset(W):
+    """Front ends leave DC offsets far larger than the GPS signal.  (raw - mean) is formed per sample in the batch
+    kernels and by moment linearity, M_p[raw w r] - mean M_p[w r], in the single-window kernel -- both must hold the
+    usual tolerance with an offset of (+900, -700) LSB on a ~60 LSB signal (W = 1: fused form; W = 2 with K = 20: the
+    separate DC-sum kernel)."""
+    K = 4 if W == 1 else 20
+    case = helpers.make_case(seed=91, S=25000, K=K, G=2048, amp=60.0, W=W)
+    for w in case["wins"]:
+        iq = w["iq"].astype(np.int32)
+        iq[0::2] += 900
+        iq[1::2] -= 700
+        w["iq"] = np.clip(iq, -32768, 32767).astype(np.int16)
+    out = helpers.run_gpu(case, 8, 32)
+    ref = helpers.run_oracle(case, 8, 32)
+    assert abs(ref["info"][0][0]["mean"].real - 900) < 5 and abs(ref["info"][0][0]["mean"].imag + 700) < 5
+    helpers.assert_parity(out, ref, tol=TOL)
