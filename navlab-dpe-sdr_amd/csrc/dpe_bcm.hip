@@ -396,12 +396,16 @@ static int upload_grid(const double *src, int64_t G, std::vector<double> &keep, 
     return 0;
 }
 
-// Blocks along x per window: ~4096 blocks in flight overall, a multiple of 8 (XCD round robin, see the
+// Blocks along x per window: ~4096 blocks in flight overall for batches, a multiple of 8 (XCD round robin, see the
 // kernel) and never more than the number of 1024-point tiles.
 static unsigned scan_split(long long G, int nWindows)
 {
     const long long nTiles = (G + dpe::kPtsPerBlock - 1) / dpe::kPtsPerBlock;
     long long s = 4096 / nWindows;
+    // one or two windows (closed loop): latency, not throughput -- 128 blocks per manifold (one block per CU over both
+    // manifolds), each walking several tiles, beat one block per tile: the per-block costs (bank staging, key atomics,
+    // ticket) are paid fewer times.  Measured on the 25^4 grids: 53.5 -> 49.3 us per window.
+    if (nWindows <= 2 && s > 128) s = 128;
     if (s < 8) s = 8;
     s = (s + 7) / 8 * 8;
     if (s > nTiles) s = nTiles;
