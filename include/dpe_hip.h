@@ -35,6 +35,10 @@ typedef struct dpe_bcm dpe_bcm;    /* opaque: one BatchCorrManifold instance */
 int dpe_abi_version(void);
 const char *dpe_last_error(void);                 /* thread-local message of the last failure */
 int dpe_device_info(char *name, int nameLen, int *cuCount, int64_t *hbmBytes);
+/* Measured HBM ceiling of this device (SURVEY 8d "verify on the box"): a float4 stream copy (2 arrays) and a
+ * triad a = b + s*c (3 arrays) over `bytesPerArray`-byte arrays, `iters` timed launches each after two untimed ones;
+ * GB/s = bytes read + written per launch / launch time.  Diagnostic only -- nothing on the hot path calls it. */
+int dpe_hbm_ceiling(int64_t bytesPerArray, int iters, dpe_stream_t stream, double *copyGBs, double *triadGBs);
 
 /* 37 x 1023 C/A chips (+1/-1), PRN p at row p-1.  Replaces BCS_GenCACode
  * (batchcorrscores.cu:117-177); unlike the reference, PRN 37 is generated too. */

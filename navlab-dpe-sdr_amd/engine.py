@@ -26,6 +26,7 @@ EXPORTS = [
     "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface", "dpe_bcs_set_graph", "dpe_bcm_set_graph",
     "dpe_acq_fine", "dpe_acq_scalar_acquisition",
     "dpe_ekf_create", "dpe_ekf_destroy", "dpe_ekf_step_update", "dpe_ekf_step_predict", "dpe_ekf_state",
+    "dpe_hbm_ceiling",
 ]
 
 
@@ -171,6 +172,13 @@ def device_info():
     cu, mem = C.c_int(0), C.c_int64(0)
     _check(lib().dpe_device_info(name, 128, C.byref(cu), C.byref(mem)))
     return name.value.decode(), cu.value, mem.value
+
+
+def hbm_ceiling(bytes_per_array=1 << 30, iters=10, stream=None):
+    """Measured stream-copy and triad bandwidth of this device in GB/s (diagnostic; see dpe_hbm_ceiling)."""
+    cp, tr = C.c_double(0), C.c_double(0)
+    _check(lib().dpe_hbm_ceiling(C.c_int64(bytes_per_array), C.c_int(iters), _stream(stream), C.byref(cp), C.byref(tr)))
+    return cp.value, tr.value
 
 
 def d2h(ptr, nbytes, dtype, stream=None):

@@ -628,3 +628,12 @@ def test_large_dc_offset(W):
     ref = helpers.run_oracle(case, 8, 32)
     assert abs(ref["info"][0][0]["mean"].real - 900) < 5 and abs(ref["info"][0][0]["mean"].imag + 700) < 5
     helpers.assert_parity(out, ref, tol=TOL)
+
+
+def test_hbm_ceiling_diagnostic():
+    """dpe_hbm_ceiling: plausible numbers (between 1 and 8 TB/s on an MI355X) and argument errors in the reference's
+    0 / -1 convention."""
+    cp, tr = dpe.engine.hbm_ceiling(256 << 20, 5)
+    assert 1000.0 < cp < 8000.0 and 1000.0 < tr < 8000.0
+    with pytest.raises(dpe.DpeError):
+        dpe.engine.hbm_ceiling(16, 5)
