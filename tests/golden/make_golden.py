@@ -188,8 +188,63 @@ def make_o11(pg):
                         handoff_prns=ho["prn_list"], handoff_eph=ho["eph"], handoff_rxTime=ho["rxTime"])
 
 
+def time_dp(pg, iters=3):
+    """SURVEY 8d, CPU baseline (2): the PyGNSS DP path timed in the dev container -- per 20 ms window,
+    dp_time_update_channels_unfolded (vector_correlate_unfolded x K, the BatchCorrScores twin) and
+    dp_measurement_estimation_unfolded (the BatchCorrManifold twin incl. its grid generation).  Prints one JSON line;
+    quoted in DESIGN.md section 5, never used by a test."""
+    import json
+    import time
+    ho = dpe.handoff.read_handoff(os.path.join(REF, "demofiles", "handoff_params_usrp6.csv"))
+    prns = [int(p) for p in ho["prn_list"]]
+    ch_ho = dict(prn=ho["prn_list"], rc=ho["rc"], ri=ho["ri"], fc=ho["fc"], fi=ho["fi"], cp=ho["cp"],
+                 cp_ref=ho["cp_timestamp"])
+    fs, T = 2.5e6, 0.02
+    S = int(round(fs * T))
+    iq = np.concatenate([dpe.synth.gen_iq(21 + i, fs, S, ch_ho, amp=200.0, flip=np.zeros(len(prns), dtype=bool))
+                         for i in range(iters + 1)])
+    path = os.path.join(SCRATCH, "time_dp.dat")
+    iq.tofile(path)
+    rf = open_rawfile(pg, path, fs, T)
+    rx = pg.receiver.Receiver(rf, mcount_max=iters + 4)
+    rx.add_channels(prns)
+    for k, p in enumerate(prns):
+        rx.channels[p].ephemerides = Eph(ho, k)
+    rx.ekf = pg.ekf.ExtendedKalmanFilter(np.asmatrix(ho["X_ECEF"]).T, T=T)
+    rx.navguess = pg.receiver.NavigationGuesses()
+    rx.rxTime = ho["rxTime"]
+    rx.ekf.X_ECEF = np.matrix(ho["X_ECEF"]).T
+    rx.rxTime_a = rx.rxTime - (rx.ekf.X_ECEF[3, 0] / 299792458.0)
+    for k, p in enumerate(prns):
+        c = rx.channels[p]
+        c.rc[0], c.ri[0], c.fc[0], c.fi[0], c.cp[0] = ho["rc"][k], ho["ri"][k], ho["fc"][k], ho["fi"][k], float(ho["cp"][k])
+    rf.seek_rawfile(rf.S_skip)
+    t_bcs = t_bcm = 0.0
+    for it in range(iters + 1):
+        rf.update_rawsnippet()
+        rx.dp_time_update_state()
+        t0 = time.perf_counter()
+        rx.dp_time_update_channels_unfolded()
+        t1 = time.perf_counter()
+        rx._mcount += 1
+        rx.dp_measurement_estimation_unfolded()
+        t2 = time.perf_counter()
+        if it > 0:                                  # first window: warm-up
+            t_bcs += t1 - t0
+            t_bcm += t2 - t1
+    rf.close_rawfile()
+    G = 2 * 25 ** 4
+    per = (t_bcs + t_bcm) / iters
+    print(json.dumps({"windows": iters, "svs": len(prns), "bcs_twin_s_per_window": t_bcs / iters,
+                      "bcm_twin_s_per_window": t_bcm / iters, "gridpoint_sv_per_s": G * len(prns) / per,
+                      "x_realtime": 0.02 / per, "cores": 1, "numpy": np.__version__}))
+
+
 def main():
     pg = import_pygnss()
+    if "--time-dp" in sys.argv:
+        time_dp(pg)
+        return
     if "--only-o11" in sys.argv:
         make_o11(pg)
         return
