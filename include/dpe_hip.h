@@ -66,7 +66,9 @@ int dpe_stream_synchronize(dpe_stream_t stream);
 typedef struct dpe_bcs_config {
     int32_t samplesPerWindow;   /* S  = SamplingFrequency*SampleLength (sampleblock.cu:169) */
     int32_t lagHalfWidth;       /* L: code lags [-L,+L] kept about the fftshift centre S/2; 1..292 (beyond 32: chunks of 65 lags) */
-    int32_t binHalfWidth;       /* B: Doppler bins [-B,+B] kept about C/2 */
+    int32_t binHalfWidth;       /* B: Doppler bins [-B,+B] kept about C/2; B <= ~2.86e-4 * C (C = 8*2^ceil(log2 S)): 149 at
+                                 * S = 50000, 18 at S = 8192 -- the bins come from a 6th-order moment expansion over
+                                 * 256-sample blocks and create refuses a B whose remainder would reach fp32 rounding */
     int32_t maxWindows;         /* windows per dpe_bcs_update call (>=1) */
     int32_t maxChannels;        /* <= DPE_MAX_CHAN */
     int32_t reserved;

@@ -1,0 +1,61 @@
+"""Randomised differential test of the HIP path against the CPU oracle: window lengths that are not multiples of any
+tile size, 1..37 SVs, 1..5 windows, ragged grids of different sizes, every lag/bin half-width family of the kernels.
+Seeded: the default 16 cases always are the same 16; DPE_FUZZ_CASES / DPE_FUZZ_SEED widen or move the sweep
+(`DPE_FUZZ_CASES=600 python -m pytest tests/test_gpu_fuzz.py -m gpu -n 4` is the long form; 750 cases were clean in round 1).
+
+Tolerance 1e-5 of the peak / maximum score (DPE_FUZZ_TOL), against 2e-6 in the named parity tests: the sweep mixes in what
+those avoid on purpose -- a single weak SV (the "peak" is then close to the fp32 rounding of the noise it is summed out of),
+lpower = 2 (relative errors double) and lag windows beyond +-32 (boundary-difference kernel).  Worst case seen: 6.2e-6; every
+case that exceeded 2e-6 had L > 32 or lpower = 2.  Arg-max, nav-bit decisions, out-of-window counts and the DC mean
+stay exact."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("DPE_FUZZ_CASES", "24"))
+SEED = int(os.environ.get("DPE_FUZZ_SEED", "1234"))
+
+
+def draw(i):
+    rng = np.random.Generator(np.random.PCG64(SEED * 100003 + i))
+    fs = float(rng.choice([2.046e6, 2.5e6, 4.0e6, 5.0e6]))
+    S = 2 * int(rng.integers(1024, 15001))      # even: the reference's fftshift centre S/2 (dpe_bcm_create refuses odd S)
+    if rng.random() < 0.25:
+        S = int(rng.choice([4096, 8192, 16384, 12500, 25000, 20460, 50000, 40920]))
+    K = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 13, 20, 37, int(rng.integers(1, 38))]))
+    W = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    G = int(rng.choice([1, 7, 255, 256, 1023, 1024, 1025, int(rng.integers(2, 6000))]))
+    vel_G = int(rng.choice([G, 1, 1024, int(rng.integers(2, 6000))]))
+    # metres of grid half-width / c * fs = lags the position grid can reach; keep the bank wide enough
+    need_L = int(np.ceil(140.0 / 299792458.0 * fs)) + 2
+    L = int(rng.choice([need_L, need_L + 1, 8, 16, 17, 32, 33, 40, 70]))
+    L = max(L, need_L)
+    # widest B the moment expansion takes at this C (include/dpe_hip.h, dpe_bcs_config.binHalfWidth)
+    C = 8 * (1 << int(np.ceil(np.log2(S))))
+    b_max = int(np.floor((720 * 2e-7) ** (1.0 / 6.0) * C / (2 * np.pi * 127.5) * 0.999))
+    B = min(int(rng.choice([12, 20, 32, 33, 64, b_max])), b_max)
+    lpower = int(rng.choice([1, 1, 2]))
+    amp = float(rng.choice([48.0, 200.0]))
+    return dict(seed=1000 + i, fs=fs, S=S, K=K, W=W, G=G, vel_G=vel_G, L=L, B=B, lpower=lpower, amp=amp)
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_case(i):
+    p = draw(i)
+    case = helpers.make_case(seed=p["seed"], fs=p["fs"], S=p["S"], K=p["K"], G=p["G"], vel_G=p["vel_G"], amp=p["amp"],
+                             W=p["W"])
+    try:
+        out = helpers.run_gpu(case, p["L"], p["B"], lpower=p["lpower"])
+        ref = helpers.run_oracle(case, p["L"], p["B"], lpower=p["lpower"])
+        for w in range(p["W"]):
+            assert out["res"][w]["posOutOfWindow"] == ref["res"][w]["posOutOfWindow"]
+            assert out["res"][w]["velOutOfWindow"] == ref["res"][w]["velOutOfWindow"]
+        helpers.assert_parity(out, ref, tol=float(os.environ.get('DPE_FUZZ_TOL', '1e-5')))
+    except Exception:
+        print("fuzz case %d: %r" % (i, p))
+        raise
