@@ -168,6 +168,22 @@ static long double pos_base_ld(const double *s, const double *g, const double *c
     return ((long double)fs / fc) * (-rc0) + numSamps / 2.0L;
 }
 
+/* Grid points of the last dpo_bcm_pos call at which the reference's two floors (:1798-1799) were TWO apart: an index
+ * within one rounding step below an integer has floor(idx) = n-1 but idx+1 rounds up to n+1, so the weights
+ * (idx - fidx, cidx - idx) are both ~1 and the pair contributes c[n+1] + c[n-1] instead of ~c[n].  Only met where the
+ * predicted index is an integer by construction (a grid point with zero offset and self-consistent channel
+ * parameters); which side of the integer the fp64 rounding falls decides the reference's value there. */
+#define DPO_MAX_QUIRKS 256
+static int64_t g_quirk_idx[DPO_MAX_QUIRKS];
+static int64_t g_quirk_n = 0;
+
+int64_t dpo_bcm_pos_quirks(int64_t *idx, int64_t max)
+{
+    const int64_t n = g_quirk_n < DPO_MAX_QUIRKS ? g_quirk_n : DPO_MAX_QUIRKS;
+    for (int64_t i = 0; i < n && i < max; i++) idx[i] = g_quirk_idx[i];
+    return g_quirk_n;
+}
+
 int dpo_bcm_pos(const double *sat, const double *codeWin, int winLo, int winLen,
                 const double *c, const double *grid, int64_t G, const double *R,
                 const double *codeFreq, const int *cpRefTOW, const int *cpElapsedEnd,
@@ -178,6 +194,7 @@ int dpo_bcm_pos(const double *sat, const double *codeWin, int winLo, int winLen,
     const int extended = LPower < 0;
     if (extended) LPower = -LPower;
     int64_t nOob = 0;
+    g_quirk_n = 0;
     for (int64_t i = 0; i < G; i++) {
         const double *g = grid + 4 * i;
         /* :1760-1763 */
@@ -207,6 +224,10 @@ int dpo_bcm_pos(const double *sat, const double *codeWin, int winLo, int winLen,
             const double fi_ = floor(idx), ci_ = floor(idx + 1);              /* :1798-1799 */
             const int64_t fin = (int64_t)fi_ - (int64_t)numSamps * k - winLo;
             const int64_t cin = (int64_t)ci_ - (int64_t)numSamps * k - winLo;
+            if (!extended && cin - fin != 1 && (g_quirk_n == 0 || g_quirk_idx[(g_quirk_n - 1) % DPO_MAX_QUIRKS] != i)) {
+                if (g_quirk_n < DPO_MAX_QUIRKS) g_quirk_idx[g_quirk_n] = i;
+                g_quirk_n++;
+            }
             if (fin < 0 || cin < 0 || fin >= winLen || cin >= winLen) { nOob++; continue; }
             const double *row = codeWin + 2 * (int64_t)winLen * k;
             double wc = idx - fi_, wf = ci_ - idx;                            /* :1810-1811 */

@@ -79,6 +79,7 @@ int dpo_bcs_sv(const int16_t *iq, int S, double fs, const int8_t *chips,
  * LPower < 0: evaluate the index in long double (exponent |LPower|) -- not the reference's
  * arithmetic, only used to measure the reference's own fp64 cancellation noise.
  */
+int64_t dpo_bcm_pos_quirks(int64_t *idx, int64_t max);   /* see dpe_oracle.c: double-counted points of the last call */
 int dpo_bcm_pos(const double *satStates, const double *codeWin, int winLo, int winLen,
                 const double *centerPt, const double *grid, int64_t G,
                 const double *enu2ecef, const double *codeFreq, const int *cpRefTOW,

@@ -160,6 +160,15 @@ def bcm_pos(sat, code_win, win_lo, center, grid, R, fc, cp_ref_tow, cp_ela_end, 
     return scores, oob.value
 
 
+def bcm_pos_quirks():
+    """Indices of the grid points at which the last faithful bcm_pos call took the reference's double-counting branch
+    (floor(idx) and floor(idx+1) two apart; see dpe_oracle.c)."""
+    buf = np.zeros(256, dtype=np.int64)
+    lib().dpo_bcm_pos_quirks.restype = C.c_int64
+    n = lib().dpo_bcm_pos_quirks(_p(buf, C.c_int64), C.c_int64(256))
+    return buf[:min(n, 256)].copy()
+
+
 def bcm_vel(sat, carr_win, win_lo, center, grid, R, fi, rx_time, fs, num_fft, doppler_sign=1, lpower=1):
     sat = np.ascontiguousarray(sat, dtype=np.float64)
     K = sat.shape[0]

@@ -77,7 +77,8 @@ def run_oracle(case, L, B, lpower=1, windows=None):
         code, carr = np.stack(code), np.stack(carr)
         sp, oobp = o.bcm_pos(w["sat"], code, S // 2 - L, w["centre"], case["pos"], w["R"], w["fc"], w["cpRefTOW"],
                              w["cpElaEnd"], w["cpRef"], w["rcEnd"], w["rxTime"], fs, S, lpower)
-        spx, _ = o.bcm_pos(w["sat"], code, S // 2 - L, w["centre"], case["pos"], w["R"], w["fc"], w["cpRefTOW"],
+        quirks = o.bcm_pos_quirks()
+        spx, oobx = o.bcm_pos(w["sat"], code, S // 2 - L, w["centre"], case["pos"], w["R"], w["fc"], w["cpRefTOW"],
                            w["cpElaEnd"], w["cpRef"], w["rcEnd"], w["rxTime"], fs, S, lpower, extended=True)
         sv, oobv = o.bcm_vel(w["sat"], carr, C // 2 - B, w["centre"], case["vel"], w["R"], w["fi"], w["rxTime"], fs,
                              C, 1, lpower)
@@ -89,7 +90,9 @@ def run_oracle(case, L, B, lpower=1, windows=None):
         out["pos_x"].append(spx)
         out["vel"].append(sv)
         out["info"].append(info)
-        out["res"].append(dict(posIndex=ip, velIndex=iv, zVal=z, posOutOfWindow=oobp, velOutOfWindow=oobv))
+        out["res"].append(dict(posIndex=ip, velIndex=iv, zVal=z, posOutOfWindow=oobp, velOutOfWindow=oobv,
+                               posOutOfWindowX=oobx))
+        out.setdefault("pos_quirk", []).append(quirks)
         out.setdefault("R", []).append(w["R"])
         out.setdefault("centre", []).append(w["centre"])
     out["pos_grid"], out["vel_grid"] = case["pos"], case["vel"]
@@ -162,18 +165,39 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
         if check_scores:
             for name, rname, lim in (("pos", "pos_x", tol), ("pos", "pos", POS_REF_NOISE), ("vel", "vel", tol)):
                 r, g = ref[rname][w], gpu[name][w]
+                if rname == "pos":
+                    keep = np.ones(r.size, dtype=bool)
+                    # points where the reference's floor(idx) / floor(idx+1) pair double-counts (oracle/dpe_oracle.c):
+                    # its value there is decided by the last bit of its fp64 index; held to the continuous value only
+                    keep[ref["pos_quirk"][w]] = False
+                    if ref["res"][w]["posOutOfWindow"] > 0:
+                        # banks narrower than the grid reaches: a pair within the reference's own index noise of the
+                        # bank edge is dropped by one evaluation and kept by the other; a bounded number of such points
+                        # is set aside (they are still held to `tol` against the extended-precision index above)
+                        flips = np.abs(r - ref["pos_x"][w]) > 10 * POS_REF_NOISE * r.max()
+                        assert (flips & keep).sum() <= 16, "too many edge flips between the faithful and the extended index"
+                        keep &= ~flips
+                    r, g = r[keep], g[keep]
+                    if r.size == 0:
+                        continue
                 err = np.abs(g - r).max() / r.max()
                 worst[rname] = max(worst.get(rname, 0.0), err)
                 assert err < lim, "%s scores vs %s window %d: rel err %.3g" % (name, rname, w, err)
         rr, gr = ref["res"][w], gpu["res"][w]
         for name, key in (("pos", "posIndex"), ("vel", "velIndex")):
             if gr[key] != rr[key]:   # only acceptable as an fp32 tie
-                r = ref[name][w]
+                r, best = ref[name][w], rr[key]
+                if name == "pos" and len(ref["pos_quirk"][w]):
+                    r = ref["pos_x"][w]          # the faithful arg-max may sit on a double-counted point
+                    best = int(np.argmax(r))
                 lim = POS_REF_NOISE if name == "pos" else tol
-                assert abs(r[gr[key]] - r[rr[key]]) < lim * r.max(), "%s arg-max differs beyond tolerance" % name
+                assert abs(r[gr[key]] - r[best]) < lim * r.max(), "%s arg-max differs beyond tolerance" % name
         if gr["posIndex"] == rr["posIndex"] and gr["velIndex"] == rr["velIndex"]:
             assert np.abs(gr["zVal"] - rr["zVal"]).max() < 1e-6     # same grid point -> same fix
-        assert gr["posOutOfWindow"] == rr["posOutOfWindow"] and gr["velOutOfWindow"] == rr["velOutOfWindow"]
+        # pairs outside the banks: exact against the extended-precision index; the faithful fp64 index moves a few
+        # pairs at the window edges by its own rxTime - pr/C rounding (1.4e-4 samples) when the banks are narrow
+        assert gr["posOutOfWindow"] == rr["posOutOfWindowX"] and gr["velOutOfWindow"] == rr["velOutOfWindow"]
+        assert abs(gr["posOutOfWindow"] - rr["posOutOfWindow"]) <= 8
         if "zValMean" in gr and "pos_grid" in ref and np.any(gr["zValMean"] != 0):   # "Method 1" weighted-mean estimator vs fp64 sums of the oracle scores
             zp = (ref["pos_x"][w][:, None] * ref["pos_grid"]).sum(0) / ref["pos_x"][w].sum()
             zv = (ref["vel"][w][:, None] * ref["vel_grid"]).sum(0) / ref["vel"][w].sum()
