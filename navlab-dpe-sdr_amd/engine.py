@@ -107,14 +107,6 @@ def lib():
     return _lib
 
 
-def _quiet(fn):
-    """Finaliser helper: at interpreter shutdown module globals may already be gone."""
-    try:
-        fn()
-    except Exception:
-        pass
-
-
 def _check(rc):
     if rc != 0:
         raise DpeError(lib().dpe_last_error().decode("utf-8", "replace"))
@@ -274,7 +266,10 @@ class BatchCorrScores:
         return 0
 
     def __del__(self):
-        _quiet(self.Stop)
+        try:            # at interpreter shutdown module globals may already be gone
+            self.Stop()
+        except Exception:
+            pass
 
     # ---- host-side readers (tests / diagnostics)
     def read_banks(self, stream=None):
@@ -402,7 +397,10 @@ class BatchCorrManifold:
         return 0
 
     def __del__(self):
-        _quiet(self.Stop)
+        try:            # at interpreter shutdown module globals may already be gone
+            self.Stop()
+        except Exception:
+            pass
 
 
 class ChmConfig(C.Structure):
@@ -468,7 +466,10 @@ class ChanMgr:
         return 0
 
     def __del__(self):
-        _quiet(self.Stop)
+        try:            # at interpreter shutdown module globals may already be gone
+            self.Stop()
+        except Exception:
+            pass
 
 
 class AcqConfig(C.Structure):
@@ -562,7 +563,10 @@ class Acquisition:
             self._h = C.c_void_p(None)
 
     def __del__(self):
-        _quiet(self.close)
+        try:            # at interpreter shutdown module globals may already be gone
+            self.close()
+        except Exception:
+            pass
 
 
 class EkfConfig(C.Structure):
@@ -623,7 +627,10 @@ class cuEKF:
             self._h = C.c_void_p(None)
 
     def __del__(self):
-        _quiet(self.Stop)
+        try:            # at interpreter shutdown module globals may already be gone
+            self.Stop()
+        except Exception:
+            pass
 
 
 class HipEventTimer:
