@@ -270,6 +270,8 @@ typedef struct dpe_acq_config {
     int32_t prn[DPE_MAX_CHAN];
     int32_t reserved;
 } dpe_acq_config;
+/* cppr / cppm mask +-ceil(fs/F_CA) delays about the peak (correlator.py:96-99).  The reference's index array wraps at
+ * the low end only and raises IndexError for a peak that close to the LAST delay; here the mask wraps at both ends. */
 typedef struct dpe_acq_result {  /* return values of coarse_acquisition, correlator.py:86-103 */
     int32_t prn, found, maxCodeIdx, maxDoppIdx;
     double rc, fc, fi, cppr, cppm, peak;

@@ -307,12 +307,16 @@ def trim_mean(arr, percent):
     return sel.mean()
 
 
-def coarse_acquisition(iq, fs, prn, bins, coherent=True, mode=None, doppler_sign=1.0):
+def coarse_acquisition(iq, fs, prn, bins, coherent=True, mode=None, doppler_sign=1.0, wrap_mask=False):
     """numpy restatement of Correlator.coarse_acquisition (correlator.py:53-103).
 
     mode None -> the reference's semantics (coherent flag as given).  mode 'textbook' -> the
     BASELINE.json config-5 wording (1 ms coherent x N non-coherent): NOT a reference algorithm,
-    parity unpinned, provided for comparison only."""
+    parity unpinned, provided for comparison only.
+
+    The reference masks +-ceil(fs/F_CA) delays about the peak with a plain index array (correlator.py:96-99): negative
+    indices wrap, but a peak within that distance of the LAST delay indexes past the end and the reference raises
+    IndexError -- as does this restatement.  wrap_mask=True wraps both ends instead (what the HIP path does)."""
     iq = np.asarray(iq, dtype=np.int16)
     S = iq.size // 2
     N = int(round(S / fs / T_CA))
@@ -348,7 +352,8 @@ def coarse_acquisition(iq, fs, prn, bins, coherent=True, mode=None, doppler_sign
     peak = max_percode[max_code_idx]
     mask_S = int(np.ceil(fs / F_CA))
     mp = max_percode.copy()
-    mp[np.arange(-mask_S, mask_S + 1) + max_code_idx] = 0                      # negative indices wrap, as in numpy
+    mask_idx = np.arange(-mask_S, mask_S + 1) + max_code_idx
+    mp[mask_idx % mp.size if wrap_mask else mask_idx] = 0                      # negative indices wrap, as in numpy
     cppr = peak / mp.max()
     cppm = peak / trim_mean(mp, 10)
     return dict(surface=res_abs, max_code_idx=max_code_idx, max_dopp_idx=max_dopp_idx, rc=rc, fi=fi, fc=fc,

@@ -68,3 +68,68 @@ def test_random_case(i):
     except Exception:
         print("fuzz case %d: %r" % (i, p))
         raise
+
+
+N_ACQ = int(os.environ.get("DPE_FUZZ_ACQ_CASES", "6"))
+
+
+def draw_acq(i):
+    rng = np.random.Generator(np.random.PCG64(SEED * 7919 + i))
+    fs = float(rng.choice([2.046e6, 2.5e6, 4.0e6]))
+    n_ms = int(rng.choice([2, 4, 5, 10]))
+    mode = str(rng.choice(["coherent", "noncoherent", "textbook"]))
+    present = sorted(int(p) for p in rng.choice(np.arange(1, 33), size=int(rng.integers(1, 5)), replace=False))
+    absent = sorted(int(p) for p in rng.choice([p for p in range(1, 38) if p not in present],
+                                               size=int(rng.integers(0, 4)), replace=False))
+    if mode == "coherent":          # a coherent sum over n_ms ms resolves 1/(n_ms ms): raster of half that
+        step = float(rng.choice([50.0, 100.0])) * 10.0 / n_ms
+    else:
+        step = float(rng.choice([250.0, 500.0]))
+    nb = int(rng.integers(3, 40)) | 1
+    return dict(seed=5000 + i, fs=fs, S=int(round(fs * 1e-3)) * n_ms, mode=mode, present=present, absent=absent, step=step,
+                nb=nb, chunk=int(rng.choice([0, 1, 3, 32])), amp=float(rng.choice([100.0, 200.0])))
+
+
+@pytest.mark.parametrize("i", range(N_ACQ))
+def test_random_acquisition_case(i):
+    """Coarse acquisition vs the oracle's restatement of Correlator.coarse_acquisition: window lengths of 2..10 code
+    periods at three sampling rates, all three modes, random PRN sets (present and absent), rasters and chunk sizes."""
+    import torch
+    import navlab_dpe_sdr_amd as dpe
+    o = helpers._oracle()
+    p = draw_acq(i)
+    try:
+        fs, S = p["fs"], p["S"]
+        K = len(p["present"])
+        ch = dpe.synth.random_channels(p["seed"], K, prns=p["present"])
+        bins = (np.arange(p["nb"]) - p["nb"] // 2) * p["step"]
+        ch["fi"] = np.random.Generator(np.random.PCG64(p["seed"] + 1)).uniform(bins[0], bins[-1], K)   # inside the raster
+        ch["fc"] = 1.023e6 * (1.0 + ch["fi"] / 1.57542e9)
+        ch["cp_ref"] = ch["cp"].copy()
+        iq = dpe.synth.gen_iq(p["seed"] + 2, fs, S, ch, amp=p["amp"], flip=np.zeros(K, dtype=bool))
+        prns = p["present"] + p["absent"]
+        acq = dpe.Acquisition(fs, S, prns, bins, mode=p["mode"], prn_chunk=p["chunk"])
+        acq.search(torch.from_numpy(iq).to("cuda:0"))
+        res, surf = acq.results(), acq.read_surface()
+        acq.close()
+        for q, prn in enumerate(prns):
+            kw = dict(coherent=(p["mode"] == "coherent"), mode="textbook" if p["mode"] == "textbook" else None)
+            try:
+                ref = o.coarse_acquisition(iq, fs, prn, bins, **kw)
+            except IndexError:
+                # peak within ceil(fs/F_CA) delays of the last one: the reference's mask indexes past the end and raises
+                # (correlator.py:96-99); the HIP path wraps the mask at both ends
+                ref = o.coarse_acquisition(iq, fs, prn, bins, wrap_mask=True, **kw)
+            peak = ref["surface"].max()
+            assert np.abs(surf[q] - ref["surface"]).max() < 2e-5 * peak, "surface PRN %d" % prn
+            r = res[q]
+            if (r["max_code_idx"], r["max_dopp_idx"]) != (ref["max_code_idx"], ref["max_dopp_idx"]):   # fp32 tie only
+                assert ref["surface"][r["max_dopp_idx"], r["max_code_idx"]] > peak * (1 - 2e-5)
+            else:
+                assert abs(r["rc"] - ref["rc"]) < 1e-9 and r["fi"] == ref["fi"]
+                assert abs(r["cppr"] / ref["cppr"] - 1) < 1e-4 and abs(r["cppm"] / ref["cppm"] - 1) < 1e-4
+                if abs(ref["cppm"] - 2.0) > 1e-3:
+                    assert r["found"] == ref["found"]
+    except Exception:
+        print("acquisition fuzz case %d: %r" % (i, p))
+        raise
