@@ -82,6 +82,49 @@ def test_chanmgr_matches_oracle(built, oracle):
     cm.Stop()
 
 
+@pytest.mark.parametrize("seed,T,n", [(1, 0.02, 120), (2, 0.005, 150), (3, 0.001, 200), (4, 0.02, 60)])
+def test_chanmgr_long_runs_random_subsets(built, oracle, seed, T, n):
+    """Product cuChanMgr vs the oracle over long runs: random SV subsets, window lengths of 1 / 5 / 20 ms (code-period
+    counters and nav-bit references roll over many times), a receiver that accelerates and whose fix is noisy.
+    Integer state must agree exactly at every step; phases must not drift apart."""
+    from tests import helpers
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ho = dpe.handoff.read_handoff(helpers.HANDOFF)
+    K = int(rng.integers(1, 9))
+    sel = np.sort(rng.choice(8, size=K, replace=False))
+    sub = dict(ho)
+    for key in ("prn_list", "rc", "ri", "fc", "fi", "cp", "cp_timestamp", "TOW", "eph"):
+        sub[key] = ho[key][sel]
+    tg = np.array([-2.0, -1.0, 0.0, 1.0, 2.0]) * 6.0
+    cm = dpe.ChanMgr.from_handoff(sub, T)
+    om = oracle.ChanMgr(sub["prn_list"], sub["rc"], sub["ri"], sub["fc"], sub["fi"], sub["cp"], sub["cp_timestamp"],
+                        sub["TOW"], sub["eph"], sub["rxTime"], T)
+    x = ho["X_ECEF"].copy()
+    v = rng.uniform(-30.0, 30.0, 3)
+    for it in range(n):
+        x[:3] += v * T
+        v += rng.uniform(-2.0, 2.0, 3) * T
+        x[4:7] = v
+        xk = x + np.concatenate([rng.normal(0, 2.0, 4), rng.normal(0, 0.1, 4)])       # the fix fed back
+        centre = xk + np.concatenate([rng.normal(0, 1.0, 4), np.zeros(4)])
+        if it == 0:
+            cm.Start(xk, centre, tg)
+            ob, oR = om.start(xk, centre, tg)
+        else:
+            cm.Update(xk, centre, tg)
+            ob, oR = om.update(xk, centre, tg)
+        s, e, w, batch = cm.outputs(with_batch=True)
+        assert np.array_equal(s["cpElapsedStart"], om.cpElaStart) and np.array_equal(e["cpElapsedEnd"], om.cpElaEnd), it
+        assert np.array_equal(e["cpRef"], om.cpRef) and np.array_equal(e["cpRefTOW"], om.cpRefTOW), it
+        assert np.abs(s["codePhaseStart"] - om.rcStart).max() < 1e-8 and np.abs(e["codePhaseEnd"] - om.rcEnd).max() < 1e-8, it
+        d = np.abs(s["carrierPhaseStart"] - om.riStart)
+        assert np.minimum(d, 1.0 - d).max() < 1e-7, it
+        assert np.abs(s["codeFrequency"] - om.fc).max() < 1e-6 and np.abs(s["carrierFrequency"] - om.fi).max() < 1e-6, it
+        assert w["rxTime"][0] == om.rxTime, it
+        assert np.abs(batch - ob).max() < 1e-5 and np.abs(w["enu2ecef"][0] - oR).max() < 1e-13, it
+    cm.Stop()
+
+
 @pytest.mark.parametrize("gtype,dim,sp", [(0, 5, 1.0), (0, 6, 0.5), (2, 9, 1.5), (2, 25, 1.0)])
 def test_host_grid_builders_match_oracle(built, oracle, tmp_path, gtype, dim, sp):
     """C++ host (host/grids.hpp via `dpe_flow --dump-grid`) vs the oracle's BCM_InitPosGrid restatement."""
