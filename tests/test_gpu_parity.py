@@ -637,3 +637,40 @@ def test_hbm_ceiling_diagnostic():
     assert 1000.0 < cp < 8000.0 and 1000.0 < tr < 8000.0
     with pytest.raises(dpe.DpeError):
         dpe.engine.hbm_ceiling(16, 5)
+
+
+def test_reference_maximum_grid_size():
+    """BCM_MAX_GRID_SIZE = 2 * 75^4 (batchcorrmanifold.h:17): a 75^4 = 31 640 625-point Cartesian position grid plus a
+    velocity grid of the same size in one call.  The oracle scores every 997th point (and the neighbourhood of the
+    maximum); the arg-max the scan reports must be the first maximum of the scores it wrote."""
+    import torch
+    dim = 75
+    case = helpers.make_case(seed=23, S=12500, K=4, G=16, amp=200.0, grid="uniform")   # grids replaced below
+    pos = dpe.synth.uniform_grid(dim, 1.0)
+    vel = dpe.synth.uniform_grid(dim, 0.1)
+    G = dim ** 4
+    assert pos.shape[0] == G
+    iq, cs, ce, bw = helpers.pack_gpu_inputs(case)
+    L, B = 6, 32
+    bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=L, bin_half_width=B, max_channels=4)
+    bcs.Start()
+    bcm = dpe.BatchCorrManifold(case["fs"], case["S"], bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B,
+                                max_channels=4, write_scores=True)
+    bcm.Start()
+    bcs.Update(torch.from_numpy(iq).to("cuda:0"), cs)
+    bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+    r = bcm.results()[0]
+    ps, vs = bcm.read_scores()
+    bcm.Stop(); bcs.Stop()
+    assert r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0
+    assert r["posIndex"] == int(np.argmax(ps[0])) and r["velIndex"] == int(np.argmax(vs[0]))
+    assert r["posScore"] == ps[0].max() and r["velScore"] == vs[0].max()
+    # oracle on a strided subset plus the tail and the neighbourhood of the maxima
+    for name, grid, sc, best in (("pos", pos, ps[0], r["posIndex"]), ("vel", vel, vs[0], r["velIndex"])):
+        idx = np.unique(np.concatenate([np.arange(0, G, 997), np.arange(G - 300, G),
+                                        np.clip(np.arange(best - 200, best + 200), 0, G - 1)]))
+        sub = dict(case, pos=grid[idx] if name == "pos" else case["pos"], vel=grid[idx] if name == "vel" else case["vel"])
+        ref = helpers.run_oracle(sub, L, B)
+        want = ref["pos_x" if name == "pos" else "vel"][0]
+        assert np.abs(sc[idx] - want).max() < TOL * want.max(), name
+        assert sc[best] >= want.max() * (1 - TOL)
