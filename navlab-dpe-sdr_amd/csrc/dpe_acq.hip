@@ -353,14 +353,20 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             rep[p * h->len + i] = make_float2((float)acc, 0.f);
         }
     }
-    DPE_CHECK_HIP(hipMemcpy(h->Rc_d, rep.data(), sizeof(float2) * rep.size(), hipMemcpyHostToDevice));
-    {
-        hipfftHandle pr;
+    hipfftHandle pr = 0;
+    const auto finish = [&]() -> int {   // a failure here must leak neither the handle nor the temporary plan
+        DPE_CHECK_HIP(hipMemcpy(h->Rc_d, rep.data(), sizeof(float2) * rep.size(), hipMemcpyHostToDevice));
         DPE_CHECK_FFT(hipfftPlanMany(&pr, 1, n, nullptr, 1, h->len, nullptr, 1, h->len, HIPFFT_C2C, (int)P));
         DPE_CHECK_FFT(hipfftExecC2C(pr, (hipfftComplex *)h->Rc_d, (hipfftComplex *)h->Rc_d, HIPFFT_FORWARD));
         hipLaunchKernelGGL(acq_conj_scale_kernel, dim3(256), dim3(256), 0, 0, h->Rc_d, (long long)(P * h->len), 1.0f / (float)h->len);
         DPE_CHECK_HIP(hipDeviceSynchronize());
-        hipfftDestroy(pr);
+        return 0;
+    };
+    const int rc = finish();
+    if (pr) hipfftDestroy(pr);
+    if (rc) {
+        dpe_acq_destroy(h);
+        return -1;
     }
     *out = h;
     return 0;

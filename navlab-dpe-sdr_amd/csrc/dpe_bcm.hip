@@ -528,12 +528,19 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     for (size_t i = 0; i < 4 * W + 8; ++i) h->keys_h[i] = 0ull;
     h->pollAllowed = getenv("DPE_BCM_NO_POLL") == nullptr;
     h->sv_h = h->svBase_h;
-    for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    DPE_CHECK_HIP(hipMemset(h->keys_d, 0, 8 * W * sizeof(unsigned long long)));
-    h->done_d = dev_alloc<unsigned int>(1);
-    DPE_REQUIRE(h->done_d, "[BatchCorrManifold] create: device allocation failed");
-    DPE_CHECK_HIP(hipMemset(h->done_d, 0, sizeof(unsigned int)));
-    DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->keys_hd, h->keys_h, 0));
+    const auto finish = [&]() -> int {   // a failure from here on must not leak the handle
+        for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DPE_CHECK_HIP(hipMemset(h->keys_d, 0, 8 * W * sizeof(unsigned long long)));
+        h->done_d = dev_alloc<unsigned int>(1);
+        DPE_REQUIRE(h->done_d, "[BatchCorrManifold] create: device allocation failed");
+        DPE_CHECK_HIP(hipMemset(h->done_d, 0, sizeof(unsigned int)));
+        DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->keys_hd, h->keys_h, 0));
+        return 0;
+    };
+    if (finish()) {
+        dpe_bcm_destroy(h);
+        return -1;
+    }
     h->win_h.resize(W);
     *out = h;
     return 0;

@@ -1069,12 +1069,19 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         dpe_bcs_destroy(h);
         return -1;
     }
-    DPE_CHECK_HIP(hipMemcpy(h->chipTable_d, table.data(), table.size(), hipMemcpyHostToDevice));
-    DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
-    DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
+    const auto finish = [&]() -> int {   // a failure from here on must not leak the handle
+        DPE_CHECK_HIP(hipMemcpy(h->chipTable_d, table.data(), table.size(), hipMemcpyHostToDevice));
+        DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
+        DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
+        for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return 0;
+    };
+    if (finish()) {
+        dpe_bcs_destroy(h);
+        return -1;
+    }
     h->idxNext_h.assign(W * K, 0);
     h->chan_h = h->chanBase_h;
-    for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     h->wideAllowed = getenv("DPE_BCS_NO_WIDE") == nullptr;
     h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
     h->fuseAllowed = getenv("DPE_BCS_NO_FUSE") == nullptr;
