@@ -46,6 +46,7 @@ void set_error(const char *fmt, ...);
 
 void gen_ca_code_host(int prn, int8_t *chips);  // dpe_util.hip
 
+#ifdef __HIPCC__   // device helpers: the host-only sources (dpe_chanmgr.hip, dpe_ekf.hip) also build with a plain C++ compiler
 // 64-lane butterfly sum; every lane ends with the total.
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -94,6 +95,7 @@ __device__ __forceinline__ float lane63(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#endif  // __HIPCC__
 
 // Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
 struct KernelProfiler {
