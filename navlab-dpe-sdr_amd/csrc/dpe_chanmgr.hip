@@ -27,7 +27,9 @@ static bool solve_kepler(double M, double e, double &E)  // :97-107
     E = M;
     double dE = 1.0;
     for (int it = 0; it < 10 && std::fabs(dE) > 1e-12; ++it) {
-        dE = (M - E + e * std::sin(E)) / (1.0 - e * std::cos(E));
+        double sE, cE;
+        sincos(E, &sE, &cE);   // glibc: bit-identical to sin() and cos(), one argument reduction
+        dE = (M - E + e * sE) / (1.0 - e * cE);
         E = std::fmod(E + dE, k2Pi);
     }
     return std::fabs(dE) <= 1e-12;
@@ -49,27 +51,35 @@ static int sat_state(const Eph &p, double tx, double out[8])
     const double clkd = p.f1 + 2.0 * p.f2 * tc;
     tk = half_week(tx - clkb - p.toes);
     if (!solve_kepler(std::fmod(p.M0 + n * tk, k2Pi), p.e, E)) return -1;
-    const double sE = std::sin(E), cE = std::cos(E), den = 1.0 - p.e * cE;
+    double sE, cE;
+    sincos(E, &sE, &cE);
+    const double den = 1.0 - p.e * cE;
     const double nu = std::atan2(std::sqrt(1.0 - p.e * p.e) * sE / den, (cE - p.e) / den);
     double u = std::fmod(nu + p.omg, k2Pi);
-    double c2 = std::cos(2.0 * u), s2 = std::sin(2.0 * u);
+    double c2, s2;
+    sincos(2.0 * u, &s2, &c2);
     u += p.cuc * c2 + p.cus * s2;
     const double r = A * den + p.crc * c2 + p.crs * s2;
     const double inc = p.i0 + p.idot * tk + p.cic * c2 + p.cis * s2;
     const double Om = std::fmod(p.OMG0 + (p.OMGd - kOEDot) * tk - kOEDot * p.toes, k2Pi);
-    const double xo = r * std::cos(u), yo = r * std::sin(u);
-    const double cO = std::cos(Om), sO = std::sin(Om), ci = std::cos(inc), si = std::sin(inc);
+    double su, cu, sO, cO, si, ci;
+    sincos(u, &su, &cu);
+    sincos(Om, &sO, &cO);
+    sincos(inc, &si, &ci);
+    const double xo = r * cu, yo = r * su;
     out[0] = xo * cO - yo * sO * ci;
     out[1] = xo * sO + yo * cO * ci;
     out[2] = yo * si;
     out[3] = clkb;
-    c2 = std::cos(2.0 * u); s2 = std::sin(2.0 * u);  // recomputed with the corrected u (:180-181)
+    sincos(2.0 * u, &s2, &c2);  // recomputed with the corrected u (:180-181)
     const double Ed = n / den;
-    const double nud = sE * Ed * (1.0 + p.e * std::cos(nu)) / (std::sin(nu) * den);
+    double snu, cnu;
+    sincos(nu, &snu, &cnu);
+    const double nud = sE * Ed * (1.0 + p.e * cnu) / (snu * den);
     const double ud = nud + 2.0 * (p.cus * c2 - p.cuc * s2) * nud;
     const double rd = A * p.e * sE * Ed + 2.0 * (p.crs * c2 - p.crc * s2) * nud;
     const double id = p.idot + (p.cis * c2 - p.cic * s2) * 2 * nud;
-    const double vxo = rd * std::cos(u) - yo * ud, vyo = rd * std::sin(u) + xo * ud;
+    const double vxo = rd * cu - yo * ud, vyo = rd * su + xo * ud;
     const double Omd = p.OMGd - kOEDot;
     const double ta = vxo - yo * ci * Omd, tb = xo * Omd + vyo * ci - yo * si * id;
     out[4] = ta * cO - tb * sO;
@@ -98,9 +108,15 @@ static double tx_of(const Chan &c, double cpEla, double rc)  // :258-260
 }
 
 // Earth-rotation of a satellite state by the signal time of flight (:383-404, :895-916)
+static void rotate_state_cs(const double s[8], double ct, double st, double o[8]);
 static void rotate_state(const double s[8], double tau, double o[8])
 {
-    const double ct = std::cos(-kOEDot * tau), st = std::sin(-kOEDot * tau);
+    double ct, st;
+    sincos(-kOEDot * tau, &st, &ct);
+    rotate_state_cs(s, ct, st, o);
+}
+static void rotate_state_cs(const double s[8], double ct, double st, double o[8])
+{
     o[0] = ct * s[0] - st * s[1];
     o[1] = st * s[0] + ct * s[1];
     o[2] = s[2];
@@ -164,21 +180,36 @@ static void grid_prep(dpe_chanmgr *h, const double *xkk1, const double *timeGrid
     using namespace dpe;
     const int K = (int)h->ch.size();
     h->dimT = dimT;
-    h->batch.assign((size_t)K * dimT * 8, 0.0);
+    h->batch.resize((size_t)K * dimT * 8);
     memcpy(h->xkk1, xkk1, sizeof(double) * 8);
-    for (int k = 0; k < K; ++k)
-        for (int t = 0; t < dimT; ++t) {  // CHM_GridPrep :892-916
-            const Chan &c = h->ch[k];
+    const int mid = dimT / 2;
+    for (int k = 0; k < K; ++k) {  // CHM_GridPrep :892-916
+        const Chan &c = h->ch[k];
+        // The entry the ML kernels read (dimT/2, BCM :1775) takes the reference's own evaluation.  The others differ from it
+        // by a clock-offset step of metres / c in the time of flight, i.e. by d <= 1e-10 rad of Earth rotation: their
+        // rotation is the mid one advanced to first order, cos(a+d) = cos a - d sin a, sin(a+d) = sin a + d cos a -- the
+        // d^2/2 <= 1e-20 remainder is far below the last bit -- instead of 2 (dimT-1) more sin/cos evaluations per SV.
+        const double tau0 = h->rxTime - (c.txTime + ((timeGrid[mid] + xkk1[3]) / kC)) + c.sat[3];
+        double ct0, st0;
+        sincos(-kOEDot * tau0, &st0, &ct0);
+        for (int t = 0; t < dimT; ++t) {
+            double *o = &h->batch[((size_t)k * dimT + t) * 8];
+            if (t == mid) { rotate_state_cs(c.sat, ct0, st0, o); continue; }
             const double tau = h->rxTime - (c.txTime + ((timeGrid[t] + xkk1[3]) / kC)) + c.sat[3];
-            rotate_state(c.sat, tau, &h->batch[((size_t)k * dimT + t) * 8]);
+            const double d = -kOEDot * (tau - tau0);
+            if (std::fabs(d) < 1e-8) rotate_state_cs(c.sat, ct0 - d * st0, st0 + d * ct0, o);
+            else rotate_state(c.sat, tau, o);   // a time grid of kilometres: evaluate directly
         }
+    }
     // CHM_Dev_ECEF2LL_Rad :37-50 + CHM_Dev_R_ENU2ECEF :54-73
     const double p = std::sqrt(xkk1[0] * xkk1[0] + xkk1[1] * xkk1[1]);
     const double th = std::atan2(xkk1[2] * kWgsA, p * kWgsB);
     const double lat = std::atan2(xkk1[2] + std::pow(kWgsEp, 2) * kWgsB * std::pow(std::sin(th), 3),
                                   p - std::pow(kWgsE, 2) * kWgsA * std::pow(std::cos(th), 3));
     const double lon = std::atan2(xkk1[1], xkk1[0]);
-    const double sa = std::sin(lat), ca = std::cos(lat), so = std::sin(lon), co = std::cos(lon);
+    double sa, ca, so, co;
+    sincos(lat, &sa, &ca);
+    sincos(lon, &so, &co);
     const double Rm[9] = {-so, -sa * co, ca * co, co, -sa * so, ca * so, 0.0, ca, sa};
     memcpy(h->R, Rm, sizeof(Rm));
 }
