@@ -270,6 +270,7 @@ class BatchCorrScores : public Module {
         InsertParam("LagHalfWidth", &lagHalf, INT_t, sizeof(int), sizeof(int));
         InsertParam("BinHalfWidth", &binHalf, INT_t, sizeof(int), sizeof(int));
         InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
+        InsertParam("SyncOutputs", &syncOutputs, BOOL_t, sizeof(bool), sizeof(bool));
     }
     ~BatchCorrScores() override { Stop(); }
     int Start(void *) override
@@ -313,7 +314,9 @@ class BatchCorrScores : public Module {
         if (dpe_bcs_update(h, (const int16_t *)inputs[0]->Data, S, 1, K, ch, st)) { Stop(); return -1; }
         // The reference synchronises here (:1192-1195).  The banks are consumed by BatchCorrManifold on the
         // same flow stream, so stream order already guarantees they are complete there; not waiting lets
-        // BatchCorrManifold's host-side geometry overlap the correlator kernels.
+        // BatchCorrManifold's host-side geometry overlap the correlator kernels.  SyncOutputs = true restores the
+        // reference's contract (outputs complete when Update returns) for a consumer on another stream.
+        if (syncOutputs && dpe_stream_synchronize(st)) { Stop(); return -1; }
         return 0;
     }
     int Stop() override
@@ -330,6 +333,7 @@ class BatchCorrScores : public Module {
     bool Started = false;
     int lagHalf = 8, binHalf = 48, carrSTot = 0, S = 0;
     bool useGraph = false;  // replay the per-window launch sequence as one hipGraph (dpe_hip.h; measured slower)
+    bool syncOutputs = false;
 };
 
 // ------------------------------------------------------------------------------------------------
