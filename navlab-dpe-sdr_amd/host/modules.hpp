@@ -201,7 +201,7 @@ class SampleBlock : public Module {
     }
 
   private:
-    static constexpr int kNumBlocks = 8;
+    static constexpr int kNumBlocks = 32;   // NumBlocksDefault, sampleblock.h:78
     struct Slot { int16_t *host = nullptr, *dev = nullptr; bool ready = false; };
     void ReaderLoop()   // GetSamplesThread (sampleblock.cu:312-463): read -> pinned -> async H2D on a private stream
     {
