@@ -118,7 +118,9 @@ int dpe_bcs_export_dense(dpe_bcs *h, int32_t window, double *codeScores_dev,
 typedef struct dpe_bcm_config {
     int32_t samplesPerWindow;   /* S  (numSamps, batchcorrmanifold.cu:2536) */
     int32_t lagHalfWidth;       /* must equal the L of the banks passed to dpe_bcm_update */
-    int32_t binHalfWidth;       /* must equal the B of the banks */
+    int32_t binHalfWidth;       /* must equal the B of the banks.  The scan keeps all maxChannels banks in LDS:
+                                 * maxChannels * ((2 max(L,B) + 1) * 16 + 32) <= 150 KB, i.e. max(L,B) <= 129 at 37
+                                 * channels, 599 at 8 (create refuses more) */
     int32_t lPower;             /* LPower param (batchcorrmanifold.cu:2290) */
     int32_t maxWindows;
     int32_t maxChannels;
@@ -169,7 +171,8 @@ typedef struct dpe_bcm_result {
     /* "Method 1" of BatchCorrManifold::Update (:2546-2567, kernels :816-1056,1365-1510; what PyGNSS'
      * folded dp_measurement_estimation does, receiver.py:317-318): score-weighted mean state.
      * weightedSums[m] = {sum s, sum s*x, sum s*y, sum s*z, sum s*t} over the local shard of manifold m
-     * (ENU offsets; all-reduce(SUM) them across shards), zValMean = the resulting ECEF state. */
+     * (ENU offsets; all-reduce(SUM) them across shards), zValMean = the resulting ECEF state (NaN, as in the
+     * reference, when every score of a manifold is 0, e.g. every pair outside the banks). */
     double zValMean[8];
     double weightedSums[2][5];
 } dpe_bcm_result;

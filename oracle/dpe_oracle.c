@@ -222,8 +222,13 @@ int dpo_bcm_pos(const double *sat, const double *codeWin, int winLo, int winLen,
             if (!(base < numSamps && base > 0)) { nOob++; continue; }         /* :1795 */
             const double idx = base + ((double)numSamps * k);                 /* :1797 */
             const double fi_ = floor(idx), ci_ = floor(idx + 1);              /* :1798-1799 */
-            const int64_t fin = (int64_t)fi_ - (int64_t)numSamps * k - winLo;
-            const int64_t cin = (int64_t)ci_ - (int64_t)numSamps * k - winLo;
+            int64_t fin = (int64_t)fi_ - (int64_t)numSamps * k - winLo;
+            int64_t cin = (int64_t)ci_ - (int64_t)numSamps * k - winLo;
+            if (extended) {   /* neighbours and weight from the SAME long-double index (an index within a double rounding
+                               * step of an integer would otherwise pair floor(double) with frac(long double)) */
+                fin = (int64_t)floorl(baseLd) - winLo;
+                cin = fin + 1;
+            }
             if (!extended && cin - fin != 1 && (g_quirk_n == 0 || g_quirk_idx[(g_quirk_n - 1) % DPO_MAX_QUIRKS] != i)) {
                 if (g_quirk_n < DPO_MAX_QUIRKS) g_quirk_idx[g_quirk_n] = i;
                 g_quirk_n++;

@@ -142,7 +142,7 @@ def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True, repeats
 POS_REF_NOISE = 1e-4
 
 
-def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
+def assert_parity(gpu, ref, tol=2e-5, check_scores=True, pos_ref_noise=None):
     """fp32 HIP path vs fp64 oracle.  Tolerances are relative to the peak magnitude / max score.
 
     Position-manifold scores are held to `tol` against the oracle's extended-precision index
@@ -150,6 +150,7 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
     `rxTime - pr/C` (batchcorrmanifold.cu:1784, rxTime ~4e5 s) rounds at 5.8e-11 s = 17 mm =
     1.4e-4 samples per (point, SV), i.e. ~3e-5 of the score -- measured, see DESIGN.md."""
     n = len(ref["res"])
+    pos_noise = POS_REF_NOISE if pos_ref_noise is None else pos_ref_noise
     worst = dict(code=0.0, carr=0.0, pos=0.0, vel=0.0)
     for w in range(n):
         for name in ("code", "carr"):
@@ -163,7 +164,7 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
         rm = ref["info"][w][0]["mean"]
         assert gpu["mean"][w] == rm, "DC mean must be bit-exact (integer sums)"
         if check_scores:
-            for name, rname, lim in (("pos", "pos_x", tol), ("pos", "pos", POS_REF_NOISE), ("vel", "vel", tol)):
+            for name, rname, lim in (("pos", "pos_x", tol), ("pos", "pos", pos_noise), ("vel", "vel", tol)):
                 r, g = ref[rname][w], gpu[name][w]
                 if rname == "pos":
                     keep = np.ones(r.size, dtype=bool)
@@ -174,12 +175,17 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
                         # banks narrower than the grid reaches: a pair within the reference's own index noise of the
                         # bank edge is dropped by one evaluation and kept by the other; a bounded number of such points
                         # is set aside (they are still held to `tol` against the extended-precision index above)
-                        flips = np.abs(r - ref["pos_x"][w]) > 10 * POS_REF_NOISE * r.max()
-                        assert (flips & keep).sum() <= 16, "too many edge flips between the faithful and the extended index"
+                        flips = np.abs(r - ref["pos_x"][w]) > 10 * pos_noise * r.max()
+                        # expected number: (pairs per sample of index) x 2 edges x the reference's 1.4e-4-sample noise
+                        allowed = 16 + r.size * len(ref["info"][w]) // 2000
+                        assert (flips & keep).sum() <= allowed, "too many edge flips between the faithful and the extended index"
                         keep &= ~flips
                     r, g = r[keep], g[keep]
                     if r.size == 0:
                         continue
+                if r.max() == 0:          # every pair of every point outside the banks: all scores exactly 0
+                    assert not g.any()
+                    continue
                 err = np.abs(g - r).max() / r.max()
                 worst[rname] = max(worst.get(rname, 0.0), err)
                 assert err < lim, "%s scores vs %s window %d: rel err %.3g" % (name, rname, w, err)
@@ -190,14 +196,16 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True):
                 if name == "pos" and len(ref["pos_quirk"][w]):
                     r = ref["pos_x"][w]          # the faithful arg-max may sit on a double-counted point
                     best = int(np.argmax(r))
-                lim = POS_REF_NOISE if name == "pos" else tol
-                assert abs(r[gr[key]] - r[best]) < lim * r.max(), "%s arg-max differs beyond tolerance" % name
+                lim = pos_noise if name == "pos" else tol
+                assert abs(r[gr[key]] - r[best]) <= lim * r.max(), "%s arg-max differs beyond tolerance" % name
         if gr["posIndex"] == rr["posIndex"] and gr["velIndex"] == rr["velIndex"]:
             assert np.abs(gr["zVal"] - rr["zVal"]).max() < 1e-6     # same grid point -> same fix
         # pairs outside the banks: exact against the extended-precision index; the faithful fp64 index moves a few
         # pairs at the window edges by its own rxTime - pr/C rounding (1.4e-4 samples) when the banks are narrow
         assert gr["posOutOfWindow"] == rr["posOutOfWindowX"] and gr["velOutOfWindow"] == rr["velOutOfWindow"]
-        assert abs(gr["posOutOfWindow"] - rr["posOutOfWindow"]) <= 8
+        assert abs(gr["posOutOfWindow"] - rr["posOutOfWindow"]) <= 8 + ref["pos"][w].size * len(ref["info"][w]) // 2000
+        if ref["pos_x"][w].sum() == 0 or ref["vel"][w].sum() == 0:
+            continue    # a manifold whose every score is 0 has no weighted mean (0/0, NaN here as in the reference)
         if "zValMean" in gr and "pos_grid" in ref and np.any(gr["zValMean"] != 0):   # "Method 1" weighted-mean estimator vs fp64 sums of the oracle scores
             zp = (ref["pos_x"][w][:, None] * ref["pos_grid"]).sum(0) / ref["pos_x"][w].sum()
             zv = (ref["vel"][w][:, None] * ref["vel_grid"]).sum(0) / ref["vel"][w].sum()

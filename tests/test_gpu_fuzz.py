@@ -39,6 +39,7 @@ def draw(i):
     C = 8 * (1 << int(np.ceil(np.log2(S))))
     b_max = int(np.floor((720 * 2e-7) ** (1.0 / 6.0) * C / (2 * np.pi * 127.5) * 0.999))
     B = min(int(rng.choice([12, 20, 32, 33, 64, b_max])), b_max)
+    B = min(B, (150 * 1024 // K - 32) // 16 // 2 - 1)   # all K banks must fit the scan's LDS (dpe_bcm_config.binHalfWidth)
     lpower = int(rng.choice([1, 1, 2]))
     amp = float(rng.choice([48.0, 200.0]))
     # drawn after everything else so that the first round's sweep keeps its parameters
@@ -64,7 +65,8 @@ def test_random_case(i):
     try:
         out = helpers.run_gpu(case, p["L"], p["B"], lpower=p["lpower"])
         ref = helpers.run_oracle(case, p["L"], p["B"], lpower=p["lpower"])
-        helpers.assert_parity(out, ref, tol=float(os.environ.get('DPE_FUZZ_TOL', '1e-5')))
+        # one or two SVs on a handful of points: nothing averages the reference's own index noise (1.4e-4 samples per pair)
+        helpers.assert_parity(out, ref, tol=float(os.environ.get('DPE_FUZZ_TOL', '1e-5')), pos_ref_noise=3e-4)
     except Exception:
         print("fuzz case %d: %r" % (i, p))
         raise
