@@ -186,8 +186,8 @@ int dpe_bcm_destroy(dpe_bcm *h);                                   /* ::Stop :24
 int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev,
                    int32_t nWindows, int32_t nChan, const dpe_bcm_window *win_host,
                    const dpe_chan_end *chan_host, dpe_stream_t stream);
-/* Waits for the last Update (single windows: polls the sequence word the kernel writes behind the results in pinned
- * memory; otherwise synchronises `stream`) and returns the per-window ML results (zVal/RVal ports; RVal is the
+/* Waits for the last Update (single windows without the weighted-mean estimator: polls the sequence word the kernel writes
+ * behind the results in pinned memory; otherwise synchronises `stream`) and returns the per-window ML results (zVal/RVal ports; RVal is the
  * 8x8 identity the reference writes, :2003-2011,2055-2063).  results: [nWindows]. */
 int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream);
 /* PosScores port (:2300,2404) and its velocity twin: float [maxWindows][gridSize]. */

@@ -671,7 +671,9 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     a.seq = ++h->seq;
     // (a replayed graph carries a stale sequence argument: polling only for eager single-window launches whose mirror
     //  has the sequence word right behind the results, i.e. maxWindows == 1)
-    h->pollable = nWindows == 1 && W == 1 && !h->graphs.capturing && h->pollAllowed;
+    // (with the weighted-mean estimator the per-block sums are fetched with a copy after the results arrive: that copy must
+    //  see the finished kernel, so the stream is waited for instead)
+    h->pollable = nWindows == 1 && W == 1 && !h->graphs.capturing && h->pollAllowed && !h->cfg.weightedMean;
     a.grid = dim3(h->lastSplit[0] > h->lastSplit[1] ? h->lastSplit[0] : h->lastSplit[1], nWindows, 2);
     a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * 16;
     a.st = stream;
