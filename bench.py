@@ -171,6 +171,8 @@ def main():
                          "all-reduce(SUM) of the zero-initialised full score vectors")
     ap.add_argument("--acq", choices=["coherent", "noncoherent", "textbook"], default=None,
                     help="time the cold-start acquisition search instead (8f row 4; separate JSON line, not the headline)")
+    ap.add_argument("--clock-warmup-s", type=float, default=1.0,
+                    help="seconds of untimed steps after --warmup, before the timed region (GPU clock settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scores", action="store_true", help="skip the per-point score write (arg-max only)")
     ap.add_argument("--include-h2d", action="store_true",
@@ -271,6 +273,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Clock warm-up, untimed: a GPU that idled at its lowest sclk takes on the order of a second of load to settle at its
+    # sustained clock -- the first bench of a fresh box measured 3 % below an immediate second one with only the
+    # --warmup steps in front.  The metric is steady-state throughput, so the settle time stays outside the timed region.
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < args.clock_warmup_s:
+        for _ in range(32):
+            step()
+        fence()
     # Untimed side pass: per-kernel HIP events on every kernel, for `kernels_ms_per_step` (informational).  It runs
     # BEFORE the timed region so that it also serves as clock warm-up (the first ~20 launches of a fresh process run
     # 5-10 % slower; rocprofv3 per-launch trace, profiles/README.md).
