@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- pyt
     > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err
 cp $OUT/${TAG}_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline \
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline \
         > /dev/null 2> $OUT/${TAG}_pmc_$C.err
     cp $OUT/${TAG}_pmc_$C/*/*_counter_collection.csv $OUT/${TAG}_pmc_${C}_counter_collection.csv
 done
