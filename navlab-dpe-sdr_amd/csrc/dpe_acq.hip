@@ -248,6 +248,137 @@ __global__ __launch_bounds__(256) void acq_fine_peak_kernel(const float2 *__rest
     }
 }
 
+// Peak statistics of one PRN's max_percode row (correlator.py:86-103, _trim_mean :546-564) on the device, so that
+// dpe_acq_results copies 48 bytes per PRN instead of the row: the masked row's maximum (cppr), and the mean of the values
+// strictly between the 5 % and 95 % percentiles (cppm).  Percentiles as numpy / scipy define them (linear interpolation
+// between the order statistics floor(pos) and floor(pos)+1, pos = (M-1) q / 100): the order statistics are EXACT -- an
+// 8-bit-digit radix select over the bit patterns (non-negative floats order like unsigned integers) -- and the
+// interpolation repeats the host expression; only the fp64 summation order of the trimmed mean differs from a serial loop.
+struct AcqStats {
+    float peak, maxRest;
+    int ci, di;
+    double sum;
+    long long cnt;
+    double lo, hi;
+};
+
+__device__ __forceinline__ unsigned int block_sum_u32(unsigned int v, unsigned int *sTmp)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sTmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sTmp[0] + sTmp[1] + sTmp[2] + sTmp[3];
+}
+
+__global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict__ mp, const int *__restrict__ codeIdx,
+                                                        const int *__restrict__ doppIdx, int M, int maskS, int iLo, double fLo,
+                                                        int iHi, double fHi, AcqStats *__restrict__ out)
+{
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const float *m = mp + (size_t)p * M;
+    const int ci = codeIdx[p];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int sTmp[4];
+    __shared__ unsigned int sSel[2];
+    __shared__ float sF[4];
+    __shared__ double sD[4];
+    // row value with the +-maskS delays about the peak zeroed (indices wrap at both ends, see dpe_hip.h)
+    auto val = [&](int j) -> float {
+        int d = j - ci;
+        if (d < 0) d += M;
+        const int c = d < M - d ? d : M - d;
+        return c <= maskS ? 0.f : m[j];
+    };
+    // k-th smallest (0-based) of the masked row
+    auto select = [&](unsigned int k) -> float {
+        unsigned int prefix = 0u, mask = 0u;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0u;
+            __syncthreads();
+            for (int j = tid; j < M; j += 256) {
+                const unsigned int u = __float_as_uint(val(j));
+                if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            // exclusive prefix over the 256 digit counts: the digit whose range holds rank k
+            const unsigned int c = hist[tid];
+            unsigned int inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned int o = __shfl_up(inc, off, 64);
+                if ((tid & 63) >= off) inc += o;
+            }
+            if ((tid & 63) == 63) sTmp[tid >> 6] = inc;
+            __syncthreads();
+            unsigned int base = 0u;
+            for (int q = 0; q < (tid >> 6); ++q) base += sTmp[q];
+            const unsigned int excl = base + inc - c;
+            if (c && k >= excl && k < excl + c) { sSel[0] = prefix | ((unsigned int)tid << shift); sSel[1] = k - excl; }
+            __syncthreads();
+            prefix = sSel[0]; k = sSel[1];
+            mask |= 0xFFu << shift;
+            __syncthreads();
+        }
+        return __uint_as_float(prefix);
+    };
+    // the order statistic after x = select(k): x itself if it occurs beyond rank k, else the smallest larger value
+    auto next_after = [&](float x, unsigned int k) -> float {
+        unsigned int le = 0u;
+        float mn = 3.0e38f;
+        for (int j = tid; j < M; j += 256) {
+            const float v = val(j);
+            le += v <= x ? 1u : 0u;
+            mn = (v > x && v < mn) ? v : mn;
+        }
+        const unsigned int nLe = block_sum_u32(le, sTmp);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(mn, off, 64); mn = o < mn ? o : mn; }
+        __syncthreads();
+        if ((tid & 63) == 0) sF[tid >> 6] = mn;
+        __syncthreads();
+        mn = fminf(fminf(sF[0], sF[1]), fminf(sF[2], sF[3]));
+        return nLe > k + 1u ? x : mn;
+    };
+    // masked maximum
+    float mx = 0.f;
+    for (int j = tid; j < M; j += 256) mx = fmaxf(mx, val(j));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((tid & 63) == 0) sF[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sF[0], sF[1]), fmaxf(sF[2], sF[3]));
+    __syncthreads();
+    // percentiles: lo + (hi - lo) * f with a float difference, as the host expression (and scipy) evaluate it
+    double pLo, pHi;
+    {
+        const float a = select((unsigned int)iLo);
+        pLo = (double)a;
+        if (iLo + 1 < M) { const float b = next_after(a, (unsigned int)iLo); pLo = (double)a + (double)(b - a) * fLo; }
+        const float c = select((unsigned int)iHi);
+        pHi = (double)c;
+        if (iHi + 1 < M) { const float d = next_after(c, (unsigned int)iHi); pHi = (double)c + (double)(d - c) * fHi; }
+    }
+    double sum = 0.0;
+    unsigned int cnt = 0u;
+    for (int j = tid; j < M; j += 256) {
+        const float v = val(j);
+        if ((double)v > pLo && (double)v < pHi) { sum += (double)v; ++cnt; }
+    }
+    const unsigned int nCnt = block_sum_u32(cnt, sTmp);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if ((tid & 63) == 0) sD[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        AcqStats r;
+        r.peak = m[ci]; r.maxRest = mx; r.ci = ci; r.di = doppIdx[p];
+        r.sum = ((sD[0] + sD[1]) + sD[2]) + sD[3]; r.cnt = (long long)nCnt; r.lo = pLo; r.hi = pHi;
+        out[p] = r;
+    }
+}
+
 }  // namespace dpe
 
 struct dpe_acq {
@@ -259,6 +390,7 @@ struct dpe_acq {
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
     float *surf_d = nullptr, *mp_d = nullptr;
     int *peakIdx_d = nullptr;   // [2][P]: max_code_idx, max_dopp_idx
+    dpe::AcqStats *stats_d = nullptr, *stats_h = nullptr;   // per-PRN peak statistics; pinned host copy
     bool searched = false;
     // fine-frequency stage, allocated on first use
     int fineC = 0, fineLo = 0, fineHi = -1;
@@ -288,8 +420,9 @@ int dpe_acq_destroy(dpe_acq *h)
     if (h->haveFwd) hipfftDestroy(h->planFwd);
     if (h->haveInv) hipfftDestroy(h->planInv);
     if (h->haveFine) hipfftDestroy(h->planFine);
-    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d};
+    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->stats_d};
     for (void *b : bufs) (void)hipFree(b);
+    if (h->stats_h) (void)hipHostFree(h->stats_h);
     delete h;
     return 0;
 }
@@ -318,7 +451,9 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
     h->peakIdx_d = dev_alloc<int>(2 * P);
-    if (!h->X_d || !h->Rc_d || !h->Y_d || !h->surf_d || !h->mp_d || !h->peakIdx_d) {
+    h->stats_d = dev_alloc<AcqStats>(P);
+    if (hipHostMalloc((void **)&h->stats_h, P * sizeof(AcqStats), hipHostMallocDefault) != hipSuccess) h->stats_h = nullptr;
+    if (!h->X_d || !h->Rc_d || !h->Y_d || !h->surf_d || !h->mp_d || !h->peakIdx_d || !h->stats_d || !h->stats_h) {
         set_error("[Acquisition] create: device allocation failed");
         dpe_acq_destroy(h);
         return -1;
@@ -399,55 +534,39 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     }
     hipLaunchKernelGGL(acq_colmax_kernel, dim3((M + 255) / 256, P), dim3(256), 0, st, h->surf_d, B, M, h->mp_d);
     hipLaunchKernelGGL(acq_peak_kernel, dim3(P), dim3(256), 0, st, h->surf_d, h->mp_d, B, M, h->peakIdx_d, h->peakIdx_d + P);
+    {
+        // percentile positions of _trim_mean(max_percode, 10): pos = (M - 1) q / 100, q = 5 and 95 (numpy.percentile)
+        const double posLo = (double)(M - 1) * 5.0 / 100.0, posHi = (double)(M - 1) * 95.0 / 100.0;
+        const int iLo = (int)std::floor(posLo), iHi = (int)std::floor(posHi);
+        const int maskS = (int)std::ceil(h->cfg.samplingFrequency / kFCA);                      // :96-99
+        hipLaunchKernelGGL(acq_stats_kernel, dim3(P), dim3(256), 0, st, h->mp_d, h->peakIdx_d, h->peakIdx_d + P, M, maskS, iLo,
+                           posLo - (double)iLo, iHi, posHi - (double)iHi, h->stats_d);
+        DPE_CHECK_HIP(hipMemcpyAsync(h->stats_h, h->stats_d, sizeof(AcqStats) * P, hipMemcpyDeviceToHost, st));
+    }
     DPE_CHECK_HIP(hipGetLastError());
     h->searched = true;
     return 0;
-}
-
-// numpy/scipy percentile with linear interpolation, by selection (reorders a; O(n) instead of a sort)
-static double percentile_select(std::vector<float> &a, double q)
-{
-    const double pos = (a.size() - 1) * q / 100.0;
-    const size_t i = (size_t)std::floor(pos);
-    const double f = pos - (double)i;
-    std::nth_element(a.begin(), a.begin() + i, a.end());
-    const float lo = a[i];
-    if (i + 1 >= a.size()) return lo;
-    const float hi = *std::min_element(a.begin() + i + 1, a.end());
-    return lo + (hi - lo) * f;
 }
 
 int dpe_acq_results(dpe_acq *h, dpe_acq_result *out, dpe_stream_t stream)
 {
     using namespace dpe;
     DPE_REQUIRE(h && out && h->searched, "[Acquisition] results: no search yet");
-    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    const int M = h->M, B = h->B, P = h->P;
-    std::vector<float> mp((size_t)P * M);
-    std::vector<int> pk(2 * (size_t)P);
-    DPE_CHECK_HIP(hipMemcpy(mp.data(), h->mp_d, sizeof(float) * mp.size(), hipMemcpyDeviceToHost));
-    DPE_CHECK_HIP(hipMemcpy(pk.data(), h->peakIdx_d, sizeof(int) * pk.size(), hipMemcpyDeviceToHost));
+    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));   // the statistics were copied to stats_h behind the search
+    const int P = h->P;
     const double fs = h->cfg.samplingFrequency;
     for (int p = 0; p < P; ++p) {
-        float *m = mp.data() + (size_t)p * M;
-        const int ci = pk[p], di = pk[P + p];                                      // first maxima, correlator.py:88-89
+        const AcqStats &st = h->stats_h[p];
+        const int ci = st.ci, di = st.di;                                          // first maxima, correlator.py:88-89
         dpe_acq_result &r = out[p];
         r.prn = h->cfg.prn[p];
         r.maxCodeIdx = ci; r.maxDoppIdx = di;
         r.rc = (double)kLCA - ((double)ci / fs) * kFCA;                            // :90
         r.fi = h->cfg.binStartHz + h->cfg.binStepHz * di;                          // :91
         r.fc = kFCA + (h->cfg.dopplerSign * kFCA / kFL1) * r.fi;                   // :92
-        r.peak = m[ci];
-        const int maskS = (int)std::ceil(fs / kFCA);                               // :96-99 (indices wrap)
-        std::vector<float> a(m, m + M);
-        for (int d = -maskS; d <= maskS; ++d) a[((ci + d) % M + M) % M] = 0.f;
-        r.cppr = r.peak / *std::max_element(a.begin(), a.end());                   // :100
-        const double lo = percentile_select(a, 5.0), hi = percentile_select(a, 95.0);   // _trim_mean :546-564
-        double sum = 0;
-        long long cnt = 0;
-        for (float v : a)
-            if (v > lo && v < hi) { sum += v; ++cnt; }
-        r.cppm = cnt ? r.peak / (sum / cnt) : 0.0;
+        r.peak = st.peak;
+        r.cppr = r.peak / (double)st.maxRest;                                           // :96-100 (mask: acq_stats_kernel)
+        r.cppm = st.cnt ? r.peak / (st.sum / (double)st.cnt) : 0.0;               // _trim_mean :546-564
         r.found = r.cppm > 2.0 ? 1 : 0;                                            // :103
     }
     return 0;
