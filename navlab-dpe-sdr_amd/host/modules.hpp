@@ -208,6 +208,9 @@ class SampleBlock : public Module {
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mtx);
+                // RunLive: no free buffer at once means samples of a live source are being lost (sampleblock.cu:421-425:
+                // the reference logs it and carries on)
+                if (RunLive && !stop && ring[load].ready) std::clog << "[SampleBlock] Fail real-time." << std::endl;
                 cvFree.wait(lk, [&] { return stop || !ring[load].ready; });
                 if (stop) return;
             }
