@@ -148,12 +148,18 @@ class SampleBlock : public Module {
         InsertParam("SamplingFrequency", &SamplingFrequency, DOUBLE_t, sizeof(double), sizeof(double));
         InsertParam("SampleLength", &SampleLength, DOUBLE_t, sizeof(double), sizeof(double));
         InsertParam("RunLive", &RunLive, BOOL_t, sizeof(bool), sizeof(bool));
+        // network source of the reference (sampleblock.cu:51-52,57): the keys are accepted so that a parameter script
+        // written for it loads; a non-file source is refused at Start (networking is outside this build's scope)
+        InsertParam("Hostname", Hostname, CHAR_t, sizeof(Hostname), 0);
+        InsertParam("PortNo", &PortNo, INT_t, sizeof(int), sizeof(int));
+        InsertParam("InputSourceType", &InputSourceType, CHAR_t, sizeof(char), sizeof(char));
     }
     ~SampleBlock() override { Stop(); }
     int Start(void *) override
     {
         if (running) return 0;
         if (SamplingFrequency <= 0 || SampleLength <= 0) DPE_MOD_FAIL("SamplingFrequency / SampleLength not set");
+        if (InputSourceType != 0) DPE_MOD_FAIL("InputSourceType " << (int)InputSourceType << ": only the file source (0) is built");
         fd = ::open(Filename, O_RDONLY);
         if (fd < 0) DPE_MOD_FAIL("Unable to open file: " << Filename);
         const long long start = inputs[0] ? *(long long *)inputs[0]->Data : 0;
@@ -238,6 +244,9 @@ class SampleBlock : public Module {
     char Filename[512] = "";
     double SamplingFrequency = 0, SampleLength = 0;
     bool RunLive = false, running = false, stop = false, eof = false;
+    char Hostname[64] = "";
+    int PortNo = 0;
+    char InputSourceType = 0;   // 0 = file
     int fd = -1, load = 0, proc = -1;
     uint32_t BlockLength = 0;
     size_t bytes = 0;

@@ -103,6 +103,10 @@ int main()
         SampleBlock sb;
         EXPECT(sb.SetParam("Filename", "/nonexistent/samples.dat") == 0 && sb.SetParam("SamplingFrequency", 2.5e6) == 0);
         EXPECT(sb.Update(nullptr) == -1);                             // not started
+        // the reference's network-source keys are accepted (sampleblock.cu:51-52,57); a non-file source is refused at Start
+        EXPECT(sb.SetParam("Hostname", "192.168.10.7") == 0 && sb.SetParam("PortNo", 49152) == 0);
+        EXPECT(sb.SetParam("SampleLength", 0.02) == 0 && sb.SetParam("InputSourceType", (char)1) == 0);
+        EXPECT(sb.Start(nullptr) == -1);
     }
     std::printf(failures ? "%d failure(s)\n" : "ok\n", failures);
     return failures ? 1 : 0;
