@@ -194,8 +194,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # DPE_BENCH_BACKEND=gloo DPE_BENCH_SHARE_GPU=1: functional check of the N > 1 code path on a one-GPU box (all
+        # ranks on cuda:0, exchange through gloo) -- RCCL refuses two ranks on one device.  Never a performance number.
+        backend = os.environ.get("DPE_BENCH_BACKEND", "nccl")
+        if os.environ.get("DPE_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if use_dist else 0)
