@@ -674,3 +674,50 @@ def test_reference_maximum_grid_size():
         want = ref["pos_x" if name == "pos" else "vel"][0]
         assert np.abs(sc[idx] - want).max() < TOL * want.max(), name
         assert sc[best] >= want.max() * (1 - TOL)
+
+
+def test_bench_configuration_256_windows_against_the_oracle(oracle):
+    """The exact configuration bench.py times (config R: S = 50000, 8 SVs, two 390625-point rngrid3-format grids, 256 windows
+    per call, banks L = 4 / B = 20 -- i.e. the 16-samples-per-lane bank kernel, the fat finalize shape and the batch scan):
+    banks and every 97th score of three windows against the oracle, and for ALL 256 windows the reported arg-max against the
+    first maximum of the scores the scan wrote."""
+    import torch
+    o = oracle
+    cfg = dpe.workload.CONFIG_R
+    fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
+    W = 256
+    iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=0, amp=cfg["amp"])
+    _, _, pos, vel, _ = dpe.workload.build_grids(G)
+    bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K)
+    bcs.Start()
+    bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B, max_windows=W,
+                                max_channels=K, write_scores=True)
+    bcm.Start()
+    bcs.Update(torch.from_numpy(iq).to("cuda:0"), cs)
+    bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+    res = bcm.results()
+    code, carr = bcs.read_banks()
+    ps, vs = bcm.read_scores()
+    bcm.Stop(); bcs.Stop()
+    C = dpe.engine.carr_fft_len(S)
+    for w in range(W):
+        assert res[w]["posOutOfWindow"] == 0 and res[w]["velOutOfWindow"] == 0
+        assert res[w]["posIndex"] == int(np.argmax(ps[w])) and res[w]["velIndex"] == int(np.argmax(vs[w]))
+        assert res[w]["posScore"] == ps[w].max() and res[w]["velScore"] == vs[w].max()
+    idx = np.arange(0, G, 97)
+    for w in (0, 100, 255):
+        rc, rf = [], []
+        for k in range(K):
+            c = cs[w, k]
+            a, b, _ = o.bcs_sv(iq[w], fs, int(c["prn"]), c["codePhaseStart"], c["carrierPhaseStart"], c["codeFrequency"],
+                               c["carrierFrequency"], int(c["cpElapsedStart"]), int(c["cpReference"]), -L, L, -B, B, C)
+            rc.append(a); rf.append(b)
+        rc, rf = np.stack(rc), np.stack(rf)
+        assert np.abs(code[w] - rc).max() < TOL * np.abs(rc).max() and np.abs(carr[w] - rf).max() < TOL * np.abs(rf).max()
+        e = ce[w]
+        sp, _ = o.bcm_pos(e["satState"], rc, S // 2 - L, bw[w]["xCurrkk1"], pos[idx], bw[w]["enu2ecef"], e["codeFrequency"],
+                          e["cpRefTOW"], e["cpElapsedEnd"], e["cpRef"], e["codePhaseEnd"], float(bw[w]["rxTime"]), fs, S, 1,
+                          extended=True)
+        sv, _ = o.bcm_vel(e["satState"], rf, C // 2 - B, bw[w]["xCurrkk1"], vel[idx], bw[w]["enu2ecef"],
+                          e["carrierFrequency"], float(bw[w]["rxTime"]), fs, C, 1, 1)
+        assert np.abs(ps[w][idx] - sp).max() < TOL * sp.max() and np.abs(vs[w][idx] - sv).max() < TOL * sv.max()
