@@ -676,16 +676,17 @@ def test_reference_maximum_grid_size():
         assert sc[best] >= want.max() * (1 - TOL)
 
 
-def test_bench_configuration_256_windows_against_the_oracle(oracle):
-    """The exact configuration bench.py times (config R: S = 50000, 8 SVs, two 390625-point rngrid3-format grids, 256 windows
-    per call, banks L = 4 / B = 20 -- i.e. the 16-samples-per-lane bank kernel, the fat finalize shape and the batch scan):
-    banks and every 97th score of three windows against the oracle, and for ALL 256 windows the reported arg-max against the
-    first maximum of the scores the scan wrote."""
+@pytest.mark.parametrize("name,W,probe", [("R", 256, (0, 100, 255)), ("H", 32, (0, 31))])
+def test_bench_configurations_against_the_oracle(oracle, name, W, probe):
+    """The exact configurations bench.py times.  R: S = 50000, 8 SVs, two 390625-point rngrid3-format grids, 256 windows per
+    call, banks L = 4 / B = 20 (the 16-samples-per-lane bank kernel, the fat finalize shape, the batch scan).  H (--config H):
+    25 Msps, S = 500000, 12 SVs, 1e5-point grids, 32 windows, L = 31 (boundary-difference bank kernel).  Banks and every 97th
+    score of a few windows against the oracle, and for ALL windows the reported arg-max against the first maximum of the
+    scores the scan wrote."""
     import torch
     o = oracle
-    cfg = dpe.workload.CONFIG_R
+    cfg = dpe.workload.CONFIG_R if name == "R" else dpe.workload.CONFIG_H
     fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
-    W = 256
     iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=0, amp=cfg["amp"])
     _, _, pos, vel, _ = dpe.workload.build_grids(G)
     bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K)
@@ -705,7 +706,7 @@ def test_bench_configuration_256_windows_against_the_oracle(oracle):
         assert res[w]["posIndex"] == int(np.argmax(ps[w])) and res[w]["velIndex"] == int(np.argmax(vs[w]))
         assert res[w]["posScore"] == ps[w].max() and res[w]["velScore"] == vs[w].max()
     idx = np.arange(0, G, 97)
-    for w in (0, 100, 255):
+    for w in probe:
         rc, rf = [], []
         for k in range(K):
             c = cs[w, k]
