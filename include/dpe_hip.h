@@ -24,6 +24,10 @@
 extern "C" {
 #endif
 
+/* Diagnostic environment switches, read when a handle is created (all default off; results stay within the stated
+ * tolerances, kernel selection changes):  DPE_BCS_NO_BANK16=1 (batches use the single-window bank kernel),
+ * DPE_BCS_NO_WIDE=1 (no boundary-difference kernel for +-32-lag windows), DPE_BCS_NO_FUSE=1 (single windows run the
+ * separate DC-sum kernel), DPE_BCM_NO_POLL=1 (dpe_bcm_results always waits for the stream). */
 #define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
 #define DPE_ABI_VERSION 1
 
