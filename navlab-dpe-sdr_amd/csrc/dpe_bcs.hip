@@ -60,6 +60,7 @@ struct BcsChanDev {
     int32_t prn;
     int32_t pad;
     double fc, fi;    // raw code / carrier frequency (time-table mode)
+    double invStep;   // samples per chip = fs / fc (chip-boundary kernel)
 };
 
 // Time of sample n: n/fs, or (TABLE) the reference's ns-rounded table (BCS_GenTimeIdcs,
@@ -737,11 +738,19 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
     }
 }
 
+}  // namespace dpe
+
+#include "dpe_bcs_chip.h"   // chip-boundary form of stage 1 (high sampling rates)
+
+namespace dpe {
+
 // ------------------------------------------------------------------------------------------
 // blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
+// momLen = samples per moment block (kSub for the per-sample kernels, kPass for the chip kernel); nValid = entries of a
+// block partial that hold lags (65, or 64 for the chip kernel whose lanes cover lagShift - 32 .. lagShift + 31).
 template <int kNMom, bool FUSE>
 __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide, int lagShift,
-                                                           long long C, const BcsChanDev *__restrict__ chan,
+                                                           int momLen, int nValid, long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
                                                            const float2 *__restrict__ mom,
                                                            float2 *__restrict__ codeBank, float2 *__restrict__ carrBank,
@@ -845,7 +854,7 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
         if (tid == 0 && lagShift == 0) info[w * K + k] = noFlip;
         for (int jj = tid; jj < NL; jj += 256) {
             const int lag = lagShift + jj - LH;        // this chunk holds the lags lagShift - LH .. lagShift + LH
-            if (lag < -L || lag > L) continue;
+            if (lag < -L || lag > L || jj >= nValid) continue;
             const float2 X = sXY[jj], Y = sXY[NL + jj];
             codeBank[((size_t)w * maxK + k) * (2 * L + 1) + lag + L] = make_float2(X.x + sgn * Y.x, X.y + sgn * Y.y);
         }
@@ -869,11 +878,11 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
         live[g] = g < gCount && bi < 2 * B + 1;
         F[g] = make_float2(0.f, 0.f);
         theta[g] = (float)(6.283185307179586476925286766559 * (double)bb[g] / (double)C);
-        // centre twiddle exp(-j 2 pi n_c b / C), n_c = 256 sub + 127.5: exact (integer-reduced phase +
-        // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 4096 b / C) between
+        // centre twiddle exp(-j 2 pi n_c b / C), n_c = momLen sub + (momLen - 1) / 2: exact (integer-reduced phase +
+        // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 16 momLen b / C) between
         stepS[g] = 0.f; stepC[g] = 1.f; sn[g] = 0.f; cs[g] = 1.f;
         if (live[g]) {
-            long long ts = ((long long)8192 * (long long)bb[g]) % (2 * C);   // 2 * (16 * 256) b  (phase unit: pi / C)
+            long long ts = ((long long)(32 * momLen) * (long long)bb[g]) % (2 * C);   // 2 * (16 * momLen) b  (phase unit: pi / C)
             if (ts < 0) ts += 2 * C;
             sincospif((float)ts * invC, &stepS[g], &stepC[g]);
         }
@@ -912,7 +921,7 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
                     ar = nr;
                 }
                 if ((it & 7) == 0) {
-                    long long tt = ((long long)(512 * sub + 255) * (long long)bb[g]) % (2 * C);
+                    long long tt = (((long long)(2 * momLen) * sub + (momLen - 1)) * (long long)bb[g]) % (2 * C);
                     if (tt < 0) tt += 2 * C;
                     sincospif((float)tt * invC, &sn[g], &cs[g]);  // angle = pi * tt / C
                 } else {
@@ -962,6 +971,13 @@ struct dpe_bcs {
     bool wideAllowed = true;     // DPE_BCS_NO_WIDE=1 in the environment at create: dense kernel only (A/B tests)
     bool bank16Allowed = true;   // DPE_BCS_NO_BANK16=1: never the 16-samples-per-lane batch kernel (A/B tests)
     bool fuseAllowed = true;     // DPE_BCS_NO_FUSE=1: always the separate DC-sum kernel (A/B tests)
+    bool chipAllowed = true;     // DPE_BCS_NO_CHIP=1: never the chip-boundary kernel (A/B tests)
+    bool chipOK = false;         // create-time eligibility of the chip-boundary kernel (dpe_bcs_chip.h)
+    int nPassChip = 0, nBlkAlloc = 0;
+    int chipDbg = 0;                   // DPE_BCS_CHIP_DBG: skips parts of the chip kernel (timing experiments; wrong results)
+    int chipTpbForce = 0;              // DPE_BCS_CHIP_TPB at create: passes per wave of the chip kernel (experiments)
+    int chipResident = 0;              // co-resident waves of the chip kernel on the whole device
+    int chipTpbMax = 1;                // longest tile (passes) whose 6-moment block still meets the Taylor bound
     long long C;
     int8_t *chipTable_d = nullptr;
     double *tTable_d = nullptr;   // ns-rounded sample times (always allocated; used only when useTable)
@@ -1057,7 +1073,35 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     }
     h->sums_d = dev_alloc<long long>(2 * W * kSumSlots);
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
-    h->part_d = dev_alloc<float2>(W * K * h->nBlk * 2 * (2 * h->LH + 1));
+    // chip-boundary kernel (dpe_bcs_chip.h): lag windows of 17..31 samples (wider: chunks of 64 lags) at sampling rates where a
+    // sub-tile holds few chips, plain n/fs sample times; its moment block is one pass of kPass samples, and a chip's
+    // second-order term (theta len)^2 / 24 must stay below fp32 rounding
+    h->nPassChip = (S + kPass - 1) / kPass;
+    {
+        const double thetaB = 6.283185307179586 * cfg->binHalfWidth / (double)C;   // phase step per sample of the outermost bin
+        const double chipLen = fs / kFCA * 1.001;
+        // the moment block is the wave's tile of tpb passes, 6 moments: (thetaB tpb kPass / 2)^6 / 720 < 2e-7
+        const double halfMax = std::pow(2e-7 * 720.0, 1.0 / 6.0) / thetaB;
+        h->chipTpbMax = (int)(2.0 * halfMax / kPass);
+        if (h->chipTpbMax > 16) h->chipTpbMax = 16;
+        h->chipOK = h->LH == 32 && !needTable && (kFCA / fs) * 128.0 < 40.0 && h->chipTpbMax >= 1 && chipLen < 31.0 &&
+                    (thetaB * chipLen) * (thetaB * chipLen) / 24.0 < 5e-7 && S >= 2 * kPass;
+    }
+    h->nBlkAlloc = h->nBlk;
+    if (h->chipOK) {
+        // partial sums of up to 128 blocks per (window, SV); a handle for a few windows gets one block per pass
+        int want = (int)(2048 / W) > 128 ? (int)(2048 / W) : 128;
+        if (want > h->nPassChip) want = h->nPassChip;
+        if (want < (h->nPassChip + h->chipTpbMax - 1) / h->chipTpbMax) want = (h->nPassChip + h->chipTpbMax - 1) / h->chipTpbMax;
+        if (h->nBlkAlloc < want) h->nBlkAlloc = want;
+        int dev = 0, cus = 256, nb = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        h->chipResident = 12 * cus;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bcs_bank_chip_kernel<6>, 64, 0) == hipSuccess && nb > 0)
+            h->chipResident = nb * cus;
+    }
+    h->part_d = dev_alloc<float2>(W * K * h->nBlkAlloc * 2 * (2 * h->LH + 1));
     h->mom_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMomMax);
     h->momRep_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMomMax);
     h->codeBank_d = dev_alloc<float2>(W * K * (2 * cfg->lagHalfWidth + 1));
@@ -1085,6 +1129,9 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->wideAllowed = getenv("DPE_BCS_NO_WIDE") == nullptr;
     h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
     h->fuseAllowed = getenv("DPE_BCS_NO_FUSE") == nullptr;
+    h->chipAllowed = getenv("DPE_BCS_NO_CHIP") == nullptr;
+    if (const char *e = getenv("DPE_BCS_CHIP_TPB")) h->chipTpbForce = atoi(e);
+    if (const char *e = getenv("DPE_BCS_CHIP_DBG")) h->chipDbg = atoi(e);
     *out = h;
     return 0;
 }
@@ -1128,6 +1175,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         d.carrStep = c.carrierFrequency / fs;
         d.fc = c.codeFrequency;
         d.fi = c.carrierFrequency;
+        d.invStep = fs / c.codeFrequency;
         const double ang = -6.283185307179586476925286766559 * d.carrStep;
         d.rotRe = (float)std::cos(ang);
         d.rotIm = (float)std::sin(ang);
@@ -1139,6 +1187,10 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         d.pad = 0;
         h->idxNext_h[i] = d.idxNext;
     }
+    // chip-boundary kernel: the closed-form DC term of a chip needs 2 pi |fi| / fc <= 0.25 (|fi| below ~40 kHz)
+    bool chip = h->chipOK && h->chipAllowed;
+    for (int i = 0; chip && i < nWindows * nChan; ++i)
+        if (6.283185307179586 * std::fabs(chan_host[i].carrierFrequency) > 0.25 * chan_host[i].codeFrequency) chip = false;
     h->lastW = nWindows;
     h->lastK = nChan;
     // the per-kernel event timing and the graph replay exclude each other
@@ -1167,7 +1219,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
     // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else a dense kernel
-    const bool wide = h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
+    const bool wide = !chip && h->LH == 32 && h->wideAllowed && (kFCA / fs) * 128.0 < 40.0;
     // narrow lag windows in batches: the 16-samples-per-lane kernel (tiles of 16 sub-tiles) once the batch
     // offers >= 2048 of its tiles; fewer (a single window in particular) keep the short 4-sub-tile tiles
     const int nTiles16 = (h->nSub + 15) / 16;
@@ -1185,11 +1237,28 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         if (tpb < h->tilesPerBlock) tpb = h->tilesPerBlock;
         if (tpb > 16) tpb = 16;
     }
-    const int nBlk = (nTiles + tpb - 1) / tpb;
+    // chip-boundary kernel: one wave per block walks tpb passes of one (window, SV)
+    int chipNMom = 6;
+    if (chip) {
+        // passes per wave: the choice that leaves the smallest tail -- ceil(waves / resident waves) rounds of tpb passes each
+        const int least = (h->nPassChip + h->nBlkAlloc - 1) / h->nBlkAlloc;
+        long long best = -1;
+        tpb = least;
+        for (int c = least; c <= h->chipTpbMax; ++c) {
+            const long long waves = (long long)((h->nPassChip + c - 1) / c) * nChan * nWindows;
+            // + the finalize kernel's share: its time grows by ~0.06 pass-rounds per partial block (measured, config H)
+            const long long cost = 100 * ((waves + h->chipResident - 1) / h->chipResident) * c + 6 * ((h->nPassChip + c - 1) / c);
+            if (best < 0 || cost < best) { best = cost; tpb = c; }
+        }
+        if (h->chipTpbForce >= least && h->chipTpbForce <= h->chipTpbMax) tpb = h->chipTpbForce;
+        const double thc = 6.283185307179586 * h->cfg.binHalfWidth / (double)h->C * 0.5 * ((double)tpb * kPass - 1.0);
+        chipNMom = (std::pow(thc, 4) / 24.0 < 1e-7) ? 4 : 6;
+    }
+    const int nBlk = chip ? (h->nPassChip + tpb - 1) / tpb : (nTiles + tpb - 1) / tpb;
     const dim3 grid(nBlk, nChan, nWindows), block(256);
     // single windows (<= 37 (window, channel) pairs) with a dense stage-1 kernel: no separate DC-sum launch, the
     // sums ride along in the bank kernel (FUSE) and the finalize kernel applies the mean
-    const bool fuse = nWindows * nChan <= DPE_MAX_CHAN && !use16 && !wide && h->LH <= 16 && h->cfg.lagHalfWidth <= 32 && h->fuseAllowed;
+    const bool fuse = nWindows * nChan <= DPE_MAX_CHAN && !use16 && !wide && !chip && h->LH <= 16 && h->cfg.lagHalfWidth <= 32 && h->fuseAllowed;
     const int sumSlotsUsed = fuse ? nBlk : sumBlocks;
     h->lastSumBlocks = sumSlotsUsed;
     if (!fuse) {
@@ -1215,16 +1284,27 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     // Lag windows wider than +-32: further chunks of 65 lags, centred 65 samples apart -- the same kernels run
     // against the replica delayed by lagShift samples (centre chunk first: it makes the replica choice and the
     // Doppler bank).  One chunk when L <= 32.
-    const int nSideChunks = h->cfg.lagHalfWidth > 32 ? (h->cfg.lagHalfWidth - 32 + 64) / 65 : 0;
+    // (the chip kernel's lanes cover lagShift - 32 .. lagShift + 31: chunks of 64 lags, 64 apart)
+    const int chunkLags = chip ? 64 : 65;
+    const int nSideChunks = chip ? (h->cfg.lagHalfWidth > 31 ? (h->cfg.lagHalfWidth - 31 + 63) / 64 : 0)
+                                 : (h->cfg.lagHalfWidth > 32 ? (h->cfg.lagHalfWidth - 32 + 64) / 65 : 0);
+    const int nMomUse = chip ? chipNMom : h->nMom;
     for (int chunk = 0; chunk <= 2 * nSideChunks; ++chunk) {
-    const int lagShift = chunk == 0 ? 0 : ((chunk + 1) / 2) * 65 * ((chunk & 1) ? 1 : -1);
+    const int lagShift = chunk == 0 ? 0 : ((chunk + 1) / 2) * chunkLags * ((chunk & 1) ? 1 : -1);
     h->prof.begin(1, stream);
 #define DPE_LAUNCH_BANK(LHV)            \
     do {                                \
         if (h->nMom == 4) DPE_LAUNCH_BANK2(LHV, 4); \
         else DPE_LAUNCH_BANK2(LHV, 6);  \
     } while (0)
-    if (use16) {
+    if (chip) {
+        const dim3 cgrid(nBlk, nChan, nWindows);
+#define DPE_LAUNCH_CHIP(NM)                                                                                                    \
+    hipLaunchKernelGGL((bcs_bank_chip_kernel<NM>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
+                       nChan, h->nPassChip, tpb, nBlk, sumBlocks, lagShift, h->chipDbg, h->chan_d, h->sums_d, h->chipTable_d, h->part_d, h->mom_d)
+        if (chipNMom == 4) DPE_LAUNCH_CHIP(4); else DPE_LAUNCH_CHIP(6);
+#undef DPE_LAUNCH_CHIP
+    } else if (use16) {
 #define DPE_LAUNCH_B16(LHV, NM, TB)                                                                                    \
     hipLaunchKernelGGL((bcs_bank16_kernel<LHV, NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
@@ -1262,11 +1342,11 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const bool fatFinalize = nBinBlk <= 4 && (long long)nChan * nWindows >= 512;
     const dim3 fgrid((fatFinalize || lagShift != 0) ? 1 : 1 + nBinBlk, nChan, nWindows);
 #define DPE_LAUNCH_FIN(NM, FS)                                                                                          \
-    hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, h->nSub, nBlk, h->LH,       \
-                       h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, h->C, h->chan_d, h->part_d, h->mom_d,  \
+    hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, chip ? nBlk : h->nSub, nBlk, h->LH, \
+                       h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, chip ? tpb * kPass : kSub, chip ? 64 : 65, h->C, h->chan_d, h->part_d, h->mom_d,  \
                        h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels, h->momRep_d, h->sums_d, sumSlotsUsed)
     const bool fuseFin = fuse && lagShift == 0;
-    if (h->nMom == 4) { if (fuseFin) DPE_LAUNCH_FIN(4, true); else DPE_LAUNCH_FIN(4, false); }
+    if (nMomUse == 4) { if (fuseFin) DPE_LAUNCH_FIN(4, true); else DPE_LAUNCH_FIN(4, false); }
     else { if (fuseFin) DPE_LAUNCH_FIN(6, true); else DPE_LAUNCH_FIN(6, false); }
 #undef DPE_LAUNCH_FIN
     h->prof.end(2, stream);

@@ -21,6 +21,9 @@ for k, v in acc.items():
     for name, ms in times.items():
         if k.startswith(name) and "SQ_INSTS_VALU" in e:
             e["valu_issue_utilisation"] = e["SQ_INSTS_VALU"] / 1024 * 4 / (ms * 1e-3 * 2.4e9)
+            e["kernel_ms"] = ms
+            if "SQ_LDS_IDX_ACTIVE" in e:   # LDS-array cycles over the 256 CUs x kernel cycles
+                e["lds_array_utilisation"] = e["SQ_LDS_IDX_ACTIVE"] / 256 / (ms * 1e-3 * 2.4e9)
     out["kernels"][k] = e
 json.dump(out, open(f"{d}/{tag}_sq_counters.json", "w"), indent=1)
 for k, e in out["kernels"].items():

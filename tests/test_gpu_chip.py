@@ -1,0 +1,126 @@
+"""Chip-boundary stage-1 kernel (csrc/dpe_bcs_chip.h; high sampling rates, lag windows wider than +-16 samples) against
+the fp64 oracle's banks (batchcorrscores.cu:1043-1180 semantics) and against the per-sample kernels it replaces.
+Tolerance: 2e-6 of the bank's peak magnitude, nav-bit decisions and DC mean exact."""
+import os
+
+import numpy as np
+import pytest
+
+import navlab_dpe_sdr_amd as dpe
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+def _banks(case, L, B, env=None):
+    import torch
+    iq, cs, _, _ = helpers.pack_gpu_inputs(case)
+    W, K = cs.shape
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=L, bin_half_width=B,
+                                  max_windows=W, max_channels=K)
+        bcs.Start()                      # the switches are read at create
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    d = torch.from_numpy(iq).to("cuda:0")
+    bcs.Update(d, cs)
+    code, carr = bcs.read_banks()
+    info = bcs.read_info()
+    bcs.profile(True)
+    bcs.Update(d, cs)
+    prof = bcs.profile(False)
+    bcs.Stop()
+    return code, carr, info, prof
+
+
+def _check(case, L, B, tol=TOL):
+    from oracle import oracle as o
+    code, carr, info, _ = _banks(case, L, B)
+    code0, carr0, info0, _ = _banks(case, L, B, {"DPE_BCS_NO_CHIP": "1"})
+    worst = 0.0
+    for wi, w in enumerate(case["wins"]):
+        s = w["start"]
+        for k in range(case["K"]):
+            c, f, inf = o.bcs_sv(w["iq"], case["fs"], int(s["prn"][k]), s["rc"][k], s["ri"][k], s["fc"][k], s["fi"][k],
+                                 int(s["cp"][k]), int(s["cp_ref"][k]), -L, L, -B, B, case["C"])
+            for got, ref in ((code[wi][k], c), (carr[wi][k], f), (code0[wi][k], c), (carr0[wi][k], f)):
+                err = np.abs(got - ref).max() / np.abs(ref).max()
+                worst = max(worst, err)
+                assert err < tol, "window %d SV %d: rel err %.3g" % (wi, k, err)
+            assert info[0][wi, k] == inf["idx_next"] and bool(info[1][wi, k]) == inf["no_flip_larger"]
+            assert bool(info0[1][wi, k]) == inf["no_flip_larger"]
+        assert info[2][wi] == info0[2][wi] == inf["mean"]          # DC mean: exact integer sums in both paths
+    return worst
+
+
+@pytest.mark.parametrize("kw,L,B", [
+    (dict(seed=11, fs=25e6, S=125000, K=4, G=64, amp=60.0), 31, 16),            # 5 ms at 25 Msps: 115 passes of 1088 samples
+    (dict(seed=12, fs=25e6, S=100002, K=5, G=64, amp=30.0, W=2), 24, 12),       # ragged window, two windows, 45 dB-Hz
+    (dict(seed=13, fs=10e6, S=200000, K=3, G=64, amp=100.0), 20, 30),           # 9.8 samples per chip: two chip rounds per pass
+    (dict(seed=14, fs=5e6, S=100000, K=9, G=64, amp=100.0), 17, 40),            # 4.9 samples per chip: four rounds
+    (dict(seed=17, fs=20e6, S=400000, K=2, G=64, amp=50.0), 31, 20),            # full 20 ms window at 20 Msps
+])
+def test_chip_kernel_vs_oracle_and_per_sample_kernels(kw, L, B):
+    worst = _check(helpers.make_case(**kw), L, B)
+    print("worst rel err", worst)
+
+
+def test_chip_kernel_really_runs_and_is_selected_for_config_h():
+    """The H configuration must go through the chip kernel (DPE_BCS_NO_CHIP switches it off), and faster than the
+    boundary-difference kernel it replaces."""
+    cfg = dpe.workload.CONFIG_H
+    case = helpers.make_case(seed=21, fs=cfg["fs"], S=cfg["S"], K=cfg["K"], G=64, amp=cfg["amp"], W=4)
+    _, _, _, p1 = _banks(case, cfg["L"], cfg["B"])
+    _, _, _, p0 = _banks(case, cfg["L"], cfg["B"], {"DPE_BCS_NO_CHIP": "1"})
+    print("bank ms: chip %.4f, per-sample %.4f" % (p1["bcs_bank"][0], p0["bcs_bank"][0]))
+    assert p1["bcs_bank"][0] < 0.8 * p0["bcs_bank"][0]
+    worst = _check(case, cfg["L"], cfg["B"])
+    print("config H (4 windows) worst rel err", worst)
+
+
+def test_chip_kernel_lag_windows_wider_than_31_samples():
+    """L = 100 at 25 Msps: chunks of 64 lags, 64 apart, each produced against the replica shifted by the chunk offset."""
+    worst = _check(helpers.make_case(seed=15, fs=25e6, S=125000, K=4, G=64, amp=200.0), 100, 16)
+    print("worst rel err", worst)
+
+
+def test_chip_kernel_large_dc_offset():
+    """(+900, -700) LSB of DC on a 40 LSB signal: the prefix sums then grow with the DC (|Q| ~ DC x 1088 per pass), which
+    costs fp32 digits in the chip differences -- still inside the tolerance (1.4e-6 measured)."""
+    c = helpers.make_case(seed=16, fs=25e6, S=250000, K=6, G=64, amp=40.0)
+    for w in c["wins"]:
+        iq = w["iq"].astype(np.int32)
+        iq[0::2] += 900
+        iq[1::2] -= 700
+        w["iq"] = np.clip(iq, -32768, 32767).astype(np.int16)
+    worst = _check(c, 31, 16)
+    print("worst rel err", worst)
+
+
+def test_chip_kernel_every_pass_per_block_count_gives_the_same_banks():
+    """The moment block is the wave's tile of tpb passes (finalize is told its length): tpb = 1, 3 and the default must
+    agree to fp32 rounding, nav-bit boundary inside a tile included."""
+    case = helpers.make_case(seed=18, fs=25e6, S=250000, K=3, G=64, amp=80.0, flips=[True, False, True])
+    ref_code, ref_carr, _, _ = _banks(case, 31, 16)
+    for tpb in ("1", "3", "7"):
+        code, carr, _, _ = _banks(case, 31, 16, {"DPE_BCS_CHIP_TPB": tpb})
+        for k in range(3):
+            assert np.abs(code[0][k] - ref_code[0][k]).max() < TOL * np.abs(ref_code[0][k]).max()
+            assert np.abs(carr[0][k] - ref_carr[0][k]).max() < TOL * np.abs(ref_carr[0][k]).max()
+
+
+def test_chip_kernel_falls_back_when_not_eligible():
+    """Carrier frequencies beyond the closed-form DC term's range (2 pi |fi| / fc > 0.25) take the per-sample kernels."""
+    case = helpers.make_case(seed=19, fs=25e6, S=125000, K=2, G=64, amp=100.0)
+    for w in case["wins"]:
+        w["start"]["fi"] = w["start"]["fi"] + 60e3      # 60 kHz intermediate frequency
+        ch = dict(w["start"])
+        w["iq"] = dpe.synth.gen_iq(5, case["fs"], case["S"], ch, amp=100.0, flip=np.zeros(2, dtype=bool))
+    _check(case, 31, 16)
