@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the sampleblock -> BCS -> BCM hot path on MI355X.
+"""bench.py -- benchmark of the sampleblock -> BCS -> BCM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 without a torch.distributed environment: this process starts
+        `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and relays its output.
 
-Workload (config.workload): BASELINE.json configs[1] -- the reference demo's shape on one GPU:
-2.5 Msps x 20 ms windows (S=50000), 8 SVs, rngrid3-format random ENU-dt grid of 25^4 = 390625 points
-plus the velocity-drift grid of the same size, synthetic I/Q (the demo recording is not shipped).
-One "step" = one pass of the hot path over a batch of `--windows` windows resident in HBM:
-BatchCorrScores (DC sum, lag/Doppler banks, finalize) + BatchCorrManifold (pos scan, vel scan,
-fused arg-max) for every window, each with its own channel state.
-
+Headline workload (config.workload, the LAST JSON line): BASELINE.json configs[1] -- the reference demo's shape on one GPU:
+2.5 Msps x 20 ms windows (S = 50000), 8 SVs, rngrid3-format random ENU-dt grid of 25^4 = 390625 points plus the
+velocity-drift grid of the same size, synthetic I/Q (the demo recording is not shipped).  One "step" = one pass of the hot
+path over a batch of `--windows` windows resident in HBM: BatchCorrScores (DC sum, lag/Doppler banks, finalize) +
+BatchCorrManifold (pos scan, vel scan, fused arg-max) for every window, each with its own channel state.
 metric = manifold gridpoints x SVs correlated per second (both manifolds), whole job.
-N>1: the grid dimension is sharded (each rank scores its own contiguous slice of an N-times larger
-global grid -> weak scaling), stage 1 is recomputed per rank, and the per-window arg-max is
-exchanged with one RCCL all-reduce(MAX) of packed (score,index) keys per step.
+
+Without --config the run first prints one line each for the other two configurations BASELINE.json names (same format,
+"headline": false):  H (configs[2]: 25 Msps, 12 SVs, 1e5-point grids; N = 1 only) and M (configs[3]: 1e6-point GLOBAL grids
+sharded over the N GPUs, strong scaling), then the headline line.
+
+N > 1: the grid dimension is sharded (R, H: each rank scores its own contiguous slice of an N-times larger global grid ->
+weak scaling; M: the global grid is fixed -> strong scaling).  Stage 1 is sharded by WINDOW: rank r correlates windows
+[r W/N, (r+1) W/N) and the banks travel with one RCCL all-gather each (code, carrier; K (2L+1 + 2B+1) 8 B per window);
+`--stage1 replicated` recomputes them on every rank instead.  The per-window arg-max is exchanged with one RCCL
+all-reduce(MAX) of packed (score, index) keys per step (`--exchange scores`: the north-star-literal all-reduce(SUM) of
+zero-initialised full score vectors).
+
+Timing: W untimed warm-up steps and a clock warm-up, then FIVE timed batches, each bracketed by barrier + synchronize and
+each made of a whole number of repetitions of the K steps so that it lasts >= 0.2 s; per batch the MAX over ranks, and the
+MEDIAN batch is reported.
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -29,18 +43,25 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
+# What physically limits each kernel (rocprofv3 SQ counters, profiles/*_sq_counters.json): none of them
+# is HBM-bound -- the "hbm" roofline below is SURVEY 8(d)'s algorithmic-bytes convention, not the physical limiter.
+BOUND_PHYSICAL = {"bcm_scan_kernel": "valu", "bcs_bank_chip_kernel": "valu+lds", "bcs_bank16_kernel": "valu",
+                  "bcs_bank_wide_kernel": "valu", "bcs_bank_kernel": "valu", "bcs_finalize_kernel": "latency",
+                  "bcs_sum_kernel": "hbm"}
 
-def pmc_traffic(windows):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.json; FETCH_SIZE doubled as the microarch guide prescribes), or None when
-    the batch size differs from the profiled one."""
+
+def pmc_traffic(config, windows, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json; FETCH_SIZE
+    doubled as the microarch guide prescribes) for this configuration and batch size -> (bytes, source file) or (None, None)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         d = json.load(open(f))
-        if d.get("windows_per_step") == windows:
-            k = d["kernels"].get("bcm_scan_kernel")
-            return k["hbm_bytes_per_launch"] if k else None
-    return None
+        if d.get("config", "R") != config or d.get("windows_per_step") != windows:
+            continue
+        for k, v in d["kernels"].items():
+            if k.startswith(kernel) or v.get("full_name", "").startswith(kernel):
+                return v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
 
 
 def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0):
@@ -48,7 +69,6 @@ def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0):
     on whole windows of the same workload: one thread (the contract's cpu_baseline), then one process per usable
     core over independent windows, with the host description beside them."""
     import shutil
-    import subprocess
     import tempfile
     import navlab_dpe_sdr_amd as dpe
     from oracle import mp_baseline as mb
@@ -135,11 +155,11 @@ def acq_main(mode):
     acq.search_signal(d)
     t0 = time.perf_counter()
     for _ in range(5):
-        full = acq.search_signal(d)                    # coarse + fine frequency, host-synchronous
+        acq.search_signal(d)                    # coarse + fine frequency, host-synchronous
     ms_full = (time.perf_counter() - t0) / 5 * 1e3
     t0 = time.perf_counter()
     for _ in range(5):
-        acq.search(d); coarse = acq.results()
+        acq.search(d); acq.results()
     ms_coarse = (time.perf_counter() - t0) / 5 * 1e3
     cells = len(prns) * bins.size * (S // 10)
     out = {"metric": "acquisition search cells (PRN x Doppler bin x code delay) per second", "mode": mode,
@@ -157,71 +177,77 @@ def acq_main(mode):
     print(json.dumps(out))
 
 
+class Ctx:
+    """Process-group state of this rank."""
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.use_dist = self.world > 1 or os.environ.get("DPE_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL self-test
+        self.backend = os.environ.get("DPE_BENCH_BACKEND", "nccl")
+        self.dist = None
+        self.dev = None
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--windows", type=int, default=None, help="windows per step (batch resident in HBM); default 256 (R) / 32 (H)")
-    ap.add_argument("--config", choices=["R", "H"], default="R",
-                    help="R = BASELINE.json configs[1] (the metric's configuration); H = configs[2] (25 Msps, 12 SVs, 1e5-point grids)")
-    ap.add_argument("--exchange", choices=["keys", "scores"], default="keys",
-                    help="multi-GPU exchange: packed arg-max keys (8 B/window/manifold) or the north-star-literal "
-                         "all-reduce(SUM) of the zero-initialised full score vectors")
-    ap.add_argument("--acq", choices=["coherent", "noncoherent", "textbook"], default=None,
-                    help="time the cold-start acquisition search instead (8f row 4; separate JSON line, not the headline)")
-    ap.add_argument("--clock-warmup-s", type=float, default=1.0,
-                    help="seconds of untimed steps after --warmup, before the timed region (GPU clock settle)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-scores", action="store_true", help="skip the per-point score write (arg-max only)")
-    ap.add_argument("--include-h2d", action="store_true",
-                    help="also time the steps with the window batch uploaded from pinned host memory inside the timed "
-                         "region (reported as pcie_inclusive_value; never the headline value)")
-    args = ap.parse_args()
-    if args.acq:
-        return acq_main(args.acq)
 
+def device_view(ptr, shape, typestr, dev):
+    """torch tensor over device memory owned by a library handle."""
     import torch
-    import torch.distributed as dist
+
+    class _Cai:
+        __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
+    return torch.as_tensor(_Cai(), device=dev)
+
+
+def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
+    """Times one configuration; rank 0 returns the result dict (None elsewhere).  `cached`: windows built for another
+    configuration of the same sampling shape (R and M share theirs)."""
+    import torch
     import navlab_dpe_sdr_amd as dpe
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or os.environ.get("DPE_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL self-test
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        # DPE_BENCH_BACKEND=gloo DPE_BENCH_SHARE_GPU=1: functional check of the N > 1 code path on a one-GPU box (all
-        # ranks on cuda:0, exchange through gloo) -- RCCL refuses two ranks on one device.  Never a performance number.
-        backend = os.environ.get("DPE_BENCH_BACKEND", "nccl")
-        if os.environ.get("DPE_BENCH_SHARE_GPU") == "1":
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    dist, dev, world, rank = ctx.dist, ctx.dev, ctx.world, ctx.rank
+    cfg = dict({"R": dpe.workload.CONFIG_R, "H": dpe.workload.CONFIG_H, "M": dpe.workload.CONFIG_M}[name])
+    fs, S, K, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["L"], cfg["B"]
+    strong = name == "M"
+    W = args.windows if (args.windows and headline) else (32 if name == "H" else 256)
+    if not headline and args.extra_windows:
+        W = args.extra_windows
+    # --- inputs
+    if cached is not None and cached["key"] == (fs, S, K, W):
+        iq, cs, ce, bw = cached["data"]
     else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if use_dist else 0)
-
-    cfg = dict(dpe.workload.CONFIG_R if args.config == "R" else dpe.workload.CONFIG_H)
-    fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
-    W = args.windows if args.windows else (256 if args.config == "R" else 32)
-    iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=0, amp=cfg["amp"])
-    pos_g, vel_g, pos, vel, off = dpe.workload.build_grids(G, rank, world)
+        distinct = W if name != "H" else min(W, 8)      # H: 8 distinct windows (1.7 s of numpy each), repeated with their state
+        iq, cs, ce, bw = dpe.workload.build_windows(distinct, fs, S, K, seed=0, amp=cfg["amp"])
+        if distinct < W:
+            rep = (W + distinct - 1) // distinct
+            iq, cs, ce, bw = (np.concatenate([a] * rep)[:W] for a in (iq, cs, ce, bw))
+    if strong:
+        G_global = cfg["G"]
+        pos_g, vel_g, pos, vel, off = dpe.workload.build_grids_strong(G_global, rank, world)
+    else:
+        pos_g, vel_g, pos, vel, off = dpe.workload.build_grids(cfg["G"], rank, world)
+        G_global = cfg["G"] * world
+    G = pos.shape[0]
     write_scores = (not args.no_scores) or args.exchange == "scores"
-
-    iq_d = torch.from_numpy(iq).to(dev)          # inputs resident in HBM before the timed region
-    bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K)
+    # --- stage-1 sharding by window
+    shard1 = ctx.use_dist and world > 1 and args.stage1 == "sharded" and W % world == 0
+    Wl = W // world if shard1 else W
+    w0 = rank * Wl if shard1 else 0
+    iq_d = torch.from_numpy(np.ascontiguousarray(iq[w0:w0 + Wl])).to(dev)     # inputs resident in HBM before the timed region
+    cs_l = np.ascontiguousarray(cs[w0:w0 + Wl])
+    bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=Wl, max_channels=K)
     bcs.Start()
     bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B, max_windows=W,
                                 max_channels=K, write_scores=write_scores, pos_index_offset=off, vel_index_offset=off)
     bcm.Start()
     stream = torch.cuda.current_stream()
+    nLag, nBin = 2 * L + 1, 2 * B + 1
+    if shard1:
+        loc_code = device_view(bcs.CodeScores, (Wl, K, nLag, 2), "<f4", dev)
+        loc_carr = device_view(bcs.CarrScores, (Wl, K, nBin, 2), "<f4", dev)
+        full_code = torch.empty((W, K, nLag, 2), dtype=torch.float32, device=dev)
+        full_carr = torch.empty((W, K, nBin, 2), dtype=torch.float32, device=dev)
+        code_ptr, carr_ptr = full_code.data_ptr(), full_carr.data_ptr()
+    else:
+        code_ptr, carr_ptr = bcs.CodeScores, bcs.CarrScores
     key_views = {}
 
     def keys_tensor():
@@ -229,42 +255,33 @@ def main():
         scores are >= 0 so the sign bit is clear"""
         ptr = bcm.Keys
         if ptr not in key_views:
-            class _Cai:
-                __cuda_array_interface__ = {"shape": (W, 2), "typestr": "<i8", "data": (ptr, False), "version": 2}
-            key_views[ptr] = torch.as_tensor(_Cai(), device=dev)
+            key_views[ptr] = device_view(ptr, (W, 2), "<i8", dev)
         return key_views[ptr]
 
-    if use_dist:
-        if args.exchange == "scores":
-            glob_p = torch.zeros((W, G * world), dtype=torch.float32, device=dev)
-            glob_v = torch.zeros((W, G * world), dtype=torch.float32, device=dev)
+    if ctx.use_dist and args.exchange == "scores":
+        glob_p = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
+        glob_v = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
+        loc_p = device_view(bcm.PosScores, (W, G), "<f4", dev)
+        loc_v = device_view(bcm.VelScores, (W, G), "<f4", dev)
 
-            class _CaiS:
-                def __init__(self, ptr):
-                    self.__cuda_array_interface__ = {"shape": (W, G), "typestr": "<f4", "data": (ptr, False), "version": 2}
-            loc_p = torch.as_tensor(_CaiS(bcm.PosScores), device=dev)
-            loc_v = torch.as_tensor(_CaiS(bcm.VelScores), device=dev)
-
-    pending = [None]   # the previous step's arg-max exchange, still in flight
-
-    def drain():
-        if pending[0] is not None:
-            pending[0].wait()            # stream-level wait: the compute stream continues after the collective
-            pending[0] = None
+    def gather_banks():
+        if ctx.backend == "nccl":
+            dist.all_gather_into_tensor(full_code, loc_code)
+            dist.all_gather_into_tensor(full_carr, loc_carr)
+        else:   # gloo (functional tests on one GPU): through host memory
+            for full, loc in ((full_code, loc_code), (full_carr, loc_carr)):
+                parts = [torch.empty(loc.shape, dtype=loc.dtype) for _ in range(world)]
+                dist.all_gather(parts, loc.cpu())
+                full.copy_(torch.cat(parts))
 
     def step():
-        bcs.Update(iq_d, cs, stream=stream)     # stage 1 overlaps the previous step's exchange
-        drain()                                 # ... which must be done before the scan clears that key set
-        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce, stream=stream)
-        if use_dist:
+        bcs.Update(iq_d, cs_l, stream=stream)
+        if shard1:
+            gather_banks()
+        bcm.Update(code_ptr, carr_ptr, bw, ce, stream=stream)
+        if ctx.use_dist:
             if args.exchange == "keys":
-                # in-order exchange by default; DPE_BENCH_EXCH_MODE=async overlaps it with the next step's stage 1
-                # (measured SLOWER on one MI355X: the collective's kernel then competes with the correlator, DESIGN.md 6)
-                mode = os.environ.get("DPE_BENCH_EXCH_MODE", "sync")
-                if mode == "async":
-                    _, pending[0] = dpe.sharding.allreduce_argmax(keys_tensor(), dist, async_op=True)
-                elif mode == "sync":
-                    dpe.sharding.allreduce_argmax(keys_tensor(), dist)
+                dpe.sharding.allreduce_argmax(keys_tensor(), dist)
             else:
                 glob_p.zero_(); glob_v.zero_()
                 glob_p[:, off:off + G].copy_(loc_p); glob_v[:, off:off + G].copy_(loc_v)
@@ -273,56 +290,66 @@ def main():
                 torch.argmax(glob_p, dim=1); torch.argmax(glob_v, dim=1)
 
     def fence():
-        drain()
-        if use_dist:
+        if ctx.use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def max_over_ranks(dt):
+        if not ctx.use_dist:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if ctx.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for _ in range(warmup):
         step()
     fence()
     # Clock warm-up, untimed: a GPU that idled at its lowest sclk takes on the order of a second of load to settle at its
-    # sustained clock -- the first bench of a fresh box measured 3 % below an immediate second one with only the
-    # --warmup steps in front.  The metric is steady-state throughput, so the settle time stays outside the timed region.
+    # sustained clock.  The metric is steady-state throughput, so the settle time stays outside the timed region.
     t_w = time.perf_counter()
-    while time.perf_counter() - t_w < args.clock_warmup_s:
-        for _ in range(32):
+    while max_over_ranks(time.perf_counter() - t_w) < args.clock_warmup_s:
+        for _ in range(8):
             step()
         fence()
-    # Untimed side pass: per-kernel HIP events on every kernel, for `kernels_ms_per_step` (informational).  It runs
-    # BEFORE the timed region so that it also serves as clock warm-up (the first ~20 launches of a fresh process run
-    # 5-10 % slower; rocprofv3 per-launch trace, profiles/README.md).
-    extra = 24   # ~22 ms: enough for the clocks to settle whatever --warmup / --steps are
+    # Untimed side pass: HIP events around every kernel (`kernels_ms_per_step`), which also names the time-dominant kernel.
     bcs.profile(True); bcm.profile(True)
-    for _ in range(extra):
+    n_side = 12
+    for _ in range(n_side):
         step()
     fence()
-    kern_extra = bcs.profile(False)
-    bcm.profile(False)
-    # Timed region: only the dominant kernel (the fused scan, `roofline`) carries HIP events -- a pair of events
-    # around every kernel costs ~2 % of the step (measured: 0.948 vs 0.928 ms).
-    bcm.profile(True)
-    if os.environ.get("DPE_BENCH_EVENTS") == "all":   # experiment: events around every kernel inside the timed region
-        bcs.profile(True)
+    side = dict(bcs.profile(False))
+    side.update(bcm.profile(False))
+    kernels_ms = {k: v[0] / max(v[1], 1) * (v[1] / n_side) for k, v in side.items()}   # per step (side chunks of a wide lag window add up)
+    dominant = max(kernels_ms, key=kernels_ms.get)
+    # Timed region: only the dominant kernel carries HIP events (a pair of events around every kernel costs ~2 % of a step)
+    est = 0.0
+    fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
-    dt = time.perf_counter() - t0
-    kern = {}
-    kern.update(bcm.profile(False))
-    if os.environ.get("DPE_BENCH_EVENTS") == "all":
-        bcs.profile(False)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    est = max_over_ranks(time.perf_counter() - t0) / steps
+    reps = max(1, int(math.ceil(args.min_batch_s / max(est * steps, 1e-9))))
+    if dominant == "bcm_scan":
+        bcm.profile(True)
+    else:
+        bcs.profile(dominant)
+    batch_ms = []
+    for _ in range(args.batches):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps * steps):
+            step()
+        fence()
+        batch_ms.append(max_over_ranks(time.perf_counter() - t0) / (reps * steps) * 1e3)
+    kern = dict(bcm.profile(False)) if dominant == "bcm_scan" else dict(bcs.profile(False))
+    ms_step = float(np.median(batch_ms))
 
-    # result sanity on rank 0: the synthetic windows put the truth at the grid centre -> the ML point must be
-    # the grid point with the smallest geometric offset pattern; just check the fix is finite and in-grid.
-    if use_dist:
+    # result sanity on rank 0: finite fix; with one rank the exchanged keys decode to what the handle itself reports,
+    # and the banks must cover every index the grids reach
+    if ctx.use_dist:
         res = bcm.results_from_keys(keys_tensor().cpu().numpy().view(np.uint64), pos_g, vel_g)
-        if world == 1:   # self-test: the exchanged keys decode to what the handle itself reports
+        if world == 1:
             ref = bcm.results()
             assert all(a["posIndex"] == b["posIndex"] and a["velIndex"] == b["velIndex"] and
                        np.array_equal(a["zVal"], b["zVal"]) for a, b in zip(res, ref))
@@ -330,19 +357,19 @@ def main():
     else:
         res = bcm.results()
     assert all(np.isfinite(r["zVal"]).all() for r in res)
-    if world == 1:   # the banks must cover every index the grids reach
+    if world == 1:
         assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res), "bank window too narrow"
 
     pcie_value = pcie_overlapped = None
-    if args.include_h2d and not use_dist:
+    if args.include_h2d and headline and not ctx.use_dist:
         iq_pin = torch.from_numpy(iq).pin_memory()
         fence()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             iq_d.copy_(iq_pin, non_blocking=True)     # SampleBlock's H2D leg (sampleblock.cu:356-410), same stream
             step()
         fence()
-        pcie_value = float(args.steps) * W * 2.0 * G * K / (time.perf_counter() - t1)
+        pcie_value = float(steps) * W * 2.0 * G * K / (time.perf_counter() - t1)
         # the same with the upload double-buffered on a copy stream (what SampleBlock does per window): batch n+1
         # travels while batch n is processed
         copy_stream = torch.cuda.Stream()
@@ -361,67 +388,175 @@ def main():
         fence()
         t2 = time.perf_counter()
         upload(0)
-        for n in range(args.steps):
+        for n in range(steps):
             cur = n & 1
-            if n + 1 < args.steps:
+            if n + 1 < steps:
                 upload(cur ^ 1)
             torch.cuda.current_stream().wait_event(ready[cur])
-            bcs.Update(bufs[cur], cs, stream=stream)
-            bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce, stream=stream)
+            bcs.Update(bufs[cur], cs_l, stream=stream)
+            bcm.Update(code_ptr, carr_ptr, bw, ce, stream=stream)
             freed[cur].record(torch.cuda.current_stream())
         fence()
-        pcie_overlapped = float(args.steps) * W * 2.0 * G * K / (time.perf_counter() - t2)
+        pcie_overlapped = float(steps) * W * 2.0 * G * K / (time.perf_counter() - t2)
 
+    out = None
     if rank == 0:
-        units = float(args.steps) * W * 2.0 * G * K * world       # (gridpoint, SV) pairs, both manifolds, all ranks
-        value = units / dt
-        windows_per_s = args.steps * W / dt
-        ms_scan, n_scan = kern["bcm_scan"]
-        # one launch scans BOTH manifolds: 16 B grid read + 4 B score write per point
-        bytes_per_launch = 2 * W * 20.0 * G
-        ach = bytes_per_launch / (ms_scan / n_scan * 1e-3) / 1e9 if n_scan else 0.0
+        units_per_step = W * 2.0 * G_global * K                    # (gridpoint, SV) pairs, both manifolds, all ranks
+        value = units_per_step / (ms_step * 1e-3)
+        windows_per_s = W / (ms_step * 1e-3)
+        # --- roofline of the time-dominant kernel, SURVEY 8(d) algorithmic bytes per launch ON THIS RANK
+        stage1 = bcs.stage1_kernel
+        kname = {"bcm_scan": "bcm_scan_kernel", "bcs_bank": stage1, "bcs_finalize": "bcs_finalize_kernel",
+                 "bcs_sum": "bcs_sum_kernel"}[dominant]
+        alg = {"bcm_scan": 2 * W * 20.0 * G,            # 16 B grid read + 4 B score write per point, both manifolds in one launch
+               "bcs_bank": Wl * 4.0 * S,                # every int16 I/Q sample once (all SVs of a window share the read)
+               "bcs_sum": Wl * 4.0 * S,
+               "bcs_finalize": Wl * K * (nLag + nBin) * 8.0}[dominant]
+        ms_k, n_k = kern[dominant]
+        avg_ms = ms_k / n_k if n_k else None
+        ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+        whole_bytes = W * (4.0 * S + 2 * 20.0 * G_global)         # per step, samples counted once for the node
+        traffic, tsrc = pmc_traffic(name, W, kname) if world == 1 else (None, None)
         out = {
             "metric": "manifold gridpoints x SVs correlated/sec", "value": value, "unit": "gridpoint*SV/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "headline": bool(headline),
             "config": {"workload": cfg["name"], "samples_per_window": S, "svs": K, "grid_points_per_manifold_per_gpu": G,
-                       "manifolds": 2, "windows_per_step": W, "lag_half_width": L, "bin_half_width": B,
-                       "exchange": args.exchange if use_dist else "none", "scores_written": write_scores},
+                       "grid_points_per_manifold_global": G_global, "manifolds": 2, "windows_per_step": W,
+                       "lag_half_width": L, "bin_half_width": B, "exchange": args.exchange if ctx.use_dist else "none",
+                       "stage1": ("sharded by window + bank all-gather" if shard1 else "replicated") if ctx.use_dist else "local",
+                       "scores_written": write_scores},
+            "timing": {"timed_batches": args.batches, "steps_per_timed_batch": reps * steps, "batch_ms_per_step": batch_ms,
+                       "statistic": "median of the batches, each the max over ranks"},
             "x_realtime": windows_per_s / 50.0, "windows_per_s": windows_per_s,
-            "roofline": {"bound": "hbm", "kernel": "bcm_scan_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(W) if world == 1 else None,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": ms_scan / n_scan if n_scan else None},
-            "kernels_ms_per_step": dict({k: v[0] / args.steps for k, v in kern.items()},
-                                        **{k: v[0] / max(v[1], 1) for k, v in kern_extra.items()}),
+            "roofline": {"bound": "hbm", "bound_physical": BOUND_PHYSICAL.get(kname, "valu"), "kernel": kname,
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": tsrc,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms,
+                         "whole_step_algorithmic_bytes": whole_bytes,
+                         "whole_step_frac": whole_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "algorithmic bytes (SURVEY 8d) over the kernel's HIP-event time; bound_physical names the "
+                                 "measured limiter (SQ counters under profiles/), the kernels are not HBM-bound"},
+            "kernels_ms_per_step": kernels_ms, "stage1_kernel": stage1,
         }
         if pcie_value is not None:
             out["pcie_inclusive_value"] = pcie_value
             out["pcie_inclusive_overlapped_value"] = pcie_overlapped
-        if world == 1:
+        if world == 1 and headline:
             # measured ceiling beside the nominal peak: stream copy and triad over 1 GiB arrays
             cp, tr = dpe.engine.hbm_ceiling(1 << 30, 10, stream)
-            tb = out["roofline"]["traffic"]
             out["roofline"]["measured_ceiling"] = {
                 "copy_GBps": cp, "triad_GBps": tr, "algorithmic_over_triad": ach / tr,
                 # what the kernel really pulls from HBM (PMC bytes / launch time): the grids are shared by the windows
                 # of a batch and stay in L2, so the algorithmic rate may exceed the physical ceiling
-                "physical_GBps": tb / (ms_scan / n_scan * 1e-3) / 1e9 if tb and n_scan else None}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+                "physical_GBps": traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms else None}
     bcm.Stop(); bcs.Stop()
-    if use_dist:
+    del iq_d
+    torch.cuda.empty_cache()
+    return out, {"key": (fs, S, K, W), "data": (iq, cs, ce, bw)}
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD (never exec: this process
+    may not replace itself once anything touched the GPU, and it keeps the relay simple), pass its output through."""
+    port = os.environ.get("MASTER_PORT", "29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=None, help="windows per step (batch resident in HBM); default 256 (R, M) / 32 (H)")
+    ap.add_argument("--config", choices=["R", "H", "M"], default=None,
+                    help="time only this configuration.  R = BASELINE.json configs[1] (the metric's configuration, the default "
+                         "headline); H = configs[2] (25 Msps, 12 SVs, 1e5-point grids); M = configs[3] (1e6-point global grids, "
+                         "strong scaling over the GPUs).  Without it: H (N = 1) and M lines first, then the R headline")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline configuration")
+    ap.add_argument("--extra-windows", type=int, default=None, help="windows per step of the extra (non-headline) lines")
+    ap.add_argument("--exchange", choices=["keys", "scores"], default="keys",
+                    help="multi-GPU exchange: packed arg-max keys (8 B/window/manifold) or the north-star-literal "
+                         "all-reduce(SUM) of the zero-initialised full score vectors")
+    ap.add_argument("--stage1", choices=["sharded", "replicated"], default="sharded",
+                    help="N > 1: correlate W/N windows per rank and all-gather the banks (default), or recompute stage 1 everywhere")
+    ap.add_argument("--acq", choices=["coherent", "noncoherent", "textbook"], default=None,
+                    help="time the cold-start acquisition search instead (8f row 4; separate JSON line, not the headline)")
+    ap.add_argument("--clock-warmup-s", type=float, default=1.0,
+                    help="seconds of untimed steps after --warmup, before the timed region (GPU clock settle)")
+    ap.add_argument("--batches", type=int, default=5, help="timed batches (the median is reported)")
+    ap.add_argument("--min-batch-s", type=float, default=0.2, help="each timed batch repeats the --steps steps until it lasts this long")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scores", action="store_true", help="skip the per-point score write (arg-max only)")
+    ap.add_argument("--include-h2d", action="store_true",
+                    help="also time the steps with the window batch uploaded from pinned host memory inside the timed "
+                         "region (reported as pcie_inclusive_value; never the headline value)")
+    args = ap.parse_args()
+    if args.acq:
+        return acq_main(args.acq)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args, sys.argv[1:])          # does not return
+
+    import torch
+    import torch.distributed as dist
+    import navlab_dpe_sdr_amd as dpe  # noqa: F401
+
+    ctx = Ctx()
+    if ctx.world != args.gpus and not (ctx.world == 1 and args.gpus == 1):
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks\n" % (args.gpus, ctx.world))
+        sys.exit(2)
+    if ctx.use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # DPE_BENCH_BACKEND=gloo DPE_BENCH_SHARE_GPU=1: functional check of the N > 1 code path on a one-GPU box (all
+        # ranks on cuda:0, exchange through gloo) -- RCCL refuses two ranks on one device.  Never a performance number.
+        if os.environ.get("DPE_BENCH_SHARE_GPU") == "1":
+            ctx.local_rank = 0
+        torch.cuda.set_device(ctx.local_rank)
+        if ctx.backend == "nccl":
+            dist.init_process_group("nccl", rank=ctx.rank, world_size=ctx.world, device_id=torch.device("cuda", ctx.local_rank))
+        else:
+            dist.init_process_group(ctx.backend, rank=ctx.rank, world_size=ctx.world)
+        ctx.dist = dist
+    else:
+        torch.cuda.set_device(0)
+    ctx.dev = torch.device("cuda", ctx.local_rank if ctx.use_dist else 0)
+
+    def emit(d):
+        # RCCL writes a version banner through C stdio on stdout; push it out first so that the JSON line comes last
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        if ctx.rank == 0 and d is not None:
+            print(json.dumps(d), flush=True)
+
+    headline = args.config or "R"
+    cached = None
+    if args.config is None and not args.no_extras:
+        extra_steps = min(args.steps, 20)
+        if ctx.world == 1 and not ctx.use_dist:
+            out, _ = run_workload("H", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
+            emit(out)
+        out, cached = run_workload("M", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
+        emit(out)
+    out, _ = run_workload(headline, ctx, args, args.steps, args.warmup, headline=True, cached=cached)
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        cfg = {"R": dpe.workload.CONFIG_R, "H": dpe.workload.CONFIG_H, "M": dpe.workload.CONFIG_M}[headline]
+        out["cpu_baseline"] = cpu_baseline(dict(cfg, G=min(cfg["G"], 390625)))
+    if ctx.use_dist:
         dist.barrier()
+    emit(out)
+    if ctx.use_dist:
         dist.destroy_process_group()
-    # RCCL writes a version banner through C stdio on stdout; push it out first so that the JSON line is the
-    # last thing this process prints
-    import ctypes
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    if rank == 0:
-        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -314,6 +314,11 @@ int dpe_acq_surface(dpe_acq *h, const float **surface_dev, const float **maxPerC
  * BCS slots: 0 DC-sum (not launched for single windows, where the bank kernel carries the sums), 1 bank (one launch per
  * 65-lag chunk), 2 finalize (ms[3], count[3]); BCM: slot 0 = the fused position + velocity scan (slot 1 unused). */
 int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count);
+/* enable = 1: events around every kernel; enable = 2 * m: only around the slots of bit mask m (e.g. 4 = the bank kernel
+ * alone -- bench.py times just the dominant kernel inside its timed region). */
+/* Name of the stage-1 kernel the last Update launched ("bcs_bank_kernel", "bcs_bank16_kernel", "bcs_bank_wide_kernel",
+ * "bcs_bank_chip_kernel"): which of the forms of DESIGN.md 2.2 the shape selected. */
+const char *dpe_bcs_stage1_kernel(dpe_bcs *h);
 int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count);
 
 /* Closed-loop latency: with enable != 0 an Update whose shape and device pointers repeat (the per-window

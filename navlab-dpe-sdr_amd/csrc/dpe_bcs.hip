@@ -993,6 +993,7 @@ struct dpe_bcs {
     float2 *part_d = nullptr, *mom_d = nullptr, *momRep_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
     int *info_d = nullptr;
     int lastW = 0, lastK = 0, lastSumBlocks = 1;
+    const char *lastKernel = "";   // stage-1 kernel of the last Update (dpe_bcs_stage1_kernel)
     std::vector<int32_t> idxNext_h;
     dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
     dpe::GraphCache graphs;
@@ -1255,6 +1256,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         chipNMom = (std::pow(thc, 4) / 24.0 < 1e-7) ? 4 : 6;
     }
     const int nBlk = chip ? (h->nPassChip + tpb - 1) / tpb : (nTiles + tpb - 1) / tpb;
+    h->lastKernel = chip ? "bcs_bank_chip_kernel" : use16 ? "bcs_bank16_kernel" : wide ? "bcs_bank_wide_kernel" : "bcs_bank_kernel";
     const dim3 grid(nBlk, nChan, nWindows), block(256);
     // single windows (<= 37 (window, channel) pairs) with a dense stage-1 kernel: no separate DC-sum launch, the
     // sums ride along in the bank kernel (FUSE) and the finalize kernel applies the mean
@@ -1389,7 +1391,13 @@ int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count)
         if (count) count[i] = c[i];
     }
     h->prof.enabled = enable != 0;
+    h->prof.mask = enable <= 1 ? ~0u : (unsigned)(enable >> 1);   // enable = 1: every kernel; 2 * m: the slots of bit mask m
     return 0;
+}
+
+const char *dpe_bcs_stage1_kernel(dpe_bcs *h)
+{
+    return h ? h->lastKernel : "";
 }
 
 int dpe_bcs_read_info(dpe_bcs *h, int32_t *idxNext, int32_t *noFlipLarger, double *mean, dpe_stream_t stream)

@@ -100,11 +100,12 @@ __device__ __forceinline__ float lane63(float v)
 // Optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
 struct KernelProfiler {
     bool enabled = false;
+    unsigned mask = ~0u;   // slots that carry events while enabled (a pair of events costs ~1 % of a short step)
     static constexpr int kSlots = 8;
     std::vector<hipEvent_t> ev[kSlots];   // pairs: start, stop
     void begin(int slot, hipStream_t st)
     {
-        if (!enabled) return;
+        if (!enabled || !((mask >> slot) & 1u)) return;
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
         ev[slot].push_back(a);
@@ -113,7 +114,7 @@ struct KernelProfiler {
     }
     void end(int slot, hipStream_t st)
     {
-        if (!enabled || ev[slot].empty()) return;
+        if (!enabled || !((mask >> slot) & 1u) || ev[slot].empty()) return;
         (void)hipEventRecord(ev[slot].back(), st);
     }
     // total milliseconds and launch count per slot since the last call; frees the events

@@ -26,7 +26,7 @@ EXPORTS = [
     "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface", "dpe_bcs_set_graph", "dpe_bcm_set_graph",
     "dpe_acq_fine", "dpe_acq_scalar_acquisition",
     "dpe_ekf_create", "dpe_ekf_destroy", "dpe_ekf_step_update", "dpe_ekf_step_predict", "dpe_ekf_state",
-    "dpe_hbm_ceiling",
+    "dpe_hbm_ceiling", "dpe_bcs_stage1_kernel",
 ]
 
 
@@ -102,6 +102,7 @@ def lib():
             pass
         _lib = C.CDLL(LIB_PATH)
         _lib.dpe_last_error.restype = C.c_char_p
+        _lib.dpe_bcs_stage1_kernel.restype = C.c_char_p
         for name in EXPORTS:
             getattr(_lib, name)  # AttributeError if the ABI is incomplete
     return _lib
@@ -252,11 +253,19 @@ class BatchCorrScores:
         """Replay repeated Updates as one hipGraph launch (needs a created stream, see dpe_hip.h)."""
         _check(lib().dpe_bcs_set_graph(self._h, C.c_int32(1 if enable else 0)))
 
+    PROFILE_SLOTS = ("bcs_sum", "bcs_bank", "bcs_finalize")
+
     def profile(self, enable=True):
-        """-> {kernel: (total_ms, launches)} since the previous call; sets the enable flag."""
+        """-> {kernel: (total_ms, launches)} since the previous call; sets the enable flag.
+        enable: False / True (every kernel) / one of PROFILE_SLOTS (events around that kernel only)."""
         ms, cnt = (C.c_float * 3)(), (C.c_int32 * 3)()
-        _check(lib().dpe_bcs_profile(self._h, C.c_int32(1 if enable else 0), ms, cnt))
-        return {n: (ms[i], cnt[i]) for i, n in enumerate(("bcs_sum", "bcs_bank", "bcs_finalize"))}
+        code = 2 << self.PROFILE_SLOTS.index(enable) if isinstance(enable, str) else (1 if enable else 0)
+        _check(lib().dpe_bcs_profile(self._h, C.c_int32(code), ms, cnt))
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(self.PROFILE_SLOTS)}
+
+    @property
+    def stage1_kernel(self):
+        return lib().dpe_bcs_stage1_kernel(self._h).decode()
 
     def Stop(self):
         if self.Started:

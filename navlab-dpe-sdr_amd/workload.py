@@ -19,6 +19,10 @@ CONFIG_R = dict(name="R: demofiles twin, 2.5 Msps x 20 ms, 8 SVs, rngrid3-format
 CONFIG_H = dict(name="H: synthetic 25 Msps x 20 ms, 12 SVs, 1e5-point rngrid3-format grids",
                 fs=25e6, S=500000, K=12, G=100000, L=31, B=16, amp=15.2)
 
+# BASELINE.json configs[3]: 1e6-point grid over the GPUs of one node (strong scaling: the GLOBAL grid is fixed)
+CONFIG_M = dict(name="M: synthetic 2.5 Msps x 20 ms, 8 SVs, 1e6-point rngrid3-format grids sharded over the GPUs",
+                fs=2.5e6, S=50000, K=8, G=1000000, L=4, B=20, amp=48.0)
+
 _C = 299792458.0
 _FCA = 1.023e6
 _FL1 = 1.57542e9
@@ -116,8 +120,17 @@ def build_windows(W, fs, S, K, seed=0, amp=48.0, velocity=None, truth_out=None):
 
 
 def build_grids(G_local, rank=0, world=1, seed=3):
-    """This rank's contiguous slice of the global rngrid3-format grids."""
+    """This rank's contiguous slice of the global rngrid3-format grids, weak scaling: world x G_local points."""
     pos = synth.rand_grid(seed, G_local * world)
     vel = synth.rand_grid(seed + 1, G_local * world, half=(6.0, 6.0, 6.0, 3.0))
     sl = slice(rank * G_local, (rank + 1) * G_local)
     return pos, vel, pos[sl], vel[sl], rank * G_local
+
+
+def build_grids_strong(G_global, rank=0, world=1, seed=3):
+    """Strong scaling: the global grids are fixed, rank r takes sharding.shard_range(G_global, r, world)."""
+    from . import sharding
+    pos = synth.rand_grid(seed, G_global)
+    vel = synth.rand_grid(seed + 1, G_global, half=(6.0, 6.0, 6.0, 3.0))
+    b, e = sharding.shard_range(G_global, rank, world)
+    return pos, vel, pos[b:e], vel[b:e], b

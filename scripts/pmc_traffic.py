@@ -1,7 +1,7 @@
 """Builds profiles/<tag>_pmc_traffic.json from the two rocprofv3 counter passes of scripts/collect_profiles.sh:
 mean FETCH_SIZE / WRITE_SIZE (KB) per launch and kernel, HBM bytes = (2 x FETCH + WRITE) x 1024 -- gfx950
 tallies 128-byte fetches as 64 B (MI355X_MICROARCH.md), cross-checked on bcs_sum_kernel, whose only traffic
-is the sample read (windows x S x 4 bytes).   usage: python scripts/pmc_traffic.py <dir> <tag> [windows]"""
+is the sample read (windows x S x 4 bytes).   usage: python scripts/pmc_traffic.py <dir> <tag> [windows] [config]"""
 import csv, json, re, sys
 from collections import defaultdict
 
@@ -14,6 +14,7 @@ def short(name):
 def main():
     d, tag = sys.argv[1], sys.argv[2]
     windows = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    config = sys.argv[4] if len(sys.argv) > 4 else "R"
     acc = defaultdict(lambda: defaultdict(list))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         with open(f"{d}/{tag}_pmc_{c}_counter_collection.csv") as f:
@@ -21,10 +22,10 @@ def main():
                 if row["Counter_Name"] == c:
                     acc[short(row["Kernel_Name"])][(c, row["Dispatch_Id"])].append(float(row["Counter_Value"]))
     out = {"source": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --kernel-trace --output-format csv -- "
-                     "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (scripts/collect_profiles.sh)",
+                     "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline [--config C]   (scripts/collect_profiles.sh)",
            "note": "KB per launch (mean over launches, summed over the counter's instances); FETCH_SIZE doubled per "
                    "MI355X_MICROARCH.md; bcs_sum_kernel cross-check: 2*FETCH = windows*S*4 bytes",
-           "windows_per_step": windows, "kernels": {}}
+           "windows_per_step": windows, "config": config, "kernels": {}}
     for k, v in acc.items():
         per = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -1,6 +1,7 @@
-"""The N > 1 path of bench.py (grid sharded over ranks, per-step exchange, max-over-ranks timing, one JSON line from rank 0)
-exercised with two ranks on ONE GPU: gloo carries the exchange and both ranks use cuda:0 (RCCL refuses two ranks on one
-device).  A functional check of the code the driver launches with --gpus 2/4/8 -- not a performance number."""
+"""The N > 1 path of bench.py (grid sharded over ranks, stage 1 sharded by window with a bank all-gather, per-step arg-max
+exchange, max-over-ranks timing, JSON lines from rank 0 only) exercised with two ranks on ONE GPU: gloo carries the exchange
+and both ranks use cuda:0 (RCCL refuses two ranks on one device).  A functional check of the code the driver launches with
+--gpus 2/4/8 -- not a performance number.  Plus the 1-rank RCCL self-test: RCCL itself initialises and reduces on the box."""
 import json
 import os
 import subprocess
@@ -10,19 +11,65 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ["--steps", "2", "--warmup", "1", "--clock-warmup-s", "0", "--min-batch-s", "0.01", "--batches", "2", "--no-cpu-baseline"]
+
+
+def _launch(port, extra, nproc=2):
+    env = dict(os.environ, DPE_BENCH_BACKEND="gloo", DPE_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + FAST + extra
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 @pytest.mark.parametrize("exchange,port", [("keys", 29561), ("scores", 29562)])
-def test_two_rank_bench_line(exchange, port):
-    env = dict(os.environ, DPE_BENCH_BACKEND="gloo", DPE_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--clock-warmup-s", "0", "--windows", "4", "--exchange", exchange, "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 only
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+def test_two_rank_bench_lines(exchange, port):
+    """Default invocation: the M line (strong scaling, 1e6-point global grids) then the R headline, rank 0 only."""
+    lines = _launch(port, ["--windows", "4", "--extra-windows", "4", "--exchange", exchange])
+    assert len(lines) == 2, lines
+    m, d = lines
+    assert m["headline"] is False and m["scaling"] == "strong" and m["n_gpus"] == 2 and m["value"] > 0
+    assert m["config"]["grid_points_per_manifold_global"] == 1000000 and m["config"]["grid_points_per_manifold_per_gpu"] == 500000
+    assert m["config"]["stage1"].startswith("sharded")
+    assert d["headline"] is True and d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["exchange"] == exchange and d["config"]["windows_per_step"] == 4
+    assert d["config"]["grid_points_per_manifold_global"] == 2 * 390625
     assert d["roofline"]["kernel"] == "bcm_scan_kernel" and d["roofline"]["achieved"] > 0
+    assert d["timing"]["timed_batches"] == 2 and len(d["timing"]["batch_ms_per_step"]) == 2
+
+
+def test_two_rank_replicated_stage1_and_config_m_alone():
+    lines = _launch(29563, ["--config", "M", "--windows", "4", "--stage1", "replicated"])
+    assert len(lines) == 1 and lines[0]["headline"] is True and lines[0]["config"]["stage1"] == "replicated"
+    assert lines[0]["scaling"] == "strong" and lines[0]["config"]["grid_points_per_manifold_per_gpu"] == 500000
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment: bench.py starts torch.distributed.run as a child."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DPE_BENCH_BACKEND="gloo", DPE_BENCH_SHARE_GPU="1", MASTER_PORT="29564")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "R", "--windows", "4"] + FAST
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_gpus_flag_must_match_the_launcher():
+    env = dict(os.environ, DPE_BENCH_BACKEND="gloo", DPE_BENCH_SHARE_GPU="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "R", "--windows", "4"] + FAST
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr
+
+
+def test_one_rank_rccl_self_test():
+    """DPE_BENCH_FORCE_DIST=1: one rank, backend nccl (= RCCL) -- the same exchange code path as N > 1; bench.py asserts that
+    the all-reduced keys decode to the fix the handle itself reports."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DPE_BENCH_BACKEND")}
+    env.update(DPE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29565", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "R", "--windows", "4"] + FAST
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["exchange"] == "keys" and d["value"] > 0

@@ -722,3 +722,52 @@ def test_bench_configurations_against_the_oracle(oracle, name, W, probe):
         sv, _ = o.bcm_vel(e["satState"], rf, C // 2 - B, bw[w]["xCurrkk1"], vel[idx], bw[w]["enu2ecef"],
                           e["carrierFrequency"], float(bw[w]["rxTime"]), fs, C, 1, 1)
         assert np.abs(ps[w][idx] - sp).max() < TOL * sp.max() and np.abs(vs[w][idx] - sv).max() < TOL * sv.max()
+
+
+def test_config_m_one_gpu_and_a_shard(oracle):
+    """BASELINE.json configs[3] on ONE GPU: 2.5 Msps, 8 SVs, the 1e6-point global rngrid3-format grids (rand_grid seed 3 / 4,
+    SURVEY 8d) -- every 997th score of both manifolds against the oracle, arg-max == first maximum of the scores written;
+    then the [3/8, 4/8) shard of the same grids with its index offset (what rank 3 of 8 scores): identical scores on the
+    slice, global indices in the keys."""
+    import torch
+    o = oracle
+    cfg = dpe.workload.CONFIG_M
+    fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
+    W = 4
+    iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=0, amp=cfg["amp"])
+    pos, vel, _, _, _ = dpe.workload.build_grids_strong(G, 0, 1)
+    assert pos.shape == (1000000, 4)
+    bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K)
+    bcs.Start()
+    bcs.Update(torch.from_numpy(iq).to("cuda:0"), cs)
+    code, carr = bcs.read_banks()
+    C = dpe.engine.carr_fft_len(S)
+
+    def scan(p, v, off):
+        bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, p, v, lag_half_width=L, bin_half_width=B, max_windows=W,
+                                    max_channels=K, write_scores=True, pos_index_offset=off, vel_index_offset=off)
+        bcm.Start()
+        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+        res = bcm.results()
+        ps, vs = bcm.read_scores()
+        bcm.Stop()
+        return res, ps, vs
+
+    res, ps, vs = scan(pos, vel, 0)
+    idx = np.arange(0, G, 997)
+    for w in range(W):
+        assert res[w]["posOutOfWindow"] == 0 and res[w]["velOutOfWindow"] == 0
+        assert res[w]["posIndex"] == int(np.argmax(ps[w])) and res[w]["velIndex"] == int(np.argmax(vs[w]))
+        e = ce[w]
+        sp, _ = o.bcm_pos(e["satState"], code[w], S // 2 - L, bw[w]["xCurrkk1"], pos[idx], bw[w]["enu2ecef"], e["codeFrequency"],
+                          e["cpRefTOW"], e["cpElapsedEnd"], e["cpRef"], e["codePhaseEnd"], float(bw[w]["rxTime"]), fs, S, 1,
+                          extended=True)
+        sv, _ = o.bcm_vel(e["satState"], carr[w], C // 2 - B, bw[w]["xCurrkk1"], vel[idx], bw[w]["enu2ecef"],
+                          e["carrierFrequency"], float(bw[w]["rxTime"]), fs, C, 1, 1)
+        assert np.abs(ps[w][idx] - sp).max() < TOL * sp.max() and np.abs(vs[w][idx] - sv).max() < TOL * sv.max()
+    b, e_ = dpe.sharding.shard_range(G, 3, 8)
+    res3, ps3, vs3 = scan(pos[b:e_], vel[b:e_], b)
+    for w in range(W):
+        assert np.array_equal(ps3[w], ps[w][b:e_]) and np.array_equal(vs3[w], vs[w][b:e_])
+        assert res3[w]["posIndex"] == b + int(np.argmax(ps[w][b:e_])) and res3[w]["velIndex"] == b + int(np.argmax(vs[w][b:e_]))
+    bcs.Stop()
