@@ -1300,10 +1300,10 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         else DPE_LAUNCH_BANK2(LHV, 6);  \
     } while (0)
     if (chip) {
-        const dim3 cgrid(nBlk, nChan, nWindows);
+        const dim3 cgrid(((nBlk * nWindows + 7) / 8) * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
 #define DPE_LAUNCH_CHIP(NM)                                                                                                    \
     hipLaunchKernelGGL((bcs_bank_chip_kernel<NM>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
-                       nChan, h->nPassChip, tpb, nBlk, sumBlocks, lagShift, h->chipDbg, h->chan_d, h->sums_d, h->chipTable_d, h->part_d, h->mom_d)
+                       nChan, nWindows, h->nPassChip, tpb, nBlk, sumBlocks, lagShift, h->chipDbg, h->chan_d, h->sums_d, h->chipTable_d, h->part_d, h->mom_d)
         if (chipNMom == 4) DPE_LAUNCH_CHIP(4); else DPE_LAUNCH_CHIP(6);
 #undef DPE_LAUNCH_CHIP
     } else if (use16) {

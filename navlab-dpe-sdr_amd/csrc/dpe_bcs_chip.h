@@ -59,7 +59,7 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 
 template <int kNMom>
 __global__ __launch_bounds__(64, 4) void bcs_bank_chip_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
-                                                              int S, int K, int nPass, int tpb, int nBlk, int nSumBlk, int lagShift, int dbg,
+                                                              int S, int K, int nW, int nPass, int tpb, int nBlk, int nSumBlk, int lagShift, int dbg,
                                                               const BcsChanDev *__restrict__ chan,
                                                               const long long *__restrict__ sums,
                                                               const int8_t *__restrict__ chipTable,
@@ -70,7 +70,13 @@ __global__ __launch_bounds__(64, 4) void bcs_bank_chip_kernel(BcsParamBlock pb, 
     __shared__ __align__(16) float2 sRot[kSPL + 1];
     __shared__ float2 sList[64 + 8];   // boundaries of a round: {J, byte offset into sQ}
 
-    const int lane = threadIdx.x, blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
+    // Block -> (window, tile, SV), XCD-aware: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, observed;
+    // used for speed only), so the K blocks that read the SAME samples (one per SV of a tile) are given linear ids that
+    // are congruent mod 8 and consecutive on that XCD: one HBM fetch, K - 1 hits in the XCD's L2.
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x >> 3, k = slot % K, tg = (slot / K) * 8 + (blockIdx.x & 7);
+    if (tg >= nBlk * nW) return;
+    const int w = tg / nBlk, blk = tg - w * nBlk;
     (void)pb;
     const BcsChanDev ch = params_ptr(chan, inl)[(size_t)w * K + k];
     const int8_t *chips = chipTable + (ch.prn - 1) * 1024;

@@ -11,7 +11,7 @@ i=0
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
          "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq_$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${DPE_BENCH_ARGS:-} \
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq_$i -- python3 $R/bench.py --steps 2 --warmup 1 --clock-warmup-s 0 --batches 1 --min-batch-s 0 --no-extras --no-cpu-baseline ${DPE_BENCH_ARGS:-} \
       > /dev/null 2> $R/gpurun_out/${TAG}_sq_$i.err
 done
 ls $R/gpurun_out | grep ${TAG}_sq_
