@@ -141,6 +141,14 @@ typedef struct dpe_bcm_config {
     int64_t velGridIndexOffset;
     int32_t writeScores;        /* 1: keep per-point fp32 scores (PosScores port), 0: arg-max only */
     int32_t weightedMean;       /* 1: also accumulate the "Method 1" score-weighted mean (see dpe_bcm_result) */
+    int32_t referencePair;      /* 1: reproduce the reference's floor(idx) / floor(idx + 1) neighbour pair bit for bit where it
+                                 * differs from the continuous interpolation (batchcorrmanifold.cu:1798-1812): when an fp64 index
+                                 * sits one rounding step below 2^m, idx + 1 rounds UP and the two neighbours are two apart, both
+                                 * with weight ~1.  Only possible for the first channel and only when S / 2 is a power of two;
+                                 * the Update then re-evaluates the affected grid points in fp64 on the host, patches their
+                                 * scores and re-derives the arg-max (synchronous; needs writeScores).  0 (default): the
+                                 * continuous interpolation everywhere.  No effect when S / 2 is not a power of two. */
+    int32_t reserved;
 } dpe_bcm_config;
 
 /* Per-window inputs of BatchCorrManifold::Update (batchcorrmanifold.cu:2261-2279,2512-2540). */

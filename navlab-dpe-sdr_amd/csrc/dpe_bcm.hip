@@ -354,6 +354,34 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
     }
 }
 
+// referencePair mode: arg-max of the position manifold re-derived from the (host-patched) score array.
+__global__ void bcm_zero_pos_keys_kernel(unsigned long long *__restrict__ keys, int nWindows)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nWindows) keys[2 * (size_t)w] = 0ull;
+}
+
+__global__ __launch_bounds__(256) void bcm_rekey_kernel(const float *__restrict__ scores, long long G, long long indexOffset,
+                                                        unsigned long long *__restrict__ keys)
+{
+    const int w = blockIdx.y;
+    const float *row = scores + (size_t)w * G;
+    float bestSc = -1.f;
+    unsigned int bestIdx = 0u;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < G; i += (long long)gridDim.x * 256) {
+        const float sc = row[i];
+        if (sc > bestSc) { bestSc = sc; bestIdx = (unsigned int)(i + indexOffset); }   // increasing i per lane: first maximum kept
+    }
+    unsigned long long best = bestSc < 0.f ? 0ull
+                                           : (((unsigned long long)__float_as_uint(bestSc) << 32) | (unsigned long long)(0xFFFFFFFFu - bestIdx));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(&keys[2 * (size_t)w], best);
+}
+
 }  // namespace dpe
 
 // ============================================================================================
@@ -379,6 +407,12 @@ struct dpe_bcm {
     unsigned lastSplit[2] = {0, 0};
     static constexpr unsigned kMaxSplit = 4096;
     size_t wsumHalf = 0;
+    // referencePair mode (dpe_bcm_config): active only when S / 2 is a power of two
+    bool refPair = false;
+    float2 *refBank_h = nullptr;            // pinned copy of the code banks of the last Update
+    float *refPatch_h = nullptr;            // pinned staging of patched scores
+    std::vector<double> refWsum;            // [W][5] corrections of the weighted sums (patched - scanned score at offset x,y,z,t)
+    long long refPatched = 0;               // points patched by the last Update (diagnostic)
     std::vector<dpe_bcm_window> win_h;
     int lastW = 0;
     double posExtent = 0, velExtent = 0;
@@ -461,6 +495,107 @@ static void allow_big_lds()
     (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, CP, CV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
 }
 
+// ---- referencePair mode ---------------------------------------------------------------------
+// The reference forms the neighbour pair as floor(idx) and floor(idx + 1) on idx = base + S k (batchcorrmanifold.cu:1797-1799).
+// For k = 0 and S / 2 = 2^m an index one fp64 step below 2^m has idx + 1 rounding UP to 2^m + 1: the neighbours are two apart and
+// both weights ~1, so the pair contributes c[n+1] + c[n-1] instead of ~c[n].  Because the reference's rxTime - pr / C rounds at
+// 1.4e-4 samples, every grid point within that distance of the centre lag collapses onto the same fp64 value.  This pass finds
+// those points (cheap fp64 prefilter on the first channel, then the reference's own expression), evaluates their scores exactly
+// as :1760-1816 do, patches the score array and re-derives the arg-max from it.
+#pragma clang fp contract(off)
+static bool ref_pair_index(const dpe_bcm_window &win, const dpe_chan_end &ch, const double *g, double fs, int S, int k,
+                           double *idxOut, double *fiOut, double *ciOut)
+{
+    using namespace dpe;
+    const double *R = win.enu2ecef, *c = win.xCurrkk1, *s = ch.satState;
+    const double px = R[0] * g[0] + R[1] * g[1] + R[2] * g[2] + c[0];        // :1760-1763
+    const double py = R[3] * g[0] + R[4] * g[1] + R[5] * g[2] + c[1];
+    const double pz = R[6] * g[0] + R[7] * g[1] + R[8] * g[2] + c[2];
+    const double pdt = g[3] + c[3];
+    const double lx = s[0] - px, ly = s[1] - py, lz = s[2] - pz;            // :1779-1781
+    const double range = std::sqrt(lx * lx + ly * ly + lz * lz);            // :1782
+    const double pr = range - kC * s[3] + pdt;                              // :1783
+    const double txT = win.rxTime - pr / kC;                                // :1784
+    const double cfd = txT - ch.cpRefTOW - ((ch.cpElapsedEnd - ch.cpRef) * kTCA);
+    const double rcbc = cfd * kFCA;                                         // :1786
+    const double rc0 = rcbc - ch.codePhaseEnd;                              // :1790
+    const double base = (fs / ch.codeFrequency) * (-rc0) + S / 2.0;         // :1791
+    if (!(base < S && base > 0)) return false;                              // :1795
+    const double idx = base + ((double)S * k);                              // :1797
+    *idxOut = idx;
+    *fiOut = std::floor(idx);                                               // :1798
+    *ciOut = std::floor(idx + 1);                                           // :1799
+    return true;
+}
+
+static int ref_pair_fixup(dpe_bcm *h, const float *codeBank_dev, int nWindows, int nChan, const dpe_chan_end *chan_host,
+                          unsigned long long *keys_d, hipStream_t stream)
+{
+    using namespace dpe;
+    const int S = h->cfg.samplesPerWindow, L = h->cfg.lagHalfWidth, nLag = 2 * L + 1;
+    const int maxK = h->cfg.maxChannels, W = h->cfg.maxWindows;
+    const long long G = h->cfg.posGridSize;
+    const double fs = h->cfg.samplingFrequency;
+    DPE_CHECK_HIP(hipMemcpyAsync(h->refBank_h, codeBank_dev, sizeof(float2) * (size_t)nWindows * maxK * nLag, hipMemcpyDeviceToHost, stream));
+    DPE_CHECK_HIP(hipStreamSynchronize(stream));
+    h->refPatched = 0;
+    h->refWsum.assign((size_t)W * 5, 0.0);
+    struct Patch { int w; long long i; float sc; };
+    std::vector<Patch> patches;
+    for (int w = 0; w < nWindows; ++w) {
+        const BcmSvDev &p0 = h->sv_h[(size_t)(0 * W + w) * maxK + 0];          // first channel, position manifold
+        const dpe_bcm_window &win = h->win_h[w];
+        for (long long i = 0; i < G; ++i) {
+            const double *g = h->posGrid_h.data() + 4 * i;
+            // prefilter: index of the first channel within 5e-4 samples of the centre lag (bank entry L)
+            const double a = (double)p0.ue * g[0] + (double)p0.un * g[1] + (double)p0.uu * g[2];
+            const double q = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+            const double idx0 = (double)p0.idx0 + (double)p0.g * (g[3] - a + (q - a * a) * (double)p0.h);
+            if (std::fabs(idx0 - (double)L) > 5e-4) continue;
+            double idx, fi_, ci_;
+            if (!ref_pair_index(win, chan_host[(size_t)w * nChan], g, fs, S, 0, &idx, &fi_, &ci_)) continue;
+            if (ci_ - fi_ != 2.0) continue;                                   // the ordinary pair: the scan's value stands
+            double score = 0.0;
+            for (int k = 0; k < nChan; ++k) {
+                if (!ref_pair_index(win, chan_host[(size_t)w * nChan + k], g, fs, S, k, &idx, &fi_, &ci_)) continue;
+                const long long fin = (long long)fi_ - (long long)S * k - (S / 2 - L);
+                const long long cin = (long long)ci_ - (long long)S * k - (S / 2 - L);
+                if (fin < 0 || cin < 0 || fin >= nLag || cin >= nLag) continue;
+                const float2 *row = h->refBank_h + ((size_t)w * maxK + k) * nLag;
+                const double wc = idx - fi_, wf = ci_ - idx;                 // :1810-1811
+                const double vr = (double)row[cin].x * wc + (double)row[fin].x * wf;
+                const double vi = (double)row[cin].y * wc + (double)row[fin].y * wf;
+                score += std::pow(std::hypot(vr, vi), (double)h->cfg.lPower); // :1816
+            }
+            patches.push_back({w, i, (float)score});
+        }
+    }
+    h->refPatched = (long long)patches.size();
+    if (patches.empty()) return 0;
+    DPE_REQUIRE(patches.size() <= 65536, "[BatchCorrManifold] Update: referencePair: %zu points to patch (limit 65536)", patches.size());
+    for (size_t n = 0; n < patches.size(); ++n) {
+        const Patch &pt = patches[n];
+        float *dst = h->posScores_d + (size_t)pt.w * G + pt.i;
+        float old = 0.f;
+        if (h->cfg.weightedMean) DPE_CHECK_HIP(hipMemcpy(&old, dst, sizeof(float), hipMemcpyDeviceToHost));
+        h->refPatch_h[n] = pt.sc;
+        DPE_CHECK_HIP(hipMemcpyAsync(dst, h->refPatch_h + n, sizeof(float), hipMemcpyHostToDevice, stream));
+        if (h->cfg.weightedMean) {
+            const double *g = h->posGrid_h.data() + 4 * pt.i;
+            const double d = (double)pt.sc - (double)old;
+            double *c = h->refWsum.data() + (size_t)pt.w * 5;
+            c[0] += d; c[1] += d * g[0]; c[2] += d * g[1]; c[3] += d * g[2]; c[4] += d * g[3];
+        }
+    }
+    hipLaunchKernelGGL(bcm_zero_pos_keys_kernel, dim3((nWindows + 63) / 64), dim3(64), 0, stream, keys_d, nWindows);
+    const unsigned gx = (unsigned)((G + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(bcm_rekey_kernel, dim3(gx > 512 ? 512 : gx, nWindows), dim3(256), 0, stream, h->posScores_d, G,
+                       (long long)h->cfg.posGridIndexOffset, keys_d);
+    DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, keys_d, sizeof(unsigned long long) * 2 * (size_t)nWindows, hipMemcpyDeviceToHost, stream));
+    DPE_CHECK_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
 extern "C" {
 
 int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
@@ -499,6 +634,15 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     dpe_bcm *h = new dpe_bcm();
     h->cfg = *cfg;
     h->cfg.posGrid = h->cfg.velGrid = nullptr;
+    {
+        const int half = cfg->samplesPerWindow / 2;
+        h->refPair = cfg->referencePair != 0 && (half & (half - 1)) == 0;   // only then can floor(idx + 1) - floor(idx) be 2
+        if (cfg->referencePair && !cfg->writeScores) {
+            set_error("[BatchCorrManifold] create: referencePair needs writeScores (the arg-max is re-derived from the patched scores)");
+            delete h;
+            return -1;
+        }
+    }
     h->posExtent = posExt * 1.000001 + maxR2 / 2.0e7 + 1e-3;   // + second-order term bound (range > 2e7 m) + fp32 slack
     h->velExtent = velExt * 1.000001 + 1e-6;
     const size_t W = cfg->maxWindows, K = cfg->maxChannels;
@@ -527,6 +671,13 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, false, true>(); allow_big_lds<1, false, true>(); allow_big_lds<2, false, true>();
     allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
+    if (h->refPair &&
+        (hipHostMalloc((void **)&h->refBank_h, W * K * (size_t)(2 * cfg->lagHalfWidth + 1) * sizeof(float2), hipHostMallocDefault) != hipSuccess ||
+         hipHostMalloc((void **)&h->refPatch_h, 65536 * sizeof(float), hipHostMallocDefault) != hipSuccess)) {
+        set_error("[BatchCorrManifold] create: host allocation failed");
+        dpe_bcm_destroy(h);
+        return -1;
+    }
     h->oob_h = h->keys_h + 2 * W;
     for (size_t i = 0; i < 4 * W + 8; ++i) h->keys_h[i] = 0ull;
     h->pollAllowed = getenv("DPE_BCM_NO_POLL") == nullptr;
@@ -556,6 +707,8 @@ int dpe_bcm_destroy(dpe_bcm *h)
     for (void *b : bufs) (void)hipFree(b);
     if (h->svBase_h) (void)hipHostFree(h->svBase_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
+    if (h->refBank_h) (void)hipHostFree(h->refBank_h);
+    if (h->refPatch_h) (void)hipHostFree(h->refPatch_h);
     for (hipEvent_t e : h->stagingFree)
         if (e) (void)hipEventDestroy(e);
     h->graphs.clear();
@@ -638,7 +791,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     unsigned long long *keys = h->keys_d + (size_t)use * 4 * W, *oob = keys + 2 * W;
     unsigned long long *other = h->keys_d + (size_t)(use ^ 1) * 4 * W;
     GraphCache::Guard graphGuard{h->graphs, stream};
-    if (h->graphs.enabled && !h->prof.enabled) {
+    if (h->graphs.enabled && !h->prof.enabled && !h->refPair) {
         const int rc = h->graphs.begin({codeBank_dev, carrBank_dev, 0, nWindows, nChan,
                                         (posInside ? 1 : 0) | (velInside ? 2 : 0) | (use << 2) | (h->slot << 8), stream}, stream);
         DPE_REQUIRE(rc >= 0, "[BatchCorrManifold] Update: hipGraph capture/replay failed");
@@ -690,6 +843,10 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     if (captured) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     DPE_CHECK_HIP(hipGetLastError());
     h->cur = use;
+    if (h->refPair) {
+        h->pollable = false;
+        if (ref_pair_fixup(h, codeBank_dev, nWindows, nChan, chan_host, keys, stream)) return -1;
+    }
     return 0;
 }
 
@@ -752,6 +909,8 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
                 const double *base = ws.data() + slot * h->wsumHalf + (size_t)w * h->lastSplit[slot] * 5;
                 for (unsigned b = 0; b < h->lastSplit[slot]; ++b)
                     for (int j = 0; j < 5; ++j) m[slot][j] += base[(size_t)b * 5 + j];
+                if (slot == 0 && h->refPair && !h->refWsum.empty())
+                    for (int j = 0; j < 5; ++j) m[0][j] += h->refWsum[(size_t)w * 5 + j];
             }
             for (int j = 0; j < 5; ++j) r.weightedSums[slot][j] = m[slot][j];
         }

@@ -53,7 +53,7 @@ class BcmConfig(C.Structure):
                 ("posGrid", C.POINTER(C.c_double)), ("velGrid", C.POINTER(C.c_double)),
                 ("posGridSize", C.c_int64), ("velGridSize", C.c_int64),
                 ("posGridIndexOffset", C.c_int64), ("velGridIndexOffset", C.c_int64),
-                ("writeScores", C.c_int32), ("weightedMean", C.c_int32)]
+                ("writeScores", C.c_int32), ("weightedMean", C.c_int32), ("referencePair", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BcmWindow(C.Structure):
@@ -311,7 +311,7 @@ class BatchCorrManifold:
 
     def __init__(self, SamplingFrequency, samples_per_window, NumFFTPoints, pos_grid, vel_grid, LPower=1,
                  lag_half_width=8, bin_half_width=48, max_windows=1, max_channels=8, write_scores=True,
-                 pos_index_offset=0, vel_index_offset=0, weighted_mean=False):
+                 pos_index_offset=0, vel_index_offset=0, weighted_mean=False, reference_pair=False):
         self.fs, self.S, self.C = float(SamplingFrequency), int(samples_per_window), int(NumFFTPoints)
         self.pos_grid = np.ascontiguousarray(pos_grid, dtype=np.float64)
         self.vel_grid = np.ascontiguousarray(vel_grid, dtype=np.float64)
@@ -319,6 +319,7 @@ class BatchCorrManifold:
         self.max_windows, self.max_channels = int(max_windows), int(max_channels)
         self.write_scores = bool(write_scores)
         self.weighted_mean = bool(weighted_mean)
+        self.reference_pair = bool(reference_pair)
         self.pos_off, self.vel_off = int(pos_index_offset), int(vel_index_offset)
         self._h = C.c_void_p(None)
         self.Started = False
@@ -330,7 +331,7 @@ class BatchCorrManifold:
                         self.pos_grid.ctypes.data_as(C.POINTER(C.c_double)),
                         self.vel_grid.ctypes.data_as(C.POINTER(C.c_double)),
                         self.pos_grid.shape[0], self.vel_grid.shape[0], self.pos_off, self.vel_off,
-                        1 if self.write_scores else 0, 1 if self.weighted_mean else 0)
+                        1 if self.write_scores else 0, 1 if self.weighted_mean else 0, 1 if self.reference_pair else 0, 0)
         _check(lib().dpe_bcm_create(C.byref(cfg), C.byref(self._h)))
         self.PosScores = self.VelScores = None
         if self.write_scores:

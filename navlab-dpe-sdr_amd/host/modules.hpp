@@ -374,6 +374,7 @@ class BatchCorrManifold : public Module {
         InsertParam("LoadPosGrid", &loadPosGrid, BOOL_t, sizeof(bool), sizeof(bool));
         InsertParam("LoadPosGridFilename", loadPosGridFilename, CHAR_t, sizeof(loadPosGridFilename), 0);
         InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
+        InsertParam("ReferencePair", &referencePair, BOOL_t, sizeof(bool), sizeof(bool));   // dpe_bcm_config.referencePair
         ConfigOutput(0, "zVal", DOUBLE_t, STATE, HOST, 8, zVal, 0);
         ConfigOutput(1, "RVal", DOUBLE_t, COVARIANCE, HOST, 64, RVal, 0);
         ConfigOutput(2, "TimeGrid", DOUBLE_t, VALUE, HOST, VECTORLENGTH_ANY, nullptr, 0);
@@ -402,6 +403,7 @@ class BatchCorrManifold : public Module {
         cfg.posGrid = posGrid.data(); cfg.velGrid = velGrid.data();
         cfg.posGridSize = (int64_t)posGrid.size() / 4; cfg.velGridSize = (int64_t)velGrid.size() / 4;
         cfg.writeScores = 1;
+        cfg.referencePair = referencePair ? 1 : 0;
         if (dpe_bcm_create(&cfg, &h)) return -1;
         dpe_bcm_set_graph(h, useGraph ? 1 : 0);
         const float *ps, *vs;
@@ -458,6 +460,7 @@ class BatchCorrManifold : public Module {
     bool Started = false, loadPosGrid = false;
     int posDim = 25, velDim = 25, gridType = 0, LPower = 1;
     bool useGraph = false;
+    bool referencePair = false;   // reproduce the reference's floor(idx) / floor(idx + 1) pair where it double-counts (dpe_hip.h)
     float spacing = 1.0f;
     char gridLog[512] = "", loadPosGridFilename[512] = "";
     std::vector<double> posGrid, velGrid, timeGrid;

@@ -111,7 +111,7 @@ def pack_gpu_inputs(case):
     return iq, cs, ce, bw
 
 
-def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True, repeats=1):
+def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True, repeats=1, reference_pair=False):
     import torch
     iq, cs, ce, bw = pack_gpu_inputs(case)
     W, K = cs.shape
@@ -122,7 +122,7 @@ def run_gpu(case, L, B, lpower=1, write_scores=True, weighted_mean=True, repeats
     bcs.Start()
     bcm = dpe.BatchCorrManifold(case["fs"], case["S"], bcs.NumFFTPoints, case["pos"], case["vel"], LPower=lpower,
                                 lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K,
-                                write_scores=write_scores, weighted_mean=weighted_mean)
+                                write_scores=write_scores, weighted_mean=weighted_mean, reference_pair=reference_pair)
     bcm.Start()
     for _ in range(repeats):          # same handles, back-to-back Updates (staging ring, alternating key sets)
         bcs.Update(iq_d, cs)

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     e = dpe.engine
     assert C.sizeof(e.BcsConfig) == 32 and C.sizeof(e.ChanStart) == 48
     assert C.sizeof(e.BcmWindow) == 152 and C.sizeof(e.ChanEnd) == 104
-    assert C.sizeof(e.BcmResult) == 248 and C.sizeof(e.BcmConfig) == 96
+    assert C.sizeof(e.BcmResult) == 248 and C.sizeof(e.BcmConfig) == 104
 
 
 def test_no_cpu_fallback(built):

@@ -722,6 +722,10 @@ def test_bench_configurations_against_the_oracle(oracle, name, W, probe):
         sv, _ = o.bcm_vel(e["satState"], rf, C // 2 - B, bw[w]["xCurrkk1"], vel[idx], bw[w]["enu2ecef"],
                           e["carrierFrequency"], float(bw[w]["rxTime"]), fs, C, 1, 1)
         assert np.abs(ps[w][idx] - sp).max() < TOL * sp.max() and np.abs(vs[w][idx] - sv).max() < TOL * sv.max()
+        # ... and against the FAITHFUL fp64 evaluation (the reference's own rxTime - pr/C rounding, helpers.POS_REF_NOISE)
+        spf, _ = o.bcm_pos(e["satState"], rc, S // 2 - L, bw[w]["xCurrkk1"], pos[idx], bw[w]["enu2ecef"], e["codeFrequency"],
+                           e["cpRefTOW"], e["cpElapsedEnd"], e["cpRef"], e["codePhaseEnd"], float(bw[w]["rxTime"]), fs, S, 1)
+        assert np.abs(ps[w][idx] - spf).max() < helpers.POS_REF_NOISE * spf.max()
 
 
 def test_config_m_one_gpu_and_a_shard(oracle):
@@ -771,3 +775,34 @@ def test_config_m_one_gpu_and_a_shard(oracle):
         assert np.array_equal(ps3[w], ps[w][b:e_]) and np.array_equal(vs3[w], vs[w][b:e_])
         assert res3[w]["posIndex"] == b + int(np.argmax(ps[w][b:e_])) and res3[w]["velIndex"] == b + int(np.argmax(vs[w][b:e_]))
     bcs.Stop()
+
+
+@pytest.mark.parametrize("S,W", [(8192, 3), (16384, 6)])
+def test_reference_pair_mode_reproduces_the_double_counting_branch(S, W):
+    """dpe_bcm_config.referencePair: with S / 2 a power of two the reference's floor(idx) / floor(idx + 1) pair
+    (batchcorrmanifold.cu:1798-1812) double-counts at the grid points whose first-channel index collapses onto the value one
+    fp64 step below 2^m (the zero-offset centre of a closed loop and its neighbours inside the reference's 1.4e-4-sample
+    index noise).  In this mode the scores there equal the FAITHFUL oracle's (no point set aside) and the arg-max is the
+    faithful one; by default the continuous interpolation is evaluated and those points differ by ~3 %."""
+    case = helpers.make_case(seed=1, S=S, K=6, G=625, amp=200.0, W=W, grid="uniform")
+    ref = helpers.run_oracle(case, 4, 12)
+    quirky = [w for w in range(W) if len(ref["pos_quirk"][w])]
+    assert quirky, "the case must exercise the branch"
+    out = helpers.run_gpu(case, 4, 12, reference_pair=True)
+    plain = helpers.run_gpu(case, 4, 12)
+    for w in range(W):
+        r, g = ref["pos"][w], out["pos"][w]
+        assert np.abs(g - r).max() < helpers.POS_REF_NOISE * r.max()           # every point, none excluded
+        q = ref["pos_quirk"][w]
+        if len(q):
+            assert np.abs(g[q] - r[q]).max() < 5e-6 * r.max()                   # patched points: the reference's own expression
+            assert np.abs(plain["pos"][w][q] - r[q]).max() > 1e-3 * r.max()     # ... which the default mode does not follow
+        assert out["res"][w]["posIndex"] == ref["res"][w]["posIndex"]
+        assert out["res"][w]["posScore"] == g.max()
+        assert np.abs(out["res"][w]["zVal"] - ref["res"][w]["zVal"]).max() < 1e-6
+        assert np.abs(out["vel"][w] - ref["vel"][w]).max() < TOL * ref["vel"][w].max()
+    # S / 2 not a power of two: the mode changes nothing
+    case2 = helpers.make_case(seed=2, S=12500, K=4, G=625, amp=200.0, W=2, grid="uniform")
+    a, b = helpers.run_gpu(case2, 4, 20, reference_pair=True), helpers.run_gpu(case2, 4, 20)
+    for w in range(2):
+        assert np.array_equal(a["pos"][w], b["pos"][w]) and a["res"][w]["posIndex"] == b["res"][w]["posIndex"]
