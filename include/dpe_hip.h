@@ -29,6 +29,7 @@ extern "C" {
  * DPE_BCS_NO_WIDE=1 (no boundary-difference kernel for +-32-lag windows), DPE_BCS_NO_FUSE=1 (single windows run the
  * separate DC-sum kernel), DPE_BCM_NO_POLL=1 (dpe_bcm_results always waits for the stream). */
 #define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
+#define DPE_MAX_LAG_HALF_WIDTH 292  /* widest code-lag bank of the windowed stage-1 kernels: +-32 and four 65-lag chunks per side */
 #define DPE_ABI_VERSION 1
 
 typedef void *dpe_stream_t;        /* hipStream_t (reference: cudaStream_t* flow stream, module.h:23) */

@@ -1011,7 +1011,8 @@ static int sum_blocks(int S, int nWindows)
 }
 
 // widest supported lag window: the centre chunk (+-32) plus 4 chunks of 65 lags on each side
-static constexpr int kMaxLagHalfWidth = 32 + 4 * 65;
+static constexpr int kMaxLagHalfWidth = DPE_MAX_LAG_HALF_WIDTH;
+static_assert(kMaxLagHalfWidth == 32 + 4 * 65, "centre chunk plus four 65-lag chunks per side");
 
 static long long next_pow2(long long x)
 {

@@ -97,7 +97,10 @@ int main(int argc, char **argv)
         long long nfft = 8;
         while (nfft / 8 < (long long)(fs * T + 0.5)) nfft <<= 1;
         dsp::utils::bank_half_widths(pg, vg, fs, nfft, &L, &B);
-        if (L > 32) { std::fprintf(stderr, "[DPEFlow] grid needs +-%d code lags (> 32)\n", L); return 1; }
+        if (L > DPE_MAX_LAG_HALF_WIDTH) {
+            std::fprintf(stderr, "[DPEFlow] grid needs +-%d code lags (> %d)\n", L, DPE_MAX_LAG_HALF_WIDTH);
+            return 1;
+        }
     }
 
     dsp::Flow flow;                                             // dpeflow.cpp:55-62

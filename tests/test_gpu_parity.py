@@ -237,6 +237,49 @@ def test_cpp_flow_matches_python_closed_loop(tmp_path):
     assert np.abs(rows2[:, 4:7]).max() < 1.5                        # velocity estimate of a static receiver
 
 
+@pytest.mark.parametrize("half,expect_wide", [((4.0, 4.0, 4.0, 4.0), False), ((1500.0, 1500.0, 1500.0, 1500.0), True)])
+def test_cpp_flow_with_a_loaded_rngrid_csv(tmp_path, half, expect_wide):
+    """LoadPosGrid / LoadPosGridFilename (batchcorrmanifold.cu:2422-2448; dpeflow.cpp:133): a 9^4-row rngrid-format CSV
+    replaces the built position grid.  dpe_flow --load-grid == the Python closed loop on the same grid, and a file with
+    the wrong row count is refused (the reference would overrun its buffer).  The second case spreads the grid over
+    +-1500 m: +-37 code lags at 2.5 Msps, beyond the single 65-lag chunk."""
+    import os
+    import subprocess
+    W, fs, S, K = 4, 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=6, amp=200.0)
+    dat = str(tmp_path / "synthetic_2500kHz.dat")
+    iq.tofile(dat)
+    ho_path = str(tmp_path / "handoff.csv")
+    with open(dpe.workload.HANDOFF_CSV) as f, open(ho_path, "w") as g:
+        for line in f:
+            g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
+    rg = dpe.synth.rand_grid(77, 9 ** 4, half=half)
+    rg[0] = 0.0                                                    # keep the truth on the grid
+    csv = str(tmp_path / "rngrid_test.csv")
+    dpe.synth.write_grid_csv(csv, rg)
+    out = str(tmp_path / "X.csv")
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
+    r = subprocess.run([exe, "--samples", dat, "--handoff", ho_path, "--out", out, "--iters", str(W), "--grid-dim", "9",
+                        "--spacing", "1.0", "--load-grid", csv], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = np.loadtxt(out, delimiter=",")
+    assert rows.shape == (W, 8)
+    ho = dpe.handoff.read_handoff(ho_path)
+    g9 = dpe.synth.uniform_grid(9, 1.0)                            # the built grid: velocity manifold and TimeGrid
+    L, _ = dpe.pipeline.bank_half_widths(rg, g9, fs, dpe.engine.carr_fft_len(S))
+    assert (L > 32) == expect_wide and ("L=%d," % L) in r.stderr
+    fixes, res = dpe.pipeline.run_closed_loop(iq, ho, fs, rg, g9, time_grid=np.unique(g9[:, 3]))
+    assert np.abs(rows - fixes).max() < 1e-6                       # %f rows vs doubles: the same grid points
+    assert all(r_["posOutOfWindow"] == 0 for r_ in res)
+    # the loaded grid was really used: the fixes are points of the CSV grid about the fed-back centre
+    assert np.abs(fixes[:, :3] - ho["X_ECEF"][:3]).max() < (1.0 if not expect_wide else 250.0)
+    short = str(tmp_path / "short.csv")
+    dpe.synth.write_grid_csv(short, rg[:-1])
+    r2 = subprocess.run([exe, "--samples", dat, "--handoff", ho_path, "--out", out, "--iters", "1", "--grid-dim", "9",
+                         "--load-grid", short], capture_output=True, text=True)
+    assert r2.returncode == 1 and "needs 9^4 rows" in r2.stderr
+
+
 @pytest.mark.parametrize("kw,L,B", [
     (dict(seed=31, S=12502, K=3, G=1, amp=200.0), 4, 24),        # one grid point; S not a multiple of 4 (scalar loads)
     (dict(seed=32, S=12500, K=2, G=1023, amp=200.0), 4, 24),     # one short of a 1024-point tile
