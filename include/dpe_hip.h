@@ -209,9 +209,12 @@ int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velSco
  * (score bits << 32) | (0xFFFFFFFF - globalIndex): an integer max over shards reproduces
  * the "first maximum" tie-break of thrust::max_element (:2589-2590).  For RCCL all-reduce. */
 int dpe_bcm_keys(dpe_bcm *h, const uint64_t **keys_dev);
-/* Measurement from externally reduced keys (multi-GPU): host keys [nWindows][2]. */
+/* Measurement from externally reduced keys (multi-GPU): host keys [nWindows][2]; the GLOBAL grids with their sizes (a
+ * decoded index outside them, or a key of 0 = "no valid score" -- every score NaN, or a key set that was never reduced --
+ * is an error, not a wild read). */
 int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWindows,
-                              const double *posGridGlobal, const double *velGridGlobal,
+                              const double *posGridGlobal, int64_t posGridGlobalSize,
+                              const double *velGridGlobal, int64_t velGridGlobalSize,
                               dpe_bcm_result *results);
 
 /* ------------------------------------------------------------------ cuChanMgr ------ */

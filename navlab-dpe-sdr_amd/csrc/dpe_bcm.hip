@@ -285,7 +285,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
         }
         const unsigned int n = sOob[0] + sOob[1] + sOob[2] + sOob[3];
         if (n) seen += atomicAdd(&oob[(size_t)w * keyStride + keySlot], (unsigned long long)n);
-        asm volatile("" ::"v"(seen));   // keep the returns (and the s_waitcnt they imply) alive
+        asm volatile("" ::"v"(seen) : "memory");   // keep the returns (and the s_waitcnt they imply) alive, and the ticket below them
     }
 }
 
@@ -841,7 +841,14 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     const bool captured = h->graphs.capturing;
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrManifold] Update: hipGraph instantiate/launch failed");
     if (captured) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
-    DPE_CHECK_HIP(hipGetLastError());
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            h->pollable = false;   // nothing will ever write the sequence word of this Update
+            dpe::set_error("%s:%d: launch failed -> %s", __FILE__, __LINE__, hipGetErrorString(le));
+            return -1;
+        }
+    }
     h->cur = use;
     if (h->refPair) {
         h->pollable = false;
@@ -886,9 +893,9 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
     // closed-loop window); anything unexpected falls back to the stream wait.
     bool arrived = false;
     if (h->pollable) {
-        const volatile unsigned long long *seqWord = h->oob_h + 2;
-        for (int spin = 0; spin < 200000 && !arrived; ++spin) arrived = (*seqWord == h->seq);
-        std::atomic_thread_fence(std::memory_order_acquire);
+        const unsigned long long *seqWord = h->oob_h + 2;
+        for (int spin = 0; spin < 200000 && !arrived; ++spin)
+            arrived = (__atomic_load_n(seqWord, __ATOMIC_ACQUIRE) == h->seq);   // acquire: the results are read after it
     }
     if (!arrived) DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int W = h->lastW;
@@ -964,14 +971,20 @@ int dpe_bcm_keys(dpe_bcm *h, const uint64_t **keys_dev)
 }
 
 int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWindows, const double *posGridGlobal,
-                              const double *velGridGlobal, dpe_bcm_result *results)
+                              int64_t posGridGlobalSize, const double *velGridGlobal, int64_t velGridGlobalSize,
+                              dpe_bcm_result *results)
 {
     DPE_REQUIRE(h && keys_host && posGridGlobal && velGridGlobal && results, "[BatchCorrManifold] results_from_keys: null argument");
     DPE_REQUIRE(nWindows >= 1 && nWindows <= h->lastW, "[BatchCorrManifold] results_from_keys: bad nWindows");
     for (int w = 0; w < nWindows; ++w) {
         dpe_bcm_result &r = results[w];
+        DPE_REQUIRE(keys_host[2 * w] != 0 && keys_host[2 * w + 1] != 0,
+                    "[BatchCorrManifold] results_from_keys: window %d has no valid score (key 0)", w);
         decode_key(keys_host[2 * w], &r.posScore, &r.posIndex);
         decode_key(keys_host[2 * w + 1], &r.velScore, &r.velIndex);
+        DPE_REQUIRE(r.posIndex >= 0 && r.posIndex < posGridGlobalSize && r.velIndex >= 0 && r.velIndex < velGridGlobalSize,
+                    "[BatchCorrManifold] results_from_keys: window %d: arg-max index (%lld, %lld) outside the global grids (%lld, %lld)",
+                    w, (long long)r.posIndex, (long long)r.velIndex, (long long)posGridGlobalSize, (long long)velGridGlobalSize);
         r.posOutOfWindow = r.velOutOfWindow = -1;
         for (int j = 0; j < 8; ++j) r.zValMean[j] = 0.0;   // needs the all-reduced weightedSums; see sharding.py
         for (int j = 0; j < 10; ++j) (&r.weightedSums[0][0])[j] = 0.0;

@@ -379,8 +379,8 @@ class BatchCorrManifold:
         vg = np.ascontiguousarray(vel_grid_global, dtype=np.float64)
         res = (BcmResult * W)()
         _check(lib().dpe_bcm_results_from_keys(self._h, keys_host.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(W),
-                                               pg.ctypes.data_as(C.POINTER(C.c_double)),
-                                               vg.ctypes.data_as(C.POINTER(C.c_double)), res))
+                                               pg.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(pg.shape[0]),
+                                               vg.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(vg.shape[0]), res))
         return [dict(zVal=np.array(r.zVal), posIndex=r.posIndex, velIndex=r.velIndex, posScore=r.posScore,
                      velScore=r.velScore) for r in res]
 

@@ -189,9 +189,30 @@ def test_sharded_grid_equals_full_grid():
     for w in range(2):
         assert rm[w]["posIndex"] == rf[w]["posIndex"] and rm[w]["velIndex"] == rf[w]["velIndex"]
         assert np.array_equal(rm[w]["zVal"], rf[w]["zVal"])
+    # a key of 0 (no valid score / a key set that was never reduced) or an index beyond the global grids is an error
+    bad = merged.copy()
+    bad[1, 0] = 0
+    with pytest.raises(dpe.DpeError, match="no valid score"):
+        m0.results_from_keys(bad, case["pos"], case["vel"])
+    with pytest.raises(dpe.DpeError, match="outside the global grids"):
+        m0.results_from_keys(merged, case["pos"][:10], case["vel"])
     for m in (full, m0, m1):
         m.Stop()
     bcs.Stop()
+
+
+def test_closed_loop_poll_and_stream_wait_modes_agree(monkeypatch):
+    """dpe_bcm_results either polls the sequence word the scan's last block writes behind the results (default for single
+    windows) or waits for the stream (DPE_BCM_NO_POLL=1, read at create): same fixes, window by window."""
+    W, fs, S, K = 12, 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=8, amp=200.0)
+    ho = dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV)
+    g9 = dpe.synth.uniform_grid(9, 1.0)
+    polled, _ = dpe.pipeline.run_closed_loop(iq, ho, fs, g9, g9, time_grid=np.unique(g9[:, 3]))
+    monkeypatch.setenv("DPE_BCM_NO_POLL", "1")
+    waited, _ = dpe.pipeline.run_closed_loop(iq, ho, fs, g9, g9, time_grid=np.unique(g9[:, 3]))
+    assert np.array_equal(polled, waited)
+    assert np.abs(polled[:, :3] - ho["X_ECEF"][:3]).max() < 1.0
 
 
 def test_cpp_flow_matches_python_closed_loop(tmp_path):
