@@ -125,7 +125,8 @@ typedef struct dpe_bcm_config {
     int32_t lagHalfWidth;       /* must equal the L of the banks passed to dpe_bcm_update */
     int32_t binHalfWidth;       /* must equal the B of the banks.  The scan keeps all maxChannels banks in LDS:
                                  * maxChannels * ((2 max(L,B) + 1) * 16 + 32) <= 150 KB, i.e. max(L,B) <= 129 at 37
-                                 * channels, 599 at 8 (create refuses more) */
+                                 * channels, 599 at 8; wider ones go through a slower variant with 12-byte entries
+                                 * (max(L,B) <= 174 at 37 channels); create refuses more */
     int32_t lPower;             /* LPower param (batchcorrmanifold.cu:2290) */
     int32_t maxWindows;
     int32_t maxChannels;

@@ -58,7 +58,9 @@ struct ScanSide {
     int nEnt, split;          // bank entries per SV; blocks along x that work on this manifold
 };
 
-template <int LP, bool SECOND, bool CLAMP, bool WMEAN>
+// COMPACT: 12-byte LDS entries {A, B, C} instead of 16 (three dword reads per pair instead of b64 + b32): the layout for
+// bank sets that do not fit the LDS otherwise (37 channels with +-130 .. +-172 entries) -- slower, always with the clamps.
+template <int LP, bool SECOND, bool CLAMP, bool WMEAN, bool COMPACT = false>
 __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, int maxK, int lpower,
                                           unsigned long long *__restrict__ keys, unsigned long long *__restrict__ oob,
                                           int keyStride, int keySlot)
@@ -77,6 +79,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
     // neighbouring entries (the index moves by << 1 entry per grid step), so the 16-byte stride is
     // conflict-free as long as a wave spans < 16 entries.
     float4 *sE = reinterpret_cast<float4 *>(smem);                           // [K][nEnt]
+    float *sF = reinterpret_cast<float *>(smem);                             // COMPACT: [K][nEnt][3]
     __shared__ unsigned long long sKey[4];
     __shared__ unsigned int sOob[4];
     __shared__ double sW[4][5];
@@ -99,9 +102,12 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
         if (j + 1 < nEnt) {
             const float2 c0 = bw[(size_t)k * nEnt + j], c1 = bw[(size_t)k * nEnt + j + 1];
             const float dr = c1.x - c0.x, di = c1.y - c0.y;
-            sE[i] = make_float4(c0.x * c0.x + c0.y * c0.y, 2.f * (c0.x * dr + c0.y * di), 0.f, dr * dr + di * di);
+            const float eA = c0.x * c0.x + c0.y * c0.y, eB = 2.f * (c0.x * dr + c0.y * di), eC = dr * dr + di * di;
+            if (COMPACT) { sF[3 * i] = eA; sF[3 * i + 1] = eB; sF[3 * i + 2] = eC; }
+            else sE[i] = make_float4(eA, eB, 0.f, eC);
         } else {
-            sE[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (COMPACT) { sF[3 * i] = 0.f; sF[3 * i + 1] = 0.f; sF[3 * i + 2] = 0.f; }
+            else sE[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
@@ -173,8 +179,14 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
                         e = min(e, last);
                         emax = max(emax, e);
                     }
-                    const float2 ab = *reinterpret_cast<const float2 *>(&bk[e]);
-                    const float m2 = fmaf(wgt, fmaf(wgt, bk[e].w, ab.y), ab.x);
+                    float m2;
+                    if (COMPACT) {
+                        const float *bf = sF + ((size_t)k * nEnt + e) * 3;
+                        m2 = fmaf(wgt, fmaf(wgt, bf[2], bf[1]), bf[0]);
+                    } else {
+                        const float2 ab = *reinterpret_cast<const float2 *>(&bk[e]);
+                        m2 = fmaf(wgt, fmaf(wgt, bk[e].w, ab.y), ab.x);
+                    }
                     if (LP == 1) c[j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(m2));    // raw v_sqrt_f32 (1 ulp)
                     else if (LP == 2) c[j] = m2;
                     else c[j] = powf(__builtin_amdgcn_sqrtf(__builtin_fabsf(m2)), (float)lpower);
@@ -296,7 +308,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
 //  * lets the last block to finish publish keys and out-of-window counts of all windows straight
 //    into the pinned host mirror (system-scope stores): dpe_bcm_results needs no D2H copy command.
 // `done` cycles 0 .. total-1 through atomicInc and is back at 0 when the kernel ends.
-template <int LP, bool CLAMP_P, bool CLAMP_V, bool WMEAN>
+template <int LP, bool CLAMP_P, bool CLAMP_V, bool WMEAN, bool COMPACT = false>
 __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl, ScanSide sp, ScanSide sv, int K, int maxK,
                                                        int lpower, unsigned long long *__restrict__ keys,
                                                        unsigned long long *__restrict__ oob,
@@ -310,9 +322,9 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         for (int i = threadIdx.x; i < clearN; i += 256) clearPtr[i] = 0ull;
     if (blockIdx.z == 0) {
-        if (blockIdx.x < (unsigned)sp.split) scan_body<LP, true, CLAMP_P, WMEAN>(sp, inl, K, maxK, lpower, keys, oob, 2, 0);
+        if (blockIdx.x < (unsigned)sp.split) scan_body<LP, true, CLAMP_P, WMEAN, COMPACT>(sp, inl, K, maxK, lpower, keys, oob, 2, 0);
     } else {
-        if (blockIdx.x < (unsigned)sv.split) scan_body<LP, false, CLAMP_V, WMEAN>(sv, inl, K, maxK, lpower, keys, oob, 2, 1);
+        if (blockIdx.x < (unsigned)sv.split) scan_body<LP, false, CLAMP_V, WMEAN, COMPACT>(sv, inl, K, maxK, lpower, keys, oob, 2, 1);
     }
     // ---- last block out publishes the results
     // Thread 0 issued this block's key / counter atomics and has their return values, i.e. they are
@@ -408,6 +420,7 @@ struct dpe_bcm {
     static constexpr unsigned kMaxSplit = 4096;
     size_t wsumHalf = 0;
     // referencePair mode (dpe_bcm_config): active only when S / 2 is a power of two
+    bool compact = false;                   // 12-byte LDS bank entries (the banks of all channels would not fit otherwise)
     bool refPair = false;
     float2 *refBank_h = nullptr;            // pinned copy of the code banks of the last Update
     float *refPatch_h = nullptr;            // pinned staging of patched scores
@@ -462,6 +475,13 @@ struct ScanLaunch {
     hipStream_t st;
 };
 
+template <int LP, bool WM>
+static void launch_scan_compact(const ScanLaunch &a)
+{
+    hipLaunchKernelGGL((dpe::bcm_scan_kernel<LP, true, true, WM, true>), a.grid, dim3(256), a.lds, a.st, a.pb, a.inl, a.sp, a.sv, a.K, a.maxK,
+                       a.lp, a.keys, a.oob, a.clr, a.clrN, a.done, a.hostKeys, a.hostOob, a.seq);
+}
+
 template <int LP, bool CP, bool CV, bool WM>
 static void launch_scan4(const ScanLaunch &a)
 {
@@ -480,8 +500,14 @@ static void launch_scan3(const ScanLaunch &a)
 // clampP / clampV = false only when the host has proved that every index of every (point, SV) pair of
 // that manifold stays inside the bank (then the kernel drops the range clamp and the out-of-window
 // bookkeeping); wmean selects the variant that also accumulates the weighted-mean sums
-static void launch_scan(bool clampP, bool clampV, bool wmean, const ScanLaunch &a)
+static void launch_scan(bool clampP, bool clampV, bool wmean, bool compact, const ScanLaunch &a)
 {
+    if (compact) {
+#define DPE_SCAN_C(LPV) do { if (wmean) launch_scan_compact<LPV, true>(a); else launch_scan_compact<LPV, false>(a); } while (0)
+        if (a.lp == 1) DPE_SCAN_C(1); else if (a.lp == 2) DPE_SCAN_C(2); else DPE_SCAN_C(0);
+#undef DPE_SCAN_C
+        return;
+    }
 #define DPE_SCAN_PICK(CP, CV) do { if (wmean) launch_scan3<CP, CV, true>(a); else launch_scan3<CP, CV, false>(a); } while (0)
     if (clampP) { if (clampV) DPE_SCAN_PICK(true, true); else DPE_SCAN_PICK(true, false); }
     else { if (clampV) DPE_SCAN_PICK(false, true); else DPE_SCAN_PICK(false, false); }
@@ -493,6 +519,10 @@ static void allow_big_lds()
 {
     (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, CP, CV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
     (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, CP, CV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+    if (CP && CV) {
+        (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+        (void)hipFuncSetAttribute((const void *)dpe::bcm_scan_kernel<LP, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+    }
 }
 
 // ---- referencePair mode ---------------------------------------------------------------------
@@ -613,9 +643,12 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     DPE_REQUIRE(cfg->posGridSize + cfg->posGridIndexOffset < 0xFFFFFFFFll &&
                 cfg->velGridSize + cfg->velGridIndexOffset < 0xFFFFFFFFll,
                 "[BatchCorrManifold] create: global grid index exceeds 32 bits");
-    const size_t ldsNeed = (size_t)cfg->maxChannels *
-                           ((size_t)(2 * (cfg->lagHalfWidth > cfg->binHalfWidth ? cfg->lagHalfWidth : cfg->binHalfWidth) + 1) * 16 + 32);
-    DPE_REQUIRE(ldsNeed <= 150 * 1024, "[BatchCorrManifold] create: score banks (%zu B) exceed the 160 KB LDS", ldsNeed);
+    const size_t nEntMax = (size_t)(2 * (cfg->lagHalfWidth > cfg->binHalfWidth ? cfg->lagHalfWidth : cfg->binHalfWidth) + 1);
+    const size_t ldsNeed = (size_t)cfg->maxChannels * (nEntMax * 16 + 32);
+    const bool compact = ldsNeed > 150 * 1024;   // 12-byte entries (slower scan variant) when the 16-byte ones do not fit
+    DPE_REQUIRE(!compact || (size_t)cfg->maxChannels * nEntMax * 12 <= 152 * 1024,
+                "[BatchCorrManifold] create: score banks (%zu B even as 12-byte entries) exceed the 160 KB LDS",
+                (size_t)cfg->maxChannels * nEntMax * 12);
     // validity of the range expansion (file header): |delta| must stay far below the SV range
     double maxR2 = 0, posExt = 0, velExt = 0;   // extents: max(|delta_xyz| + |delta_t|), bounds |delta_t - u.delta|
     for (int64_t i = 0; i < cfg->posGridSize; ++i) {
@@ -634,6 +667,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     dpe_bcm *h = new dpe_bcm();
     h->cfg = *cfg;
     h->cfg.posGrid = h->cfg.velGrid = nullptr;
+    h->compact = compact;
     {
         const int half = cfg->samplesPerWindow / 2;
         h->refPair = cfg->referencePair != 0 && (half & (half - 1)) == 0;   // only then can floor(idx + 1) - floor(idx) be 2
@@ -831,12 +865,12 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     //  see the finished kernel, so the stream is waited for instead)
     h->pollable = nWindows == 1 && W == 1 && !h->graphs.capturing && h->pollAllowed && !h->cfg.weightedMean;
     a.grid = dim3(h->lastSplit[0] > h->lastSplit[1] ? h->lastSplit[0] : h->lastSplit[1], nWindows, 2);
-    a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * 16;
+    a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * (h->compact ? 12 : 16);
     a.st = stream;
     // the kernel's last block writes keys and counts into the pinned host mirror: dpe_bcm_results only
     // has to synchronise
     h->prof.begin(0, stream);
-    launch_scan(!posInside, !velInside, h->cfg.weightedMean != 0, a);
+    launch_scan(!posInside, !velInside, h->cfg.weightedMean != 0, h->compact, a);
     h->prof.end(0, stream);
     const bool captured = h->graphs.capturing;
     DPE_REQUIRE(h->graphs.end(stream) == 0, "[BatchCorrManifold] Update: hipGraph instantiate/launch failed");

@@ -334,6 +334,21 @@ def test_max_channels_37():
     helpers.assert_parity(out, ref, tol=TOL)
 
 
+def test_37_channels_with_wide_banks_use_the_compact_lds_layout():
+    """37 channels x +-140 Doppler bins: 37 x 281 sixteen-byte bank entries (166 KB) do not fit the 160 KB LDS of a CU;
+    the scan then keeps 12-byte entries (slower variant, same arithmetic).  S = 50000 so that the 524288-point carrier
+    transform takes +-140 bins within the moment expansion (batchcorrmanifold.cu:1861-1963 reads any bin)."""
+    case = helpers.make_case(seed=36, S=50000, K=37, G=1500, amp=60.0)
+    out = helpers.run_gpu(case, 8, 140)
+    ref = helpers.run_oracle(case, 8, 140)
+    helpers.assert_parity(out, ref, tol=TOL)
+    # beyond the compact layout as well: refused with a message
+    with pytest.raises(dpe.DpeError, match="LDS"):
+        m = dpe.BatchCorrManifold(case["fs"], case["S"], dpe.engine.carr_fft_len(case["S"]), case["pos"], case["vel"],
+                                  lag_half_width=8, bin_half_width=180, max_channels=37)
+        m.Start()
+
+
 def test_window_stride_and_unaligned_base():
     """Windows separated by padding (stride > S) and a sample pointer that is only 4-byte aligned."""
     import torch
