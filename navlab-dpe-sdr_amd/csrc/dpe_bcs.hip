@@ -741,6 +741,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
 }  // namespace dpe
 
 #include "dpe_bcs_chip.h"   // chip-boundary form of stage 1 (high sampling rates)
+#include "dpe_bcs_fft.h"    // full-length FFT form (fallback for very wide lag / bin windows)
 
 namespace dpe {
 
@@ -974,6 +975,12 @@ struct dpe_bcs {
     bool chipAllowed = true;     // DPE_BCS_NO_CHIP=1: never the chip-boundary kernel (A/B tests)
     bool chipOK = false;         // create-time eligibility of the chip-boundary kernel (dpe_bcs_chip.h)
     int nPassChip = 0, nBlkAlloc = 0;
+    // full-length FFT fallback (dpe_bcs_fft.h): lag windows beyond DPE_MAX_LAG_HALF_WIDTH, bin windows beyond the moment
+    // expansion, or DPE_BCS_FORCE_FFT=1 at create (A/B tests)
+    bool fftMode = false, havePlans = false;
+    hipfftHandle planS3 = 0, planS2 = 0, planC = 0;   // length S: batch 3 chunk K (forward) / 2 chunk K (inverse); length C: batch chunk K
+    int fftChunkW = 1;
+    float2 *fftWork_d = nullptr;
     int chipDbg = 0;                   // DPE_BCS_CHIP_DBG: skips parts of the chip kernel (timing experiments; wrong results)
     int chipTpbForce = 0;              // DPE_BCS_CHIP_TPB at create: passes per wave of the chip kernel (experiments)
     int chipResident = 0;              // co-resident waves of the chip kernel on the whole device
@@ -1031,19 +1038,19 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     DPE_REQUIRE(cfg->samplingFrequency > 0, "[BatchCorrScores] create: bad samplingFrequency");
     DPE_REQUIRE(cfg->maxWindows >= 1 && cfg->maxChannels >= 1 && cfg->maxChannels <= DPE_MAX_CHAN,
                 "[BatchCorrScores] create: maxWindows/maxChannels out of range");
-    DPE_REQUIRE(cfg->lagHalfWidth >= 1 && cfg->lagHalfWidth <= kMaxLagHalfWidth,
-                "[BatchCorrScores] create: lagHalfWidth %d not in [1,%d]", cfg->lagHalfWidth, kMaxLagHalfWidth);
-    DPE_REQUIRE(cfg->lagHalfWidth + 32 + dpe::kSub < cfg->samplesPerWindow,
-                "[BatchCorrScores] create: lagHalfWidth %d too wide for %d samples per window", cfg->lagHalfWidth, cfg->samplesPerWindow);
+    DPE_REQUIRE(cfg->lagHalfWidth >= 1 && 2 * (long long)cfg->lagHalfWidth + 1 < cfg->samplesPerWindow,
+                "[BatchCorrScores] create: lagHalfWidth %d not in [1, S/2)", cfg->lagHalfWidth);
     DPE_REQUIRE(cfg->binHalfWidth >= 1, "[BatchCorrScores] create: binHalfWidth < 1");
+    bool fftMode = getenv("DPE_BCS_FORCE_FFT") != nullptr;   // full-length FFT form instead of the streaming kernels
+    if (cfg->lagHalfWidth > kMaxLagHalfWidth || cfg->lagHalfWidth + 32 + dpe::kSub >= cfg->samplesPerWindow) fftMode = true;
     const int S = cfg->samplesPerWindow;
     const long long C = 8 * next_pow2(S);  // batchcorrscores.cu:761
     // Taylor remainder of the moment expansion must stay below fp32 rounding (see file header)
     const double th = 6.283185307179586 * 127.5 * cfg->binHalfWidth / (double)C;
     const int nMom = (std::pow(th, 4) / 24.0 < 1e-7) ? 4 : 6;   // Taylor order of the moment expansion
-    DPE_REQUIRE(std::pow(th, 6) / 720.0 < 2e-7,
-                "[BatchCorrScores] create: binHalfWidth %d too wide for the moment expansion at C=%lld",
-                cfg->binHalfWidth, C);
+    DPE_REQUIRE(2 * (long long)cfg->binHalfWidth + 1 < C, "[BatchCorrScores] create: binHalfWidth %d not below C/2 = %lld",
+                cfg->binHalfWidth, C / 2);
+    if (!(std::pow(th, 6) / 720.0 < 2e-7)) fftMode = true;   // bin window too wide for the moment expansion at this C
     // The reference rounds the sample times to 1 ns (BCS_GenTimeIdcs :191-193).  For integer-ns sampling
     // periods (all usual SDR rates) that is a no-op and the kernels use n/fs; otherwise they read the
     // reference's own table.
@@ -1057,6 +1064,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->cfg = *cfg;
     h->C = C;
     h->nMom = nMom;
+    h->fftMode = fftMode;
     h->LH = cfg->lagHalfWidth <= 4 ? 4 : cfg->lagHalfWidth <= 8 ? 8 : cfg->lagHalfWidth <= 16 ? 16 : 32;
     h->nSub = (S + kSub - 1) / kSub;
     const int nTiles = (h->nSub + 3) / 4;
@@ -1120,6 +1128,24 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
         DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
         for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (h->fftMode) {
+            // windows per chunk: at most 2^27 complex work elements (1 GB); planes b, rX, rY of [chunk][K][S], reused as [chunk][K][C]
+            const size_t perW = K * (size_t)(3 * (size_t)S > (size_t)C ? 3 * (size_t)S : (size_t)C);
+            size_t chunk = ((size_t)1 << 27) / perW;
+            if (chunk < 1) chunk = 1;
+            if (chunk > W) chunk = W;
+            h->fftChunkW = (int)chunk;
+            h->fftWork_d = dev_alloc<float2>(chunk * perW);
+            DPE_REQUIRE(h->fftWork_d, "[BatchCorrScores] create: FFT work buffer (%zu MB) allocation failed", chunk * perW * 8 >> 20);
+            int nS[1] = {S}, nC[1] = {(int)C};
+            DPE_REQUIRE(C < (1ll << 31), "[BatchCorrScores] create: carrier transform length %lld too long for the FFT path", C);
+            const int b3 = (int)(3 * chunk * K), b2 = (int)(2 * chunk * K), b1 = (int)(chunk * K);
+            DPE_REQUIRE(hipfftPlanMany(&h->planS3, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b3) == HIPFFT_SUCCESS &&
+                        hipfftPlanMany(&h->planS2, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b2) == HIPFFT_SUCCESS &&
+                        hipfftPlanMany(&h->planC, 1, nC, nullptr, 1, (int)C, nullptr, 1, (int)C, HIPFFT_C2C, b1) == HIPFFT_SUCCESS,
+                        "[BatchCorrScores] create: hipfftPlanMany failed (S = %d, C = %lld, %d rows)", S, C, b1);
+            h->havePlans = true;
+        }
         return 0;
     };
     if (finish()) {
@@ -1144,6 +1170,8 @@ int dpe_bcs_destroy(dpe_bcs *h)
     void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
+    if (h->havePlans) { (void)hipfftDestroy(h->planS3); (void)hipfftDestroy(h->planS2); (void)hipfftDestroy(h->planC); }
+    (void)hipFree(h->fftWork_d);
     for (hipEvent_t e : h->stagingFree)
         if (e) (void)hipEventDestroy(e);
     h->graphs.clear();
@@ -1195,6 +1223,61 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         if (6.283185307179586 * std::fabs(chan_host[i].carrierFrequency) > 0.25 * chan_host[i].codeFrequency) chip = false;
     h->lastW = nWindows;
     h->lastK = nChan;
+    if (h->fftMode) {
+        // ---- full-length FFT form (dpe_bcs_fft.h): DC sum, then per chunk of windows the reference's own sequence
+        const long long C = h->C;
+        const int L = h->cfg.lagHalfWidth, B = h->cfg.binHalfWidth, maxK = h->cfg.maxChannels;
+        const int sumBlocks = sum_blocks(S, nWindows);
+        h->lastSumBlocks = sumBlocks;
+        h->lastKernel = "hipfft full-lag path (bcs_fft_*_kernel)";
+        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
+        h->prof.begin(0, stream);
+        hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples, S, h->sums_d);
+        h->prof.end(0, stream);
+        h->prof.begin(1, stream);
+        if (hipfftSetStream(h->planS3, stream) != HIPFFT_SUCCESS || hipfftSetStream(h->planS2, stream) != HIPFFT_SUCCESS ||
+            hipfftSetStream(h->planC, stream) != HIPFFT_SUCCESS) {
+            set_error("[BatchCorrScores] Update: hipfftSetStream failed");
+            return -1;
+        }
+        const int chunk = h->fftChunkW;
+        const size_t plane = (size_t)chunk * nChan * S;
+        const int gxS = S / 256 < 64 ? (S / 256 > 0 ? S / 256 : 1) : 64;
+#define DPE_FFT_EXEC(plan, ptr, dir)                                                                                   \
+    if (hipfftExecC2C(plan, (hipfftComplex *)(ptr), (hipfftComplex *)(ptr), dir) != HIPFFT_SUCCESS) {                 \
+        set_error("[BatchCorrScores] Update: hipfftExecC2C failed");                                                   \
+        return -1;                                                                                                     \
+    }
+        for (int w0 = 0; w0 < nWindows; w0 += chunk) {
+            const int nw = nWindows - w0 < chunk ? nWindows - w0 : chunk;
+            // the plans transform `chunk` windows of rows; a short last chunk carries stale (finite) rows that nobody reads
+            if (h->useTable)
+                hipLaunchKernelGGL((bcs_fft_prep_code_kernel<true>), dim3(gxS, nChan, nw), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples,
+                                   S, nChan, chunk, w0, h->chan_d, h->chipTable_d, h->tTable_d, h->fftWork_d);
+            else
+                hipLaunchKernelGGL((bcs_fft_prep_code_kernel<false>), dim3(gxS, nChan, nw), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples,
+                                   S, nChan, chunk, w0, h->chan_d, h->chipTable_d, h->tTable_d, h->fftWork_d);
+            DPE_FFT_EXEC(h->planS3, h->fftWork_d, HIPFFT_FORWARD);
+            hipLaunchKernelGGL(bcs_fft_mul_kernel, dim3(2048), dim3(256), 0, stream, h->fftWork_d, plane);
+            DPE_FFT_EXEC(h->planS2, h->fftWork_d + plane, HIPFFT_BACKWARD);
+            hipLaunchKernelGGL(bcs_fft_extract_code_kernel, dim3(nChan, nw), dim3(256), 0, stream, h->fftWork_d, plane, S, nChan, L, w0, maxK,
+                               h->chan_d, h->codeBank_d, h->info_d);
+            const int gxC = 256;
+            if (h->useTable)
+                hipLaunchKernelGGL((bcs_fft_prep_carr_kernel<true>), dim3(gxC, nChan, nw), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples,
+                                   S, C, nChan, w0, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->info_d, h->fftWork_d);
+            else
+                hipLaunchKernelGGL((bcs_fft_prep_carr_kernel<false>), dim3(gxC, nChan, nw), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples,
+                                   S, C, nChan, w0, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->info_d, h->fftWork_d);
+            DPE_FFT_EXEC(h->planC, h->fftWork_d, HIPFFT_FORWARD);
+            hipLaunchKernelGGL(bcs_fft_extract_carr_kernel, dim3(nChan, nw), dim3(256), 0, stream, h->fftWork_d, C, nChan, B, w0, maxK, h->carrBank_d);
+        }
+#undef DPE_FFT_EXEC
+        h->prof.end(1, stream);
+        DPE_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     // the per-kernel event timing and the graph replay exclude each other
     const bool useGraph = h->graphs.enabled && !h->prof.enabled;
     GraphCache::Guard graphGuard{h->graphs, stream};

@@ -375,10 +375,10 @@ def test_argument_errors_are_reported():
     """0 / -1 status with a [Module]-tagged message; nothing is computed on bad input."""
     import torch
     e = dpe.engine
-    with pytest.raises(dpe.DpeError, match="lagHalfWidth"):
-        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, lag_half_width=400).Start()
-    with pytest.raises(dpe.DpeError, match="too wide"):
-        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, bin_half_width=400).Start()
+    with pytest.raises(dpe.DpeError, match="lagHalfWidth"):          # (L = 400 is served by the FFT path; half the window is not)
+        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, lag_half_width=25000).Start()
+    with pytest.raises(dpe.DpeError, match="binHalfWidth"):
+        dpe.BatchCorrScores(2.5e6, samples_per_window=50000, bin_half_width=262144).Start()
     bcs = dpe.BatchCorrScores(2.5e6, samples_per_window=50000, max_channels=4)
     bcs.Start()
     iq = torch.zeros(100000, dtype=torch.int16, device="cuda:0")
