@@ -40,6 +40,8 @@ typedef struct dpe_bcm dpe_bcm;    /* opaque: one BatchCorrManifold instance */
 int dpe_abi_version(void);
 const char *dpe_last_error(void);                 /* thread-local message of the last failure */
 int dpe_device_info(char *name, int nameLen, int *cuCount, int64_t *hbmBytes);
+/* hipSetDevice for the calling thread (one process per GPU: call before anything allocates). */
+int dpe_set_device(int32_t device);
 /* Measured HBM ceiling of this device (SURVEY 8d "verify on the box"): a float4 stream copy (2 arrays) and a
  * triad a = b + s*c (3 arrays) over `bytesPerArray`-byte arrays, `iters` timed launches each after two untimed ones;
  * GB/s = bytes read + written per launch / launch time.  Diagnostic only -- nothing on the hot path calls it. */
@@ -217,6 +219,31 @@ int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWi
                               const double *posGridGlobal, int64_t posGridGlobalSize,
                               const double *velGridGlobal, int64_t velGridGlobalSize,
                               dpe_bcm_result *results);
+
+/* ------------------------------------------------------------------ multi-GPU exchange ------ */
+/* One process per GPU; the manifold grid is sharded (posGridIndexOffset / velGridIndexOffset), stage 1 may be sharded by
+ * window.  The only data-path collectives are the arg-max exchange -- all-reduce(MAX) of the packed keys, 16 B per window --
+ * and, with stage 1 sharded, the all-gather of the banks (the reference is single-GPU).  A dpe_comm is
+ * either RCCL over xGMI (librccl is bound at run time; the unique id travels through <rendezvousPath>/nccl_id, rank 0
+ * writes it) or a host-file transport for functional tests with several ranks on ONE GPU. */
+#define DPE_COMM_RCCL 0
+#define DPE_COMM_HOSTFILES 1
+typedef struct dpe_comm dpe_comm;
+int dpe_comm_create(int32_t rank, int32_t nRanks, const char *rendezvousPath, int32_t backend, dpe_comm **out);
+/* adopt the host application's own ncclComm_t (not destroyed by dpe_comm_destroy) */
+int dpe_comm_wrap_nccl(void *ncclComm, int32_t rank, int32_t nRanks, dpe_comm **out);
+int dpe_comm_destroy(dpe_comm *c);
+int dpe_comm_rank(const dpe_comm *c, int32_t *rank, int32_t *nRanks);
+int dpe_comm_allreduce_max_u64(dpe_comm *c, uint64_t *data_dev, int64_t count, dpe_stream_t stream);
+int dpe_comm_allgather(dpe_comm *c, const void *send_dev, void *recv_dev, int64_t bytesPerRank, dpe_stream_t stream);
+/* Arg-max exchange of the LAST Update: all-reduce(MAX) in place on the handle's device keys ([nWindows][2]); with keys_host
+ * != NULL the reduced keys are also copied there (synchronises) -- feed them to dpe_bcm_results_from_keys with the GLOBAL
+ * grids.  Every rank ends with the same keys. */
+int dpe_bcm_exchange_keys(dpe_bcm *h, dpe_comm *c, uint64_t *keys_host, dpe_stream_t stream);
+/* Stage 1 sharded by window: gathers the banks of this rank's LAST Update (nWindowsLocal windows, the same on every rank)
+ * into codeAll_dev [nRanks * nWindowsLocal][maxChannels][2L+1] and carrAll_dev [..][2B+1] (float2), rank-major = window order
+ * when rank r holds windows [r n, (r+1) n). */
+int dpe_bcs_allgather_banks(dpe_bcs *h, dpe_comm *c, float *codeAll_dev, float *carrAll_dev, dpe_stream_t stream);
 
 /* ------------------------------------------------------------------ cuChanMgr ------ */
 /* Host-side (fp64) restatement of dsp::cuChanMgr (cuchanmgr.cu:1004-1268): owns the per-SV

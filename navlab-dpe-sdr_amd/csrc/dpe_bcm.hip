@@ -1004,6 +1004,19 @@ int dpe_bcm_keys(dpe_bcm *h, const uint64_t **keys_dev)
     return 0;
 }
 
+int dpe_bcm_exchange_keys(dpe_bcm *h, dpe_comm *c, uint64_t *keys_host, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h && c && h->lastW > 0, "[BatchCorrManifold] exchange_keys: no update yet / null communicator");
+    unsigned long long *keys = h->keys_d + (size_t)h->cur * 4 * h->cfg.maxWindows;
+    if (dpe_comm_allreduce_max_u64(c, reinterpret_cast<uint64_t *>(keys), 2 * (int64_t)h->lastW, stream)) return -1;
+    if (keys_host) {
+        DPE_CHECK_HIP(hipMemcpyAsync(keys_host, keys, sizeof(uint64_t) * 2 * (size_t)h->lastW, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    }
+    h->pollable = false;   // the host mirror still holds this rank's LOCAL keys
+    return 0;
+}
+
 int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWindows, const double *posGridGlobal,
                               int64_t posGridGlobalSize, const double *velGridGlobal, int64_t velGridGlobalSize,
                               dpe_bcm_result *results)

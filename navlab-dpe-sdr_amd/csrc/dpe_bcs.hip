@@ -1464,6 +1464,14 @@ int dpe_bcs_outputs(dpe_bcs *h, const float **codeBank_dev, const float **carrBa
     return 0;
 }
 
+int dpe_bcs_allgather_banks(dpe_bcs *h, dpe_comm *c, float *codeAll_dev, float *carrAll_dev, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h && c && codeAll_dev && carrAll_dev && h->lastW > 0, "[BatchCorrScores] allgather_banks: no update yet / null argument");
+    const size_t K = h->cfg.maxChannels, nLag = 2 * (size_t)h->cfg.lagHalfWidth + 1, nBin = 2 * (size_t)h->cfg.binHalfWidth + 1;
+    if (dpe_comm_allgather(c, h->codeBank_d, codeAll_dev, (int64_t)(h->lastW * K * nLag * sizeof(float2)), stream)) return -1;
+    return dpe_comm_allgather(c, h->carrBank_d, carrAll_dev, (int64_t)(h->lastW * K * nBin * sizeof(float2)), stream);
+}
+
 int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count)
 {
     DPE_REQUIRE(h, "[BatchCorrScores] profile: null handle");

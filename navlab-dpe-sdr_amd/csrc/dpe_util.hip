@@ -62,6 +62,12 @@ int dpe_abi_version(void) { return DPE_ABI_VERSION; }
 
 const char *dpe_last_error(void) { return dpe::g_err; }
 
+int dpe_set_device(int32_t device)
+{
+    DPE_CHECK_HIP(hipSetDevice(device));
+    return 0;
+}
+
 int dpe_device_info(char *name, int nameLen, int *cuCount, int64_t *hbmBytes)
 {
     int dev = 0;

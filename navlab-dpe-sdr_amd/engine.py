@@ -27,6 +27,8 @@ EXPORTS = [
     "dpe_acq_fine", "dpe_acq_scalar_acquisition",
     "dpe_ekf_create", "dpe_ekf_destroy", "dpe_ekf_step_update", "dpe_ekf_step_predict", "dpe_ekf_state",
     "dpe_hbm_ceiling", "dpe_bcs_stage1_kernel",
+    "dpe_set_device", "dpe_comm_create", "dpe_comm_wrap_nccl", "dpe_comm_destroy", "dpe_comm_rank", "dpe_comm_allreduce_max_u64",
+    "dpe_comm_allgather", "dpe_bcm_exchange_keys", "dpe_bcs_allgather_banks",
 ]
 
 
@@ -305,6 +307,30 @@ class BatchCorrScores:
                                           _ptr(carr_dev) if carr_dev is not None else None, _stream(stream)))
 
 
+class Comm:
+    """dpe_comm: the multi-GPU exchange behind the C-ABI (RCCL, or host files for one-GPU functional tests)."""
+    RCCL, HOSTFILES = 0, 1
+
+    def __init__(self, rank, n_ranks, rendezvous="", backend=0):
+        self._h = C.c_void_p(None)
+        _check(lib().dpe_comm_create(C.c_int32(rank), C.c_int32(n_ranks), rendezvous.encode(), C.c_int32(backend), C.byref(self._h)))
+        self.rank, self.n_ranks = rank, n_ranks
+
+    def allreduce_max_u64(self, dev_ptr, count, stream=None):
+        _check(lib().dpe_comm_allreduce_max_u64(self._h, C.c_void_p(dev_ptr), C.c_int64(count), _stream(stream)))
+
+    def close(self):
+        if self._h:
+            lib().dpe_comm_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BatchCorrManifold:
     """Module "BatchCorrManifold" (batchcorrmanifold.cu:2247-2303): params PosGrid/VelGrid (host
     [G,4] ENU offsets, i.e. the LoadPosGrid path :2422-2448 generalised to both manifolds), LPower."""
@@ -371,6 +397,13 @@ class BatchCorrManifold:
                      posScore=r.posScore, velScore=r.velScore, posOutOfWindow=r.posOutOfWindow,
                      velOutOfWindow=r.velOutOfWindow, zValMean=np.array(r.zValMean),
                      weightedSums=np.array([list(r.weightedSums[0]), list(r.weightedSums[1])])) for r in res]
+
+    def exchange_keys(self, comm, stream=None):
+        """All-reduce(MAX) of the last Update's packed keys across the ranks of `comm` (dpe_bcm_exchange_keys);
+        returns the reduced host keys [W, 2] for results_from_keys."""
+        keys = np.zeros((self._W, 2), dtype=np.uint64)
+        _check(lib().dpe_bcm_exchange_keys(self._h, comm._h, keys.ctypes.data_as(C.POINTER(C.c_uint64)), _stream(stream)))
+        return keys
 
     def results_from_keys(self, keys_host, pos_grid_global, vel_grid_global):
         keys_host = np.ascontiguousarray(keys_host, dtype=np.uint64)

@@ -6,6 +6,8 @@
 //   dpe_flow --samples f.dat --handoff handoff.csv --out X.csv [--fs 2.5e6] [--T 0.02] [--iters 3000]
 //            [--grid-dim 25] [--spacing 1.0] [--grid-type 0|2] [--load-grid rngrid.csv] [--lpower 1]
 //            [--init-delta dx dy dz dt]
+//            [--ranks N --rank r --rendezvous DIR [--comm rccl|files] [--device d]]   one flow per GPU: grid shard r of N,
+//                                                arg-max exchanged through dpe_bcm_exchange_keys (RCCL, or host files for tests)
 //   dpe_flow --dump-grid <type> <dim> <spacing> <out.bin>        (grid builders only, no GPU)
 #include <cstdio>
 #include <cstdlib>
@@ -24,7 +26,8 @@
 
 int main(int argc, char **argv)
 {
-    std::string samples, handoff, out = "XFile.csv", loadGrid, rinex;
+    std::string samples, handoff, out = "XFile.csv", loadGrid, rinex, rendezvous, commName = "rccl";
+    int ranks = 1, rank = 0, device = -1;
     double fs = 2.5e6, T = 0.02;
     int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
     bool useGraph = false, timing = false, enableEkf = false;
@@ -74,6 +77,11 @@ int main(int argc, char **argv)
         else if (a == "--grid-type") { gridType = std::atoi(next()); ++i; }
         else if (a == "--spacing") { spacing = (float)std::atof(next()); ++i; }
         else if (a == "--lpower") { lpower = std::atoi(next()); ++i; }
+        else if (a == "--ranks") { ranks = std::atoi(next()); ++i; }
+        else if (a == "--rank") { rank = std::atoi(next()); ++i; }
+        else if (a == "--rendezvous") { rendezvous = next(); ++i; }
+        else if (a == "--comm") { commName = next(); ++i; }
+        else if (a == "--device") { device = std::atoi(next()); ++i; }
         else if (a == "--graph") { useGraph = true; }
         else if (a == "--timing") { timing = true; }
         else if (a == "--ekf") { enableEkf = true; }
@@ -137,6 +145,13 @@ int main(int argc, char **argv)
         CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGrid", true));
         CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGridFilename", loadGrid.c_str()));
     }
+    if (ranks > 1 || !rendezvous.empty()) {
+        if (commName != "rccl" && commName != "files") { std::fprintf(stderr, "--comm rccl|files\n"); return 2; }
+        CHECK(flow.SetModParam("BatchCorrManifold", "ShardRank", rank));
+        CHECK(flow.SetModParam("BatchCorrManifold", "ShardCount", ranks));
+        CHECK(flow.SetModParam("BatchCorrManifold", "CommBackend", commName == "files" ? DPE_COMM_HOSTFILES : DPE_COMM_RCCL));
+        CHECK(flow.SetModParam("BatchCorrManifold", "CommRendezvous", rendezvous.c_str()));
+    }
     CHECK(flow.SetModParam("BatchCorrScores", "LagHalfWidth", L));
     CHECK(flow.SetModParam("BatchCorrScores", "BinHalfWidth", B));
     CHECK(flow.SetModParam("BatchCorrScores", "UseGraph", useGraph));
@@ -199,6 +214,7 @@ int main(int argc, char **argv)
     for (auto &w : wires) CHECK(flow.ConnectPort(w[0], w[1], w[2], w[3]));
     std::clog << "[DPEFlow] Completed LoadFlow. (L=" << L << ", B=" << B << ")" << std::endl;
 
+    if (device >= 0) CHECK(dpe_set_device(device));            // one process per GPU: before anything allocates
     dpe_stream_t stream = nullptr;
     CHECK(dpe_stream_create(&stream));
     CHECK(flow.Start(stream));

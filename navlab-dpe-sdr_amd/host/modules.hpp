@@ -375,6 +375,11 @@ class BatchCorrManifold : public Module {
         InsertParam("LoadPosGridFilename", loadPosGridFilename, CHAR_t, sizeof(loadPosGridFilename), 0);
         InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
         InsertParam("ReferencePair", &referencePair, BOOL_t, sizeof(bool), sizeof(bool));   // dpe_bcm_config.referencePair
+        // multi-GPU (one flow per GPU): this flow scores grid shard ShardRank of ShardCount and exchanges the arg-max
+        InsertParam("ShardRank", &shardRank, INT_t, sizeof(int), sizeof(int));
+        InsertParam("ShardCount", &shardCount, INT_t, sizeof(int), sizeof(int));
+        InsertParam("CommBackend", &commBackend, INT_t, sizeof(int), sizeof(int));          // DPE_COMM_RCCL / DPE_COMM_HOSTFILES
+        InsertParam("CommRendezvous", commRendezvous, CHAR_t, sizeof(commRendezvous), 0);
         ConfigOutput(0, "zVal", DOUBLE_t, STATE, HOST, 8, zVal, 0);
         ConfigOutput(1, "RVal", DOUBLE_t, COVARIANCE, HOST, 64, RVal, 0);
         ConfigOutput(2, "TimeGrid", DOUBLE_t, VALUE, HOST, VECTORLENGTH_ANY, nullptr, 0);
@@ -402,6 +407,21 @@ class BatchCorrManifold : public Module {
         cfg.lPower = LPower; cfg.maxWindows = 1; cfg.maxChannels = DPE_MAX_CHAN;
         cfg.posGrid = posGrid.data(); cfg.velGrid = velGrid.data();
         cfg.posGridSize = (int64_t)posGrid.size() / 4; cfg.velGridSize = (int64_t)velGrid.size() / 4;
+        if (shardCount > 1 || comm_requested()) {
+            if (shardRank < 0 || shardRank >= shardCount) DPE_MOD_FAIL("Start: ShardRank " << shardRank << " not in [0, " << shardCount << ")");
+            // contiguous index ranges, remainder to the first ranks (keeps the reference's index order, "t fastest")
+            auto range = [&](int64_t G, int64_t &b, int64_t &e) {
+                const int64_t base = G / shardCount, rem = G % shardCount;
+                b = shardRank * base + (shardRank < rem ? shardRank : rem);
+                e = b + base + (shardRank < rem ? 1 : 0);
+            };
+            int64_t pb, pe, vb, ve;
+            range(cfg.posGridSize, pb, pe);
+            range(cfg.velGridSize, vb, ve);
+            cfg.posGrid = posGrid.data() + 4 * pb; cfg.posGridSize = pe - pb; cfg.posGridIndexOffset = pb;
+            cfg.velGrid = velGrid.data() + 4 * vb; cfg.velGridSize = ve - vb; cfg.velGridIndexOffset = vb;
+            if (dpe_comm_create(shardRank, shardCount, commRendezvous, commBackend, &comm)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+        }
         cfg.writeScores = 1;
         cfg.referencePair = referencePair ? 1 : 0;
         if (dpe_bcm_create(&cfg, &h)) return -1;
@@ -438,7 +458,13 @@ class BatchCorrManifold : public Module {
         dpe_stream_t st = flow_stream(flowStream);
         if (dpe_bcm_update(h, (const float *)inputs[0]->Data, (const float *)inputs[1]->Data, 1, K, &win, ch, st)) { Stop(); return -1; }
         dpe_bcm_result r;
-        if (dpe_bcm_results(h, &r, st)) return -1;                                                         // synchronises, :2606-2632
+        if (comm) {
+            // sharded grid: every rank ends with the same reduced keys and decodes the same global ML point
+            uint64_t keys[2];
+            if (dpe_bcm_exchange_keys(h, comm, keys, st)) DPE_MOD_FAIL("Update: " << dpe_last_error());
+            if (dpe_bcm_results_from_keys(h, keys, 1, posGrid.data(), (int64_t)posGrid.size() / 4, velGrid.data(),
+                                          (int64_t)velGrid.size() / 4, &r)) DPE_MOD_FAIL("Update: " << dpe_last_error());
+        } else if (dpe_bcm_results(h, &r, st)) return -1;                                                  // synchronises, :2606-2632
         std::memcpy(zVal, r.zVal, sizeof(zVal));
         last = r;
         return 0;
@@ -447,6 +473,8 @@ class BatchCorrManifold : public Module {
     {
         if (!Started) return 0;
         dpe_bcm_destroy(h);
+        if (comm) dpe_comm_destroy(comm);
+        comm = nullptr;
         h = nullptr;
         Started = false;
         return 0;
@@ -461,6 +489,10 @@ class BatchCorrManifold : public Module {
     int posDim = 25, velDim = 25, gridType = 0, LPower = 1;
     bool useGraph = false;
     bool referencePair = false;   // reproduce the reference's floor(idx) / floor(idx + 1) pair where it double-counts (dpe_hip.h)
+    int shardRank = 0, shardCount = 1, commBackend = DPE_COMM_RCCL;
+    char commRendezvous[512] = "";
+    dpe_comm *comm = nullptr;
+    bool comm_requested() const { return commRendezvous[0] != 0; }
     float spacing = 1.0f;
     char gridLog[512] = "", loadPosGridFilename[512] = "";
     std::vector<double> posGrid, velGrid, timeGrid;
