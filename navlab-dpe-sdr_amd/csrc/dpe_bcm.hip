@@ -456,6 +456,14 @@ static unsigned scan_split(long long G, int nWindows)
     // manifolds), each walking several tiles, beat one block per tile: the per-block costs (bank staging, key atomics,
     // ticket) are paid fewer times.  Measured on the 25^4 grids: 53.5 -> 49.3 us per window.
     if (nWindows <= 2 && s > 128) s = 128;
+    // batches: ~768 blocks per manifold are enough to fill the chip, and each extra block stages the banks again (K x nEnt
+    // entries).  Measured: config H (12 SVs x 63 entries, 32 windows) scan 0.090 ms at 96 blocks per window, 0.040 at 24;
+    // config R (256 windows) 0.538 at 16, 0.533 at 24.
+    if (nWindows > 2) {
+        const long long cap = 768 / nWindows > 24 ? 768 / nWindows : 24;
+        if (s > cap) s = cap;
+    }
+    if (const char *e = getenv("DPE_BCM_SPLIT")) s = atoi(e);   // experiments
     if (s < 8) s = 8;
     s = (s + 7) / 8 * 8;
     if (s > nTiles) s = nTiles;
