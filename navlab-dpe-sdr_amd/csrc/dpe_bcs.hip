@@ -78,6 +78,23 @@ __device__ __forceinline__ double carr_phase(const BcsChanDev &ch, const double 
     return fma((double)n, ch.carrStep, ch.ri);
 }
 
+// TABLE mode: the wipe-off of sample nSeed + i is reached from the seed at nSeed by i uniform rotations exp(-j 2 pi fi / fs), but the
+// reference's sample times are rounded to 1 ns (BCS_GenTimeIdcs :191-193), i.e. NOT uniformly spaced: the phase that is still owed,
+// eps = 2 pi fi ((t[n] - t[nSeed]) - i / fs) <= 2 pi fi 1 ns, is applied as the first-order rotation w (1 - j eps).  For rates
+// whose period is a half-integer number of ns (16 Msps: 62.5 ns) the rounding is systematic (every odd sample +0.5 ns) and the
+// omitted term was a first-order error of pi fi 0.5 ns of the peak (8.6e-5 at fi = 60 kHz, 3.6e-6 at 2.5 kHz; found by the round-2
+// fuzz sweep -- at 2.046 Msps the rounding is quasi-random and averaged out).
+template <bool TABLE>
+__device__ __forceinline__ f2 table_fix(f2 wv, const BcsChanDev &ch, const double *tT, int nSeed, int i, int S)
+{
+    if (!TABLE) return wv;
+    int n = nSeed + i;
+    n = n < S ? n : S - 1;
+    const double d = fma(tT[n] - tT[nSeed < S ? nSeed : S - 1], ch.fi, -(double)(n - (nSeed < S ? nSeed : S - 1)) * ch.carrStep);
+    const float eps = (float)(6.283185307179586476925286766559 * d);
+    return f2{fmaf(eps, wv.y, wv.x), fmaf(-eps, wv.x, wv.y)};
+}
+
 // ------------------------------------------------------------------------------------------
 // DC sum (thrust::reduce at batchcorrscores.cu:1065): exact int64 sums.  Each block writes its own slot
 // sums[w][blockIdx.x][2] (no atomics, nothing to zero beforehand -- the whole Update stays free of memset
@@ -281,6 +298,8 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     // rawWiped = raw * wipe (BCS_BatchMultiply :402); complex products through cmul()
+                    const f2 wrot = wv;                                       // the rotation chain stays uniform
+                    wv = table_fix<TABLE>(wrot, ch, tT, n0, i, S);           // this sample's wipe-off (ns-rounded time table)
                     const f2 bb = cmul(f2{re[i], im[i]}, wv);
                     // sample n, lag l = j-LH uses replica index n-l -> rr[i - j + 2 LH]
 #pragma unroll
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                             cp *= xp[i];
                         }
                     }
-                    wv = cmul(wv, rotv);
+                    wv = cmul(wrot, rotv);
                 }
             }
             if (sub < nSub && lagShift == 0) {   // the Doppler path belongs to the unshifted replica only
@@ -487,6 +506,8 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const f2 rawv = f2{(float)(short)(raw[i] & 0xFFFF), (float)(raw[i] >> 16)};
+                        const f2 wrot = wv;                                // the rotation chain stays uniform
+                        wv = table_fix<TABLE>(wrot, ch, tT, ns, i, S);    // this sample's wipe-off (ns-rounded time table)
                         const f2 bb = cmul(rawv, wv);                      // rawWiped = raw * wipe (BCS_BatchMultiply :402)
                         // sample n, lag l = j-LH uses replica index n-l -> rr[i - j + 2 LH]
 #pragma unroll
@@ -503,7 +524,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                             M[p] += cp;
                             cp *= xp;
                         }
-                        wv = cmul(wv, rotv);
+                        wv = cmul(wrot, rotv);
                     }
                 }
             }
@@ -650,16 +671,21 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
                     const float f = (float)ph;
                     f2 wv = wipe_seed(f);
                     const f2 rotv = f2{ch.rotRe, ch.rotIm};
+                    int seedIdx = nn, steps = 0;                               // the chain's seed sample and the rotations since
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (n0 + i == S) {   // phase restarts where the circular continuation begins
                             double p2 = ch.ri - floor(ch.ri);
                             wv = wipe_seed((float)p2);
+                            seedIdx = 0; steps = 0;
                         }
+                        const f2 wrot = wv;                                   // the rotation chain stays uniform
+                        wv = table_fix<TABLE>(wrot, ch, tT, seedIdx, steps, S);   // this sample's wipe-off (ns-rounded time table)
+                        ++steps;
                         wown[i] = wv;
                         bown[i] = cmul(f2{re[i], im[i]}, wv);
                         sB[wave][LH + 4 * lane + i] = make_float2(bown[i].x, bown[i].y);
-                        wv = cmul(wv, rotv);
+                        wv = cmul(wrot, rotv);
                     }
                 }
                 {   // halo: lanes 0..31 -> n = sub0-LH+lane ; lanes 32..63 -> n = sub0+256+(lane-32)

@@ -76,6 +76,57 @@ def test_random_case(i):
         raise
 
 
+N_WIDE = int(os.environ.get("DPE_FUZZ_WIDE_CASES", "12"))
+
+
+def draw_wide(i):
+    """Round 2: the high-rate / wide-window forms of stage 1 -- chip-boundary kernel (4 ... 30 Msps, lag windows of 17 ... 31
+    samples and chunked ones beyond), boundary-difference and dense fall-backs (carrier offsets beyond the chip kernel's
+    closed-form range), and the full-length FFT form (lag windows beyond +-292, bin windows beyond the moment expansion)."""
+    rng = np.random.Generator(np.random.PCG64((SEED + 7) * 100003 + i))
+    fs = float(rng.choice([4.0e6, 5.0e6, 8.0e6, 10.0e6, 12.5e6, 16.0e6, 20.0e6, 25.0e6, 30.0e6]))
+    S = 2 * int(rng.integers(2200, 60001))
+    K = int(rng.choice([1, 2, 3, 5, 8, 12]))
+    W = int(rng.choice([1, 1, 2, 3]))
+    G = int(rng.choice([1, 255, 1024, int(rng.integers(2, 3000))]))
+    need_L = int(np.ceil(140.0 / 299792458.0 * fs)) + 2
+    L = max(need_L, int(rng.choice([17, 20, 24, 28, 31, 31, 32, 40, 64, 100])))
+    C = 8 * (1 << int(np.ceil(np.log2(S))))
+    b_max = int(np.floor((720 * 2e-7) ** (1.0 / 6.0) * C / (2 * np.pi * 127.5) * 0.999))
+    B = min(int(rng.choice([8, 12, 20, 33])), b_max)
+    u = rng.random()
+    if u < 0.12:
+        L = int(rng.choice([300, 400]))            # FFT form (lag window)
+    elif u < 0.24:
+        B = min(b_max + int(rng.integers(1, 40)), 200)   # FFT form (bin window)
+    L = min(L, S // 2 - 300)
+    offset = [float(v) for v in rng.uniform(-40.0, 40.0, 4)] if rng.random() < 0.3 else None
+    if offset is not None:
+        L = max(L, need_L + int(np.ceil(70.0 / 299792458.0 * fs)))
+    return dict(seed=5000 + i, fs=fs, S=S, K=K, W=W, G=G, L=L, B=B, amp=float(rng.choice([48.0, 200.0])), offset=offset,
+                lpower=int(rng.choice([1, 1, 2])), if_offset=float(rng.choice([0.0, 0.0, 0.0, 60e3])))
+
+
+@pytest.mark.parametrize("i", range(N_WIDE))
+def test_random_high_rate_or_wide_window_case(i):
+    import navlab_dpe_sdr_amd as dpe
+    p = draw_wide(i)
+    case = helpers.make_case(seed=p["seed"], fs=p["fs"], S=p["S"], K=p["K"], G=p["G"], amp=p["amp"], W=p["W"],
+                             center_offset=p["offset"])
+    if p["if_offset"]:                 # an intermediate frequency: outside the chip kernel's closed-form DC term -> fall-back kernels
+        for w in case["wins"]:
+            w["start"]["fi"] = w["start"]["fi"] + p["if_offset"]
+            w["fi"] = w["fi"] + p["if_offset"]
+            w["iq"] = dpe.synth.gen_iq(p["seed"] * 1000 + 1, case["fs"], case["S"], dict(w["start"]), amp=p["amp"], flip=w["flip"])
+    try:
+        out = helpers.run_gpu(case, p["L"], p["B"], lpower=p["lpower"], weighted_mean=False)
+        ref = helpers.run_oracle(case, p["L"], p["B"], lpower=p["lpower"])
+        helpers.assert_parity(out, ref, tol=float(os.environ.get('DPE_FUZZ_TOL', '2e-5')), pos_ref_noise=3e-4)
+    except Exception:
+        print("wide fuzz case %d: %r" % (i, p))
+        raise
+
+
 N_ACQ = int(os.environ.get("DPE_FUZZ_ACQ_CASES", "6"))
 
 
