@@ -1119,7 +1119,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         // the moment block is the wave's tile of tpb passes, 6 moments: (thetaB tpb kPass / 2)^6 / 720 < 2e-7
         const double halfMax = std::pow(2e-7 * 720.0, 1.0 / 6.0) / thetaB;
         h->chipTpbMax = (int)(2.0 * halfMax / kPass);
-        if (h->chipTpbMax > 16) h->chipTpbMax = 16;
+        if (h->chipTpbMax > 32) h->chipTpbMax = 32;
         h->chipOK = h->LH == 32 && !needTable && (kFCA / fs) * 128.0 < 40.0 && h->chipTpbMax >= 1 && chipLen < 31.0 &&
                     (thetaB * chipLen) * (thetaB * chipLen) / 24.0 < 5e-7 && S >= 2 * kPass;
     }

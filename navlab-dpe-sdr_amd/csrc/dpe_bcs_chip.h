@@ -24,7 +24,10 @@
 
 namespace dpe {
 
-constexpr int kSPL = 17;             // samples per lane
+#ifndef DPE_CHIP_SPL
+#define DPE_CHIP_SPL 17
+#endif
+constexpr int kSPL = DPE_CHIP_SPL;   // samples per lane (odd: the chunk stride in LDS entries must be odd for conflict-free writes)
 constexpr int kPass = 64 * kSPL;     // samples per wave pass
 constexpr int kPad = 64;             // clamp pads of the prefix array (|boundary offset| + |lag| < 64; a chip + 8 < 64)
 constexpr int kQLen = kPass + 2 * kPad + 1;

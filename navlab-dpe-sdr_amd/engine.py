@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpe_hip.so")
+LIB_PATH = os.environ.get("DPE_LIB_PATH") or os.path.join(_HERE, "libdpe_hip.so")   # DPE_LIB_PATH: A/B builds of the library (experiments)
 _lib = None
 
 EXPORTS = [
