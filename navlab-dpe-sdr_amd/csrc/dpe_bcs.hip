@@ -451,12 +451,14 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                     const int ci0 = (int)code_phase<TABLE>(ch, tT, lo);
                     const int shift = (ci0 % kLCA) - ci0;
                     const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
-                    for (int e = lane; e < NREP; e += 64) {
-                        const int m = lo + e;
-                        const int ci = (int)code_phase<TABLE>(ch, tT, m) + shift;
-                        float r = sChips[ci];
-                        if (straddle) r = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
-                        sRep[wave][e] = r;
+                    if (!straddle) {   // (two loops: the side mask of the one straddling pass costs 3 of 17 slots per entry)
+                        for (int e = lane; e < NREP; e += 64) sRep[wave][e] = sChips[(int)code_phase<TABLE>(ch, tT, lo + e) + shift];
+                    } else {
+                        for (int e = lane; e < NREP; e += 64) {
+                            const int m = lo + e;
+                            const float r = sChips[(int)code_phase<TABLE>(ch, tT, m) + shift];
+                            sRep[wave][e] = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
+                        }
                     }
                 } else {
                     for (int e = lane; e < NREP; e += 64) {
