@@ -59,7 +59,7 @@ def pmc_traffic(config, windows, kernel):
         if d.get("config", "R") != config or d.get("windows_per_step") != windows:
             continue
         for k, v in d["kernels"].items():
-            if k.startswith(kernel) or v.get("full_name", "").startswith(kernel):
+            if kernel in k or kernel in v.get("full_name", ""):
                 return v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
     return None, None
 
