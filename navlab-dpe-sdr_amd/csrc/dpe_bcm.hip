@@ -405,7 +405,7 @@ struct dpe_bcm {
     dpe::BcmSvDev *sv_d = nullptr;  // [2][W][maxK]  (manifold-major)
     // pinned staging ring (see dpe_bcs): Updates may be issued kStaging - 1 deep without waiting
     static constexpr int kStaging = 4;
-    dpe::BcmSvDev *svBase_h = nullptr, *sv_h = nullptr;
+    dpe::BcmSvDev *svBase_h = nullptr, *sv_h = nullptr, *svBase_hd = nullptr;   // _hd: the pinned block's device address
     hipEvent_t stagingFree[kStaging] = {};
     int slot = 0;
     unsigned long long *keys_d = nullptr;  // [2 sets][{keys [W][2], counts [W][2]}], alternating between Updates
@@ -731,6 +731,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
         DPE_REQUIRE(h->done_d, "[BatchCorrManifold] create: device allocation failed");
         DPE_CHECK_HIP(hipMemset(h->done_d, 0, sizeof(unsigned int)));
         DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->keys_hd, h->keys_h, 0));
+        DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->svBase_hd, h->svBase_h, 0));
         return 0;
     };
     if (finish()) {
@@ -852,7 +853,8 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         memcpy(pb.s[0], h->sv_h, sizeof(BcmSvDev) * nChan);
         memcpy(pb.s[1], h->sv_h + (size_t)W * maxK, sizeof(BcmSvDev) * nChan);
     } else {
-        DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
+        if (h->graphs.capturing) DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * 2 * (size_t)W * maxK, hipMemcpyHostToDevice, stream));
+        else upload_params(h->sv_d, h->svBase_hd + (h->sv_h - h->svBase_h), sizeof(BcmSvDev) * 2 * (size_t)W * maxK, stream);
         if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     }
     const int nLag = 2 * L + 1, nBin = 2 * B + 1;

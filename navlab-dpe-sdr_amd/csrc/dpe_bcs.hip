@@ -1022,7 +1022,7 @@ struct dpe_bcs {
     // pinned parameter staging: a ring of kStaging blocks, each guarded by an event recorded once its H2D copy (or the
     // graph that contains it) has been enqueued -- Updates may be issued kStaging - 1 deep without waiting
     static constexpr int kStaging = 4;
-    dpe::BcsChanDev *chanBase_h = nullptr, *chan_h = nullptr;
+    dpe::BcsChanDev *chanBase_h = nullptr, *chan_h = nullptr, *chanBase_hd = nullptr;   // _hd: the pinned block's device address
     hipEvent_t stagingFree[kStaging] = {};
     int slot = 0;
     float2 *part_d = nullptr, *mom_d = nullptr, *momRep_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
@@ -1156,6 +1156,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
         DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
         for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->chanBase_hd, h->chanBase_h, 0));
         if (h->fftMode) {
             // windows per chunk: at most 2^27 complex work elements (1 GB); planes b, rX, rY of [chunk][K][S], reused as [chunk][K][C]
             const size_t perW = K * (size_t)(3 * (size_t)S > (size_t)C ? 3 * (size_t)S : (size_t)C);
@@ -1258,7 +1259,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         const int sumBlocks = sum_blocks(S, nWindows);
         h->lastSumBlocks = sumBlocks;
         h->lastKernel = "hipfft full-lag path (bcs_fft_*_kernel)";
-        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        if (h->graphs.capturing) DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        else upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
         DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
         h->prof.begin(0, stream);
         hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples, S, h->sums_d);
@@ -1326,7 +1328,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     BcsParamBlock pb{};
     if (inl) memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
     else {
-        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        if (h->graphs.capturing) DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        else upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
         if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
     }
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
