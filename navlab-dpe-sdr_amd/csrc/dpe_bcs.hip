@@ -62,6 +62,7 @@ struct BcsChanDev {
     double fc, fi;    // raw code / carrier frequency (time-table mode)
     double invStep;   // samples per chip = fs / fc (chip-boundary kernel)
 };
+static_assert(sizeof(BcsChanDev) % 16 == 0, "the parameter upload copies 16-byte words");
 
 // Time of sample n: n/fs, or (TABLE) the reference's ns-rounded table (BCS_GenTimeIdcs,
 // batchcorrscores.cu:185-196) when the sampling period is not an integer number of nanoseconds.
@@ -141,9 +142,14 @@ __device__ __forceinline__ void sum_body(const int16_t *__restrict__ iq, long lo
     }
 }
 
+// (upDst / upSrc / upN16: the batch's channel parameters ride along -- the blocks copy the pinned staging block to the device,
+//  one launch boundary less than a separate upload kernel; upN16 = 0: nothing to copy)
 __global__ __launch_bounds__(256) void bcs_sum_kernel(const int16_t *__restrict__ iq, long long winStride, int S,
-                                                      long long *__restrict__ sums)
+                                                      long long *__restrict__ sums, uint4 *__restrict__ upDst,
+                                                      const uint4 *__restrict__ upSrc, int upN16)
 {
+    const int nThreads = gridDim.x * gridDim.y * 256;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < upN16; i += nThreads) upDst[i] = upSrc[i];
     sum_body(iq, winStride, S, sums);
 }
 
@@ -1263,7 +1269,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         else upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
         DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
         h->prof.begin(0, stream);
-        hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples, S, h->sums_d);
+        hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples, S, h->sums_d,
+                           (uint4 *)nullptr, (const uint4 *)nullptr, 0);
         h->prof.end(0, stream);
         h->prof.begin(1, stream);
         if (hipfftSetStream(h->planS3, stream) != HIPFFT_SUCCESS || hipfftSetStream(h->planS2, stream) != HIPFFT_SUCCESS ||
@@ -1327,11 +1334,10 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int inl = (!h->graphs.capturing && nWindows * nChan <= DPE_MAX_CHAN) ? 1 : 0;
     BcsParamBlock pb{};
     if (inl) memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
-    else {
-        if (h->graphs.capturing) DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
-        else upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
-        if (!h->graphs.capturing) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
-    }
+    // (batches: the DC-sum kernel below carries the parameter upload; a captured graph keeps a copy node)
+    else if (h->graphs.capturing)
+        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+    const bool upInSum = !inl && !h->graphs.capturing;
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
     // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else a dense kernel
@@ -1381,8 +1387,11 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     if (!fuse) {
         h->prof.begin(0, stream);
         hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
-                           (long long)windowStrideSamples, S, h->sums_d);
+                           (long long)windowStrideSamples, S, h->sums_d, (uint4 *)h->chan_d,
+                           (const uint4 *)(h->chanBase_hd + (h->chan_h - h->chanBase_h)),
+                           upInSum ? (int)(sizeof(BcsChanDev) * nWindows * nChan / 16) : 0);
         h->prof.end(0, stream);
+        if (upInSum) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));   // the staging block is free again
     }
 #define DPE_LAUNCH_BANK4(LHV, NM, TB, FS)                                                                               \
     hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB, FS>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
