@@ -228,7 +228,8 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     G = pos.shape[0]
     write_scores = (not args.no_scores) or args.exchange == "scores"
     # --- stage-1 sharding by window
-    shard1 = ctx.use_dist and world > 1 and args.stage1 == "sharded" and W % world == 0
+    # (the 1-rank RCCL self-test keeps the all-gather in the loop: a gather over one rank is a copy through the same calls)
+    shard1 = ctx.use_dist and args.stage1 == "sharded" and W % world == 0
     Wl = W // world if shard1 else W
     w0 = rank * Wl if shard1 else 0
     iq_d = torch.from_numpy(np.ascontiguousarray(iq[w0:w0 + Wl])).to(dev)     # inputs resident in HBM before the timed region
@@ -261,8 +262,8 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     if ctx.use_dist and args.exchange == "scores":
         glob_p = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
         glob_v = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
-        loc_p = device_view(bcm.PosScores, (W, G), "<f4", dev)
-        loc_v = device_view(bcm.VelScores, (W, G), "<f4", dev)
+        loc_p = device_view(bcm.PosScores, (W, bcm.PosScoresPitch), "<f4", dev)[:, :G]     # rows are 128-byte aligned (pitch >= G)
+        loc_v = device_view(bcm.VelScores, (W, bcm.VelScoresPitch), "<f4", dev)[:, :G]
 
     def gather_banks():
         if ctx.backend == "nccl":

@@ -206,8 +206,12 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
  * behind the results in pinned memory; otherwise synchronises `stream`) and returns the per-window ML results (zVal/RVal ports; RVal is the
  * 8x8 identity the reference writes, :2003-2011,2055-2063).  results: [nWindows]. */
 int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream);
-/* PosScores port (:2300,2404) and its velocity twin: float [maxWindows][gridSize]. */
+/* PosScores port (:2300,2404) and its velocity twin: one row of gridSize floats per window; window w's row starts at
+ * scores_dev + w * pitch, where pitch (dpe_bcm_scores_pitch) is the grid size rounded up to a multiple of 32 floats so that
+ * every row starts on a 128-byte line (the reference's port is the single row of a one-window handle: unchanged).  The
+ * pitch - gridSize floats behind a row are never written. */
 int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velScores_dev);
+int dpe_bcm_scores_pitch(dpe_bcm *h, int64_t *posPitch, int64_t *velPitch);
 /* Packed arg-max keys of the LAST update (two sets alternate: query after every Update), device uint64 [maxWindows][2] (pos,vel):
  * (score bits << 32) | (0xFFFFFFFF - globalIndex): an integer max over shards reproduces
  * the "first maximum" tie-break of thrust::max_element (:2589-2590).  For RCCL all-reduce. */

@@ -52,9 +52,9 @@ struct ScanSide {
     const float4 *grid;       // [G] ENU-dt offsets of this rank's shard
     const float2 *bank;       // [W][maxK][nEnt] score bank
     const BcmSvDev *sv;       // [W][maxK] coefficients (ignored when they ride in the kernel arguments)
-    float *scores;            // [W][G] or nullptr
+    float *scores;            // [W][pitch] or nullptr (rows start on 128-byte lines, see dpe_bcm_scores_pitch)
     double *wsum;             // weighted-sum partials (WMEAN) or nullptr
-    long long G, indexOffset;
+    long long G, indexOffset, pitch;
     int nEnt, split;          // bank entries per SV; blocks along x that work on this manifold
 };
 
@@ -231,7 +231,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
         const unsigned int gi0 = (unsigned int)(base + indexOffset);   // global index of the lane's first point (< 2^32, checked at create)
         if (base + (kPtsPerThread - 1) * 256 < G) {
             // whole lane inside the grid (every tile but the last): no per-point bounds checks, one store address
-            float *srow = scores ? scores + (size_t)w * G + base : nullptr;
+            float *srow = scores ? scores + (size_t)w * sd.pitch + base : nullptr;
 #pragma unroll
             for (int it = 0; it < kPtsPerThread; ++it) {
                 const float sc = score[it >> 1][it & 1];
@@ -247,7 +247,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
                 const long long i = base + it * 256;
                 if (i < G) {
                     const float sc = score[it >> 1][it & 1];
-                    if (scores) __builtin_nontemporal_store(sc, &scores[(size_t)w * G + i]);
+                    if (scores) __builtin_nontemporal_store(sc, &scores[(size_t)w * sd.pitch + i]);
                     if (sc > bestSc) { bestSc = sc; bestIdx = gi0 + it * 256; }
                 }
             }
@@ -373,11 +373,11 @@ __global__ void bcm_zero_pos_keys_kernel(unsigned long long *__restrict__ keys, 
     if (w < nWindows) keys[2 * (size_t)w] = 0ull;
 }
 
-__global__ __launch_bounds__(256) void bcm_rekey_kernel(const float *__restrict__ scores, long long G, long long indexOffset,
+__global__ __launch_bounds__(256) void bcm_rekey_kernel(const float *__restrict__ scores, long long G, long long pitch, long long indexOffset,
                                                         unsigned long long *__restrict__ keys)
 {
     const int w = blockIdx.y;
-    const float *row = scores + (size_t)w * G;
+    const float *row = scores + (size_t)w * pitch;
     float bestSc = -1.f;
     unsigned int bestIdx = 0u;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < G; i += (long long)gridDim.x * 256) {
@@ -402,6 +402,7 @@ struct dpe_bcm {
     std::vector<double> posGrid_h, velGrid_h;  // local shard, fp64 (for zVal)
     float4 *posGrid_d = nullptr, *velGrid_d = nullptr;
     float *posScores_d = nullptr, *velScores_d = nullptr;
+    long long posPitch = 0, velPitch = 0;   // floats between the score rows of consecutive windows (grid size rounded up to 32)
     dpe::BcmSvDev *sv_d = nullptr;  // [2][W][maxK]  (manifold-major)
     // pinned staging ring (see dpe_bcs): Updates may be issued kStaging - 1 deep without waiting
     static constexpr int kStaging = 4;
@@ -613,7 +614,7 @@ static int ref_pair_fixup(dpe_bcm *h, const float *codeBank_dev, int nWindows, i
     DPE_REQUIRE(patches.size() <= 65536, "[BatchCorrManifold] Update: referencePair: %zu points to patch (limit 65536)", patches.size());
     for (size_t n = 0; n < patches.size(); ++n) {
         const Patch &pt = patches[n];
-        float *dst = h->posScores_d + (size_t)pt.w * G + pt.i;
+        float *dst = h->posScores_d + (size_t)pt.w * h->posPitch + pt.i;
         float old = 0.f;
         if (h->cfg.weightedMean) DPE_CHECK_HIP(hipMemcpy(&old, dst, sizeof(float), hipMemcpyDeviceToHost));
         h->refPatch_h[n] = pt.sc;
@@ -627,7 +628,7 @@ static int ref_pair_fixup(dpe_bcm *h, const float *codeBank_dev, int nWindows, i
     }
     hipLaunchKernelGGL(bcm_zero_pos_keys_kernel, dim3((nWindows + 63) / 64), dim3(64), 0, stream, keys_d, nWindows);
     const unsigned gx = (unsigned)((G + 256 * 16 - 1) / (256 * 16));
-    hipLaunchKernelGGL(bcm_rekey_kernel, dim3(gx > 512 ? 512 : gx, nWindows), dim3(256), 0, stream, h->posScores_d, G,
+    hipLaunchKernelGGL(bcm_rekey_kernel, dim3(gx > 512 ? 512 : gx, nWindows), dim3(256), 0, stream, h->posScores_d, G, h->posPitch,
                        (long long)h->cfg.posGridIndexOffset, keys_d);
     DPE_CHECK_HIP(hipMemcpyAsync(h->keys_h, keys_d, sizeof(unsigned long long) * 2 * (size_t)nWindows, hipMemcpyDeviceToHost, stream));
     DPE_CHECK_HIP(hipStreamSynchronize(stream));
@@ -693,9 +694,13 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
         dpe_bcm_destroy(h);
         return -1;
     }
+    // score rows start on 128-byte lines: a wave's 64 consecutive scores are then two whole lines instead of one whole and two
+    // partial ones (config R, 390 625-point rows: 0.779 -> 0.755 ms per step, the write-back of a step's 0.8 GB drains faster)
+    h->posPitch = (cfg->posGridSize + 31) / 32 * 32;
+    h->velPitch = (cfg->velGridSize + 31) / 32 * 32;
     if (cfg->writeScores) {
-        h->posScores_d = dev_alloc<float>(W * (size_t)cfg->posGridSize);
-        h->velScores_d = dev_alloc<float>(W * (size_t)cfg->velGridSize);
+        h->posScores_d = dev_alloc<float>(W * (size_t)h->posPitch);
+        h->velScores_d = dev_alloc<float>(W * (size_t)h->velPitch);
     }
     h->sv_d = dev_alloc<BcmSvDev>(2 * W * K);
     h->keys_d = dev_alloc<unsigned long long>(8 * W);   // two alternating sets of {keys [W][2], out-of-window counts [W][2]}
@@ -861,10 +866,10 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     ScanLaunch a;
     a.pb = pb; a.inl = inlineParams ? 1 : 0; a.K = nChan; a.maxK = maxK; a.lp = h->cfg.lPower;
     a.sp = ScanSide{h->posGrid_d, reinterpret_cast<const float2 *>(codeBank_dev), h->sv_d, h->posScores_d,
-                    h->cfg.weightedMean ? h->wsum_d : nullptr, h->cfg.posGridSize, h->cfg.posGridIndexOffset, nLag,
+                    h->cfg.weightedMean ? h->wsum_d : nullptr, h->cfg.posGridSize, h->cfg.posGridIndexOffset, h->posPitch, nLag,
                     (int)h->lastSplit[0]};
     a.sv = ScanSide{h->velGrid_d, reinterpret_cast<const float2 *>(carrBank_dev), h->sv_d + (size_t)W * maxK, h->velScores_d,
-                    h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr, h->cfg.velGridSize, h->cfg.velGridIndexOffset, nBin,
+                    h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr, h->cfg.velGridSize, h->cfg.velGridIndexOffset, h->velPitch, nBin,
                     (int)h->lastSplit[1]};
     a.keys = keys; a.oob = oob; a.clr = other; a.clrN = 4 * W;
     a.done = h->done_d; a.hostKeys = h->keys_hd; a.hostOob = h->keys_hd + 2 * W;
@@ -1004,6 +1009,14 @@ int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velSco
     DPE_REQUIRE(h->cfg.writeScores, "[BatchCorrManifold] scores: created with writeScores=0");
     if (posScores_dev) *posScores_dev = h->posScores_d;
     if (velScores_dev) *velScores_dev = h->velScores_d;
+    return 0;
+}
+
+int dpe_bcm_scores_pitch(dpe_bcm *h, int64_t *posPitch, int64_t *velPitch)
+{
+    DPE_REQUIRE(h, "[BatchCorrManifold] scores_pitch: null handle");
+    if (posPitch) *posPitch = h->posPitch;
+    if (velPitch) *velPitch = h->velPitch;
     return 0;
 }
 

@@ -404,7 +404,10 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
 // (dpe_bcs_update); single windows keep the 4-samples-per-lane kernel, whose blocks are 4x shorter.
 // Same partial / moment layouts, so bcs_finalize_kernel is shared.
 template <int LH, int kNMom, bool TABLE>
-__global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
+#ifndef DPE_B16_OCC
+#define DPE_B16_OCC 4
+#endif
+__global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? DPE_B16_OCC : 3) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
                                                          int S, int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                          const BcsChanDev *__restrict__ chan,
                                                          const long long *__restrict__ sums,
@@ -438,6 +441,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
         f2 acc[NL];   // (re, im) pairs: packed fp32 FMAs against the real replica
 #pragma unroll
         for (int j = 0; j < NL; ++j) acc[j] = f2{0.f, 0.f};
+        bool anyActive = false;   // wave-uniform: most blocks lie entirely on one side of the nav-bit boundary
 
         for (int t = 0; t < tilesPerBlock; ++t) {
             const int pass = (blk * tilesPerBlock + t) * 4 + wave;
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                 if (!ch.hasFlip) active = (side == 0);
                 else if (lo >= 0 && hi < S) active = (side == 0) ? (lo < ch.idxNext) : (hi >= ch.idxNext);
             }
+            anyActive |= active;
             const int n0 = c0 + 16 * lane;
             if (active) {
                 // replica r[m] = chip[floor(t_m fc + rc) mod 1023] (BCS_ComputeCodeReplica :347-349), masked to this
@@ -458,7 +463,22 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                     const int shift = (ci0 % kLCA) - ci0;
                     const bool straddle = ch.hasFlip && lo < ch.idxNext && hi >= ch.idxNext;
                     if (!straddle) {   // (two loops: the side mask of the one straddling pass costs 3 of 17 slots per entry)
-                        for (int e = lane; e < NREP; e += 64) sRep[wave][e] = sChips[(int)code_phase<TABLE>(ch, tT, lo + e) + shift];
+                        // batches of eight independent entries: the fp64 phase -> table read -> store chains overlap
+                        // instead of running one after the other (the loop is latency, not issue)
+                        static_assert(NREP >= 1024 && NREP < 1024 + 64, "sixteen full rounds of 64 entries and a partial one");
+                        if constexpr (TABLE) {   // (the time-table form reads its sample times from memory: keep the short live range)
+                            for (int e = lane; e < NREP; e += 64) sRep[wave][e] = sChips[(int)code_phase<TABLE>(ch, tT, lo + e) + shift];
+                        } else {
+#pragma unroll
+                        for (int e0 = 0; e0 < 1024; e0 += 512) {
+                            float v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = sChips[(int)code_phase<TABLE>(ch, tT, lo + e0 + 64 * j + lane) + shift];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) sRep[wave][e0 + 64 * j + lane] = v[j];
+                        }
+                        if (1024 + lane < NREP) sRep[wave][1024 + lane] = sChips[(int)code_phase<TABLE>(ch, tT, lo + 1024 + lane) + shift];
+                        }
                     } else {
                         for (int e = lane; e < NREP; e += 64) {
                             const int m = lo + e;
@@ -488,6 +508,8 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                 for (int seg = 0; seg < 2; ++seg) {
                     const int ns = n0 + 8 * seg;
                     int raw[8];   // packed I/Q
+                    // (fetching a segment ahead -- under the replica build / the previous segment -- measured 5 % slower: the
+                    // eight extra live registers cost more than the exposed load latency, which the other waves cover)
                     if (vecOK && ns + 7 < S) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -554,8 +576,8 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
                 }
             }
         }
-        // block partial of the lag sums, fixed reduction order
-        {
+        // block partial of the lag sums, fixed reduction order (a wave without a pass on this side contributes zeros)
+        if (anyActive) {
             float aa[2 * NL];
 #pragma unroll
             for (int j = 0; j < NL; ++j) { aa[2 * j] = acc[j].x; aa[2 * j + 1] = acc[j].y; }
@@ -564,6 +586,8 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? 4 : 3) void bcs_bank16_k
 #pragma unroll
                 for (int j = 0; j < NL; ++j) sAcc[wave][j] = make_float2(aa[2 * j], aa[2 * j + 1]);
             }
+        } else if (lane < NL) {
+            sAcc[wave][lane] = make_float2(0.f, 0.f);
         }
         __syncthreads();
         for (int j = tid; j < NL; j += 256) {
@@ -902,6 +926,7 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
     const int gFirst = fat ? 0 : (int)blockIdx.x - 1, gCount = fat ? nGroups : 1;   // host: fat only if nGroups <= kMaxFatGroups
     const int grp = tid >> 4;
     const float invC = 1.0f / (float)C;  // C is a power of two: exact
+    const double twoPiOverC = 6.283185307179586476925286766559 / (double)C;   // exact scaling of 2 pi (power of two)
     float2 F[kMaxFatGroups];
     float theta[kMaxFatGroups], stepS[kMaxFatGroups], stepC[kMaxFatGroups], sn[kMaxFatGroups], cs[kMaxFatGroups];
     bool live[kMaxFatGroups];
@@ -912,13 +937,14 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
         bb[g] = bi - B;
         live[g] = g < gCount && bi < 2 * B + 1;
         F[g] = make_float2(0.f, 0.f);
-        theta[g] = (float)(6.283185307179586476925286766559 * (double)bb[g] / (double)C);
+        theta[g] = (float)((double)bb[g] * twoPiOverC);
         // centre twiddle exp(-j 2 pi n_c b / C), n_c = momLen sub + (momLen - 1) / 2: exact (integer-reduced phase +
         // sincospif) every 8th step of this thread, one complex rotation by exp(-j 2 pi 16 momLen b / C) between
         stepS[g] = 0.f; stepC[g] = 1.f; sn[g] = 0.f; cs[g] = 1.f;
         if (live[g]) {
-            long long ts = ((long long)(32 * momLen) * (long long)bb[g]) % (2 * C);   // 2 * (16 * momLen) b  (phase unit: pi / C)
-            if (ts < 0) ts += 2 * C;
+            // (C = 8 next_pow2(S) is a power of two: the reduction mod 2C is a mask -- a 64-bit `%` by a run-time value costs
+            // some 300 instructions per call and was 60 % of this kernel)
+            const long long ts = ((long long)(32 * momLen) * (long long)bb[g]) & (2 * C - 1);   // 2 * (16 * momLen) b  (phase unit: pi / C)
             sincospif((float)ts * invC, &stepS[g], &stepC[g]);
         }
     }
@@ -949,15 +975,14 @@ __global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int
                 float ar = a[kNMom - 1].x, ai = a[kNMom - 1].y;
 #pragma unroll
                 for (int p = kNMom - 1; p >= 1; --p) {
-                    const float sc = theta[g] / (float)p;
+                    const float sc = theta[g] * (1.0f / (float)p);   // (constant reciprocals: no division sequence in the loop set-up)
                     const float mr = a[p - 1].x, mi = a[p - 1].y;
                     const float nr = fmaf(sc, ai, mr);
                     ai = fmaf(-sc, ar, mi);
                     ar = nr;
                 }
                 if ((it & 7) == 0) {
-                    long long tt = (((long long)(2 * momLen) * sub + (momLen - 1)) * (long long)bb[g]) % (2 * C);
-                    if (tt < 0) tt += 2 * C;
+                    const long long tt = (((long long)(2 * momLen) * sub + (momLen - 1)) * (long long)bb[g]) & (2 * C - 1);
                     sincospif((float)tt * invC, &sn[g], &cs[g]);  // angle = pi * tt / C
                 } else {
                     const float nc = cs[g] * stepC[g] - sn[g] * stepS[g];
@@ -1017,6 +1042,8 @@ struct dpe_bcs {
     float2 *fftWork_d = nullptr;
     int chipDbg = 0;                   // DPE_BCS_CHIP_DBG: skips parts of the chip kernel (timing experiments; wrong results)
     int chipTpbForce = 0;              // DPE_BCS_CHIP_TPB at create: passes per wave of the chip kernel (experiments)
+    int tpb16Force = 0;                // DPE_BCS_TPB16 at create: tiles per block of the 16-samples-per-lane kernel (experiments)
+    int resident16 = 1024;             // co-resident blocks of the 16-samples-per-lane kernel on the whole device
     int chipResident = 0;              // co-resident waves of the chip kernel on the whole device
     int chipTpbMax = 1;                // longest tile (passes) whose 6-moment block still meets the Taylor bound
     long long C;
@@ -1132,6 +1159,12 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
                     (thetaB * chipLen) * (thetaB * chipLen) / 24.0 < 5e-7 && S >= 2 * kPass;
     }
     h->nBlkAlloc = h->nBlk;
+    {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        h->resident16 = ((h->LH <= 4 && !needTable) ? DPE_B16_OCC : 3) * cus;   // the kernel's launch bounds
+    }
     if (h->chipOK) {
         // partial sums of up to 128 blocks per (window, SV); a handle for a few windows gets one block per pass
         int want = (int)(2048 / W) > 128 ? (int)(2048 / W) : 128;
@@ -1194,6 +1227,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->fuseAllowed = getenv("DPE_BCS_NO_FUSE") == nullptr;
     h->chipAllowed = getenv("DPE_BCS_NO_CHIP") == nullptr;
     if (const char *e = getenv("DPE_BCS_CHIP_TPB")) h->chipTpbForce = atoi(e);
+    if (const char *e = getenv("DPE_BCS_TPB16")) h->tpb16Force = atoi(e);
     if (const char *e = getenv("DPE_BCS_CHIP_DBG")) h->chipDbg = atoi(e);
     *out = h;
     return 0;
@@ -1349,11 +1383,18 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int nTiles = use16 ? nTiles16 : (h->nSub + 3) / 4;
     int tpb;   // tiles per block: amortise the end-of-block lag reduction while keeping >= ~4096 blocks in flight
     if (use16) {
-        tpb = (int)(((long long)nTiles * nChan * nWindows) / 4096);
+        // the choice that minimises rounds x (tiles + fixed cost): a block's start-up (chip table into LDS, parameters, the
+        // end-of-side lag reductions) measures ~0.4 tile times, and a launch whose blocks are all resident in two rounds beats
+        // eight rounds of short ones (config R: 4 tiles per block 0.237 ms, all 13 in one block 0.181 ms)
         const int least = (nTiles + h->nBlk - 1) / h->nBlk;   // the partial buffer holds h->nBlk blocks per (window, SV)
-        if (tpb > 4) tpb = 4;
-        if (tpb < least) tpb = least;
-        if (tpb < 1) tpb = 1;
+        double best = -1.0;
+        tpb = least < 1 ? 1 : least;
+        for (int c = tpb; c <= nTiles; ++c) {
+            const long long blocks = (long long)((nTiles + c - 1) / c) * nChan * nWindows;
+            const double cost = (double)((blocks + h->resident16 - 1) / h->resident16) * ((double)c + 0.4);
+            if (best < 0.0 || cost < best) { best = cost; tpb = c; }
+        }
+        if (h->tpb16Force >= least && h->tpb16Force >= 1) tpb = h->tpb16Force;
     } else {
         tpb = (int)(((long long)nTiles * nChan * nWindows) / 4096);
         if (tpb < h->tilesPerBlock) tpb = h->tilesPerBlock;

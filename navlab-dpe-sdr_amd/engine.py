@@ -20,7 +20,7 @@ EXPORTS = [
     "dpe_memcpy_d2h", "dpe_stream_create", "dpe_stream_destroy", "dpe_stream_synchronize",
     "dpe_bcs_create", "dpe_bcs_destroy", "dpe_bcs_update", "dpe_bcs_outputs", "dpe_bcs_read_info",
     "dpe_bcs_export_dense", "dpe_bcm_create", "dpe_bcm_destroy", "dpe_bcm_update", "dpe_bcm_results",
-    "dpe_bcm_scores", "dpe_bcm_keys", "dpe_bcm_results_from_keys", "dpe_event_create", "dpe_event_record",
+    "dpe_bcm_scores", "dpe_bcm_scores_pitch", "dpe_bcm_keys", "dpe_bcm_results_from_keys", "dpe_event_create", "dpe_event_record",
     "dpe_event_elapsed_ms", "dpe_event_destroy", "dpe_chm_create", "dpe_chm_destroy", "dpe_chm_start",
     "dpe_chm_update", "dpe_chm_outputs", "dpe_bcs_profile", "dpe_bcm_profile", "dpe_acq_create", "dpe_acq_destroy",
     "dpe_acq_search", "dpe_acq_results", "dpe_acq_surface", "dpe_bcs_set_graph", "dpe_bcm_set_graph",
@@ -364,6 +364,9 @@ class BatchCorrManifold:
             ps, vs = C.c_void_p(), C.c_void_p()
             _check(lib().dpe_bcm_scores(self._h, C.byref(ps), C.byref(vs)))
             self.PosScores, self.VelScores = ps.value, vs.value
+        pp, vp = C.c_int64(), C.c_int64()
+        _check(lib().dpe_bcm_scores_pitch(self._h, C.byref(pp), C.byref(vp)))
+        self.PosScoresPitch, self.VelScoresPitch = pp.value, vp.value     # floats between the rows of consecutive windows
         keys = C.c_void_p()
         _check(lib().dpe_bcm_keys(self._h, C.byref(keys)))
         self.Keys = keys.value
@@ -419,9 +422,9 @@ class BatchCorrManifold:
 
     def read_scores(self, stream=None):
         Gp, Gv = self.pos_grid.shape[0], self.vel_grid.shape[0]
-        ps = d2h(self.PosScores, self._W * Gp * 4, np.float32, stream).reshape(self._W, Gp)
-        vs = d2h(self.VelScores, self._W * Gv * 4, np.float32, stream).reshape(self._W, Gv)
-        return ps, vs
+        ps = d2h(self.PosScores, self._W * self.PosScoresPitch * 4, np.float32, stream).reshape(self._W, self.PosScoresPitch)[:, :Gp]
+        vs = d2h(self.VelScores, self._W * self.VelScoresPitch * 4, np.float32, stream).reshape(self._W, self.VelScoresPitch)[:, :Gv]
+        return np.ascontiguousarray(ps), np.ascontiguousarray(vs)
 
     def set_graph(self, enable=True):
         """Replay repeated Updates as one hipGraph launch (needs a created stream, see dpe_hip.h)."""

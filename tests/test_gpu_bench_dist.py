@@ -73,3 +73,4 @@ def test_one_rank_rccl_self_test():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["config"]["exchange"] == "keys" and d["value"] > 0
+    assert d["config"]["stage1"].startswith("sharded")     # the banks went through all_gather_into_tensor on device views
