@@ -408,7 +408,7 @@ template <int LH, int kNMom, bool TABLE>
 #define DPE_B16_OCC 4
 #endif
 __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? DPE_B16_OCC : 3) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
-                                                         int S, int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
+                                                         int S, int K, int nW, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                          const BcsChanDev *__restrict__ chan,
                                                          const long long *__restrict__ sums,
                                                          const int8_t *__restrict__ chipTable,
@@ -424,7 +424,11 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? DPE_B16_OCC : 3) void bc
     __shared__ __align__(16) float sRep[4][NREP + 8];
     __shared__ float2 sAcc[4][NL];
 
-    const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
+    // Block -> (window, tile group, SV), XCD-aware like the chip kernel's: the K blocks that read the same samples get linear
+    // ids that are congruent mod 8 (same XCD) and consecutive there, so the XCD's L2 serves K - 1 of the K reads
+    const int slot = blockIdx.x >> 3, k = slot % K, tg = (slot / K) * 8 + (blockIdx.x & 7);
+    if (tg >= nBlk * nW) return;
+    const int w = tg / nBlk, blk = tg - w * nBlk;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     (void)pb;
     const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
@@ -1473,8 +1477,9 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
 #undef DPE_LAUNCH_CHIP
     } else if (use16) {
 #define DPE_LAUNCH_B16(LHV, NM, TB)                                                                                    \
-    hipLaunchKernelGGL((bcs_bank16_kernel<LHV, NM, TB>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
-                       S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
+    hipLaunchKernelGGL((bcs_bank16_kernel<LHV, NM, TB>), dim3(((nBlk * nWindows + 7) / 8) * 8 * nChan), block, 0, stream, pb, inl, samples_dev, \
+                       (long long)windowStrideSamples, S, nChan, nWindows, h->nSub, tpb, nBlk, vecOK, sumBlocks, h->chan_d, h->sums_d,         \
+                       h->chipTable_d, h->tTable_d, h->part_d, h->mom_d)
 #define DPE_LAUNCH_B16_2(LHV)                                                                           \
     do {                                                                                                \
         if (h->nMom == 4) { if (h->useTable) DPE_LAUNCH_B16(LHV, 4, true); else DPE_LAUNCH_B16(LHV, 4, false); } \
