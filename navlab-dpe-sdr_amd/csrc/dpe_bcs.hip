@@ -811,8 +811,9 @@ namespace dpe {
 // blockIdx.x == 0: code bank (+ replica choice); blockIdx.x >= 1: 64 Doppler bins each.
 // momLen = samples per moment block (kSub for the per-sample kernels, kPass for the chip kernel); nValid = entries of a
 // block partial that hold lags (65, or 64 for the chip kernel whose lanes cover lagShift - 32 .. lagShift + 31).
+// (batch form with 4 moments: held to 128 registers = four blocks per CU -- the kernel is a chain of latencies, 0.033 -> 0.030 ms at R)
 template <int kNMom, bool FUSE>
-__global__ __launch_bounds__(256) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide, int lagShift,
+__global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide, int lagShift,
                                                            int momLen, int nValid, long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
                                                            const float2 *__restrict__ mom,
