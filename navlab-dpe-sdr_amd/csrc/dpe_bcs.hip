@@ -505,16 +505,18 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? DPE_B16_OCC : 3) void bc
             f2 M[kNMom];
 #pragma unroll
             for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
-            if (active) {
-                // two segments of 8 samples, deliberately NOT unrolled: the live set stays at one segment's
-                // samples and replica window (occupancy), and each segment re-seeds the carrier phase
+            // two segments of 8 samples, deliberately NOT unrolled: the live set stays at one segment's samples and replica
+            // window (occupancy), and each segment re-seeds the carrier phase.  allIn: the whole pass lies inside the window
+            // (every pass but the window's last) -- no per-sample bound on the carrier path
+            auto segments = [&](auto allInTag) {
+                constexpr bool kAllIn = decltype(allInTag)::value;
 #pragma unroll 1
                 for (int seg = 0; seg < 2; ++seg) {
                     const int ns = n0 + 8 * seg;
                     int raw[8];   // packed I/Q
                     // (fetching a segment ahead -- under the replica build / the previous segment -- measured 5 % slower: the
                     // eight extra live registers cost more than the exposed load latency, which the other waves cover)
-                    if (vecOK && ns + 7 < S) {
+                    if (vecOK && (kAllIn || ns + 7 < S)) {
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int4 v = *reinterpret_cast<const int4 *>(x + 2 * (size_t)(ns + 4 * q));
@@ -532,11 +534,15 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? DPE_B16_OCC : 3) void bc
                     }
                     // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300): fp64 phase
                     // seed, hardware sin/cos in revolutions, then 7 fp32 rotations -- complex products through cmul()
-                    double ph = carr_phase<TABLE>(ch, tT, ns < S ? ns : S - 1);   // lanes past the window carry zero samples
+                    double ph = carr_phase<TABLE>(ch, tT, (kAllIn || ns < S) ? ns : S - 1);   // lanes past the window carry zero samples
                     ph -= floor(ph);
                     f2 wv = wipe_seed((float)ph);
-                    const float xs = xbase + (float)(8 * seg);
-                    const bool inside = ns + 7 < S;   // false only for lanes of the window's last pass
+                    const bool inside = kAllIn || ns + 7 < S;   // false only for lanes of the window's last pass
+                    // moments of the segment about ITS centre (the powers of i - 3.5 are literals: one packed FMA per order
+                    // and sample), moved to the sub-tile's abscissa once per segment
+                    f2 m[kNMom];
+#pragma unroll
+                    for (int p = 0; p < kNMom; ++p) m[p] = f2{0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const f2 rawv = f2{(float)(short)(raw[i] & 0xFFFF), (float)(raw[i] >> 16)};
@@ -551,16 +557,38 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? DPE_B16_OCC : 3) void bc
                         }
                         // carrier path: (raw - mean) * wipe * replica (:480, :440-448)
                         const float r0 = (inside || ns + i < S) ? rr[i + LH] : 0.f;  // no sample beyond the window
-                        f2 cp = (bb - cmul(meanv, wv)) * r0;               // x^p * c, built up by one packed multiply per order
-                        const float xp = xs + (float)i;
+                        const f2 cp = (bb - cmul(meanv, wv)) * r0;
+                        const float d = (float)i - 3.5f;
+                        float dp = 1.f;
+                        m[0] += cp;
 #pragma unroll
-                        for (int p = 0; p < kNMom; ++p) {
-                            M[p] += cp;
-                            cp *= xp;
+                        for (int p = 1; p < kNMom; ++p) {
+                            dp *= d;   // folded at compile time
+                            m[p] = __builtin_elementwise_fma(cp, f2{dp, dp}, m[p]);
                         }
                         wv = cmul(wrot, rotv);
                     }
+                    // (x + d)^p = sum_q C(p,q) x^(p-q) d^q, x = the segment centre in sub-tile coordinates
+                    const float xc = xbase + (float)(8 * seg) + 3.5f;
+                    float xpow[kNMom];
+                    xpow[0] = 1.f;
+#pragma unroll
+                    for (int e = 1; e < kNMom; ++e) xpow[e] = xpow[e - 1] * xc;
+                    constexpr float bin[6][6] = {{1, 0, 0, 0, 0, 0}, {1, 1, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0}, {1, 3, 3, 1, 0, 0}, {1, 4, 6, 4, 1, 0}, {1, 5, 10, 10, 5, 1}};
+#pragma unroll
+                    for (int p = 0; p < kNMom; ++p) {
+                        M[p] += m[p];
+#pragma unroll
+                        for (int q = 0; q < p; ++q) {
+                            const float cf = bin[p][q] * xpow[p - q];
+                            M[p] = __builtin_elementwise_fma(m[q], f2{cf, cf}, M[p]);
+                        }
+                    }
                 }
+            };
+            if (active) {
+                if (c0 + kPass <= S) segments(std::true_type{});
+                else segments(std::false_type{});
             }
             {
                 // one moment set per DPP row = per 256-sample sub-tile
