@@ -25,9 +25,11 @@ namespace dpe {
 struct BcmSvDev {
     float ue, un, uu;  // unit line of sight (receiver -> SV) in the ENU frame of the grid
     float g;           // bank entries per metre of (delta_t + d_rho)   [vel: -(entries per m/s)]
-    float h;           // 1 / (2 range)  (0 for the velocity manifold)
+    float h;           // position manifold: 1 / (2 range)
     float idx0;        // bank-relative fractional index at the grid centre
     float pad0, pad1;
+    // velocity manifold (no second-order term): {h, pad0, pad1} = g {ue, un, uu}, so that the index is four chained FMAs
+    // idx0 + g dt - (g ue) dx - (g un) dy - (g uu) dz instead of dot product, difference, scale
 };
 
 // Single-window calls pass both manifolds' coefficients in the kernel-argument segment of the scan
@@ -158,15 +160,21 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
             const float4 *bk = sE + k * nEnt;
 #pragma unroll
             for (int p = 0; p < kPairs; ++p) {
-                f2 a = dx[p] * s.ue;
-                a = __builtin_elementwise_fma(dy[p], f2{s.un, s.un}, a);
-                a = __builtin_elementwise_fma(dz[p], f2{s.uu, s.uu}, a);
-                f2 x = dw[p] - a;
+                f2 idx;
                 if (SECOND) {
+                    f2 a = dx[p] * s.ue;
+                    a = __builtin_elementwise_fma(dy[p], f2{s.un, s.un}, a);
+                    a = __builtin_elementwise_fma(dz[p], f2{s.uu, s.uu}, a);
+                    f2 x = dw[p] - a;
                     const f2 t = __builtin_elementwise_fma(-a, a, q[p]);          // q - a^2
                     x = __builtin_elementwise_fma(t, f2{s.h, s.h}, x);             // + (q - a^2) / (2 range)
+                    idx = __builtin_elementwise_fma(x, f2{s.g, s.g}, f2{s.idx0, s.idx0});
+                } else {
+                    idx = __builtin_elementwise_fma(dw[p], f2{s.g, s.g}, f2{s.idx0, s.idx0});
+                    idx = __builtin_elementwise_fma(dx[p], f2{-s.h, -s.h}, idx);
+                    idx = __builtin_elementwise_fma(dy[p], f2{-s.pad0, -s.pad0}, idx);
+                    idx = __builtin_elementwise_fma(dz[p], f2{-s.pad1, -s.pad1}, idx);
                 }
-                const f2 idx = __builtin_elementwise_fma(x, f2{s.g, s.g}, f2{s.idx0, s.idx0});
                 float c[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -203,10 +211,15 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
                 const float pw = dw[it >> 1][it & 1], pq = q[it >> 1][it & 1];
                 for (int k = 0; k < K; ++k) {
                     const BcmSvDev s = svw[k];
-                    const float a = fmaf(pz, s.uu, fmaf(py, s.un, px * s.ue));
-                    float x = pw - a;
-                    if (SECOND) x = fmaf(fmaf(-a, a, pq), s.h, x);
-                    const float id = fmaf(x, s.g, s.idx0);
+                    float id;
+                    if (SECOND) {
+                        const float a = fmaf(pz, s.uu, fmaf(py, s.un, px * s.ue));
+                        float x = pw - a;
+                        x = fmaf(fmaf(-a, a, pq), s.h, x);
+                        id = fmaf(x, s.g, s.idx0);
+                    } else {   // the fast path's own expression, operation for operation
+                        id = fmaf(pz, -s.pad1, fmaf(py, -s.pad0, fmaf(px, -s.h, fmaf(pw, s.g, s.idx0))));
+                    }
                     int ei;
                     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ei) : "v"(id));
                     nOob += (min((unsigned)ei, last) == last) ? 1u : 0u;
@@ -819,10 +832,9 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
             const double gv = (Cf / fs) * kFL1 / (kC * win.dopplerSign);
             BcmSvDev &v = h->sv_h[(size_t)(1 * W + w) * maxK + k];
             v.ue = (float)ue; v.un = (float)un; v.uu = (float)uu;
-            v.g = (float)(-gv);   // kernel forms x = delta_tdot - a
-            v.h = 0.f;
+            v.g = (float)(-gv);   // index = idx0 + g (delta_tdot - u . delta_v)
             v.idx0 = (float)(baseVel - (double)(h->cfg.numFFTPoints / 2 - B));
-            v.pad0 = v.pad1 = 0.f;
+            v.h = (float)(-gv * ue); v.pad0 = (float)(-gv * un); v.pad1 = (float)(-gv * uu);   // g u, products formed in fp64
             {
                 const double reach = std::fabs(gv) * h->velExtent + 1e-3;
                 if (!((double)v.idx0 - reach >= 0.0 && (double)v.idx0 + reach < (double)(2 * B))) velInside = false;
