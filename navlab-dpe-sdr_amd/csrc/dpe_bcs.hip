@@ -403,11 +403,9 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
 // once per 16 samples instead of once per 4.  Used when the batch offers enough passes to fill the chip
 // (dpe_bcs_update); single windows keep the 4-samples-per-lane kernel, whose blocks are 4x shorter.
 // Same partial / moment layouts, so bcs_finalize_kernel is shared.
+constexpr int kB16Blocks = 4;   // blocks per CU the narrow, table-free form is held to (128 registers; five -> 96 with spills measured 1 % slower)
 template <int LH, int kNMom, bool TABLE>
-#ifndef DPE_B16_OCC
-#define DPE_B16_OCC 4
-#endif
-__global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? DPE_B16_OCC : 3) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
+__global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs_bank16_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
                                                          int S, int K, int nW, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk,
                                                          const BcsChanDev *__restrict__ chan,
                                                          const long long *__restrict__ sums,
@@ -1196,7 +1194,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        h->resident16 = ((h->LH <= 4 && !needTable) ? DPE_B16_OCC : 3) * cus;   // the kernel's launch bounds
+        h->resident16 = ((h->LH <= 4 && !needTable) ? dpe::kB16Blocks : 3) * cus;   // the kernel's launch bounds
     }
     if (h->chipOK) {
         // partial sums of up to 128 blocks per (window, SV); a handle for a few windows gets one block per pass

@@ -566,6 +566,41 @@ def test_batch_bank_kernel_matches_single_window_kernel(L, B, W, fs, S):
         assert res[w]["posIndex"] == r1[0]["posIndex"] and res[w]["velIndex"] == r1[0]["velIndex"]
 
 
+@pytest.mark.parametrize("tpb", [1, 2, 5, 13])
+def test_batch_bank_kernel_block_shapes(tpb, monkeypatch):
+    """bcs_bank16_kernel sizes its blocks by a cost model (tiles per block) and deals them to the XCDs by
+    (window, tile group, SV).  Every shape must give the same banks: 21 windows (21 x nBlk is not a multiple of the 8-block
+    dealing unit, so the padding blocks of the launch are exercised) with 1, 2, 5 and all 13 tiles per block (DPE_BCS_TPB16),
+    each against the single-window kernel."""
+    import torch
+    cfg = dpe.workload.CONFIG_R
+    W, L, B = 21, 4, 20
+    iq, cs, ce, bw = dpe.workload.build_windows(W, cfg["fs"], cfg["S"], cfg["K"], seed=43, amp=cfg["amp"])
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+
+    def run(wsel, maxw):
+        bcs = dpe.BatchCorrScores(cfg["fs"], samples_per_window=cfg["S"], lag_half_width=L, bin_half_width=B,
+                                  max_windows=maxw, max_channels=cfg["K"])
+        bcs.Start()
+        bcs.Update(iq_d[wsel], cs[wsel])
+        code, carr = bcs.read_banks()
+        info = bcs.read_info()
+        kern = bcs.stage1_kernel
+        bcs.Stop()
+        return code, carr, info, kern
+
+    monkeypatch.setenv("DPE_BCS_TPB16", str(tpb))
+    code, carr, info, kern = run(slice(0, W), W)
+    monkeypatch.delenv("DPE_BCS_TPB16")
+    assert kern == "bcs_bank16_kernel"
+    for w in (0, 10, W - 1):
+        c1, f1, i1, k1 = run(slice(w, w + 1), 1)
+        assert k1 == "bcs_bank_kernel"
+        assert np.abs(code[w] - c1[0]).max() <= 1e-6 * np.abs(c1[0]).max()
+        assert np.abs(carr[w] - f1[0]).max() <= 1e-6 * np.abs(f1[0]).max()
+        assert np.array_equal(info[0][w], i1[0][0]) and np.array_equal(info[1][w], i1[1][0]) and info[2][w] == i1[2][0]
+
+
 @pytest.mark.parametrize("pos_out,vel_out,wmean", [(False, True, False), (True, True, True), (False, False, False)])
 def test_clamp_variants_of_the_fused_scan(pos_out, vel_out, wmean):
     """The fused scan is instantiated per manifold with or without the range clamp (chosen by a host-side proof that
