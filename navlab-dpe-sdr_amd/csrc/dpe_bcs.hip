@@ -1538,7 +1538,9 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
     // batches: one fat block per (window, SV); few windows: 1 + nBinBlk short blocks (see the kernel);
     // side chunks of a wide lag window: one block per (window, SV), code-bank entries only
-    const bool fatFinalize = nBinBlk <= 4 && (long long)nChan * nWindows >= 512;
+    // (crossover measured in round 2: 96 / 128 (window, SV) pairs are faster split, 192 / 256 / 384 fat -- H at 32 windows 0.0205 -> 0.0113 ms)
+    bool fatFinalize = nBinBlk <= 4 && (long long)nChan * nWindows >= 192;
+    if (const char *e = getenv("DPE_BCS_FAT")) fatFinalize = nBinBlk <= 4 && e[0] == '1';   // experiments
     const dim3 fgrid((fatFinalize || lagShift != 0) ? 1 : 1 + nBinBlk, nChan, nWindows);
 #define DPE_LAUNCH_FIN(NM, FS)                                                                                          \
     hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, chip ? nBlk : h->nSub, nBlk, h->LH, \
