@@ -4,6 +4,8 @@ oracle on the same seeded inputs, and vs the golden fixtures from the reference'
 Tolerance (north_star: "within stated fp32 tolerance"): 2e-6 relative to the peak magnitude of a
 score bank / the maximum manifold score; identical arg-max index (an fp32 tie is the only accepted
 difference); DC mean and nav-bit bookkeeping bit-exact."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -564,6 +566,43 @@ def test_batch_bank_kernel_matches_single_window_kernel(L, B, W, fs, S):
         assert np.abs(carr[w] - f1[0]).max() <= 1e-6 * np.abs(f1[0]).max()
         assert np.array_equal(info[0][w], i1[0][0]) and np.array_equal(info[1][w], i1[1][0]) and info[2][w] == i1[2][0]
         assert res[w]["posIndex"] == r1[0]["posIndex"] and res[w]["velIndex"] == r1[0]["velIndex"]
+
+
+def test_score_rows_start_on_128_byte_lines():
+    """dpe_bcm_scores / dpe_bcm_scores_pitch: one row of gridSize floats per window, `pitch` floats apart, pitch = the grid
+    size rounded up to a multiple of 32 (aligned rows make a wave's 64 scores two whole lines).  The floats
+    between a row's end and the next row are never written, and row w holds window w's scores."""
+    import torch
+    cfg = dpe.workload.CONFIG_R
+    W, L, B, G = 3, 4, 20, 1000
+    iq, cs, ce, bw = dpe.workload.build_windows(W, cfg["fs"], cfg["S"], cfg["K"], seed=47, amp=cfg["amp"])
+    _, _, pos, vel, _ = dpe.workload.build_grids(G)
+    bcs = dpe.BatchCorrScores(cfg["fs"], samples_per_window=cfg["S"], lag_half_width=L, bin_half_width=B, max_windows=W,
+                              max_channels=cfg["K"])
+    bcs.Start()
+    bcm = dpe.BatchCorrManifold(cfg["fs"], cfg["S"], bcs.NumFFTPoints, pos, vel[:777], lag_half_width=L, bin_half_width=B,
+                                max_windows=W, max_channels=cfg["K"])
+    bcm.Start()
+    assert bcm.PosScoresPitch == 1024 and bcm.VelScoresPitch == 800 and bcm.PosScores % 128 == 0 and bcm.VelScores % 128 == 0
+    fill = np.float32(-7.0)
+    # mark the whole buffers, run, and look at what was written
+    for ptr, n in ((bcm.PosScores, W * 1024), (bcm.VelScores, W * 800)):
+        src = np.full(n, fill, np.float32)
+        dpe.engine._check(dpe.engine.lib().dpe_memcpy_h2d(C.c_void_p(ptr), src.ctypes.data_as(C.c_void_p), C.c_int64(4 * n), None))
+    torch.cuda.synchronize()
+    bcs.Update(torch.from_numpy(iq).to("cuda:0"), cs)
+    bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+    res = bcm.results()
+    raw_p = dpe.engine.d2h(bcm.PosScores, W * 1024 * 4, np.float32, None).reshape(W, 1024)
+    raw_v = dpe.engine.d2h(bcm.VelScores, W * 800 * 4, np.float32, None).reshape(W, 800)
+    ps, vs = bcm.read_scores()
+    assert ps.shape == (W, G) and vs.shape == (W, 777)
+    assert np.array_equal(raw_p[:, :G], ps) and np.array_equal(raw_v[:, :777], vs)
+    assert (raw_p[:, G:] == fill).all() and (raw_v[:, 777:] == fill).all()          # the padding is never written
+    assert (ps >= 0).all() and (vs >= 0).all()
+    for w in range(W):
+        assert res[w]["posIndex"] == int(np.argmax(ps[w])) and res[w]["velIndex"] == int(np.argmax(vs[w]))
+    bcm.Stop(); bcs.Stop()
 
 
 @pytest.mark.parametrize("tpb", [1, 2, 5, 13])
