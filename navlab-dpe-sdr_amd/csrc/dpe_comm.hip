@@ -4,11 +4,18 @@
 //
 // Two transports:
 //   RCCL      ncclAllReduce / ncclAllGather over xGMI.  librccl is opened with dlopen at the first use (a process that
-//             already carries an RCCL -- PyTorch ships its own copy under the same SONAME -- keeps using that one), the
-//             unique id travels through a file: rank 0 writes <rendezvous>/nccl_id, the others wait for it.
+//             already carries an RCCL -- PyTorch ships its own copy under the same SONAME -- keeps using that one); the
+//             unique id travels through the rendezvous directory.
 //   host files  every rank copies its buffer to the host, publishes it as a file under <rendezvous>, reads the others' and
 //             reduces on the host.  For functional tests of the sharded path with several ranks on ONE GPU (RCCL refuses
 //             two ranks per device); never a performance path.
+// Rendezvous (both transports, nRanks > 1): a directory may be REUSED by later runs, so nothing in it is trusted by name
+// alone.  Rank r > 0 publishes a fresh random token in join.<r>; rank 0 draws a run nonce, publishes
+// {nonce, tokens of all ranks, ncclUniqueId} in `rendezvous` and re-publishes whenever a join file changes; rank r accepts
+// a `rendezvous` file only if it echoes ITS token, then answers with ack.<r> = {nonce, token}; rank 0 proceeds once every
+// ack carries its nonce and then removes the handshake files.  A file left behind by an earlier run can therefore delay
+// nobody and is never believed.  Every payload of the host-file transport starts with {nonce, sequence number} and a reader
+// waits until it sees both.
 // The reference has no counterpart (single GPU); SURVEY.md 8(e) defines the exchange.
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and enums only: the library itself is bound at run time
@@ -62,20 +69,9 @@ int load_rccl()
     return 0;
 }
 
-bool wait_for_file(const std::string &path, size_t bytes, double timeoutS)
-{
-    const auto t0 = std::chrono::steady_clock::now();
-    struct stat st;
-    while (true) {
-        if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size >= bytes) return true;
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutS) return false;
-        std::this_thread::sleep_for(std::chrono::microseconds(200));
-    }
-}
-
 int write_atomic(const std::string &path, const void *data, size_t bytes)
 {
-    const std::string tmp = path + ".tmp";
+    const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
     FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) return -1;
     const size_t n = std::fwrite(data, 1, bytes, f);
@@ -84,6 +80,7 @@ int write_atomic(const std::string &path, const void *data, size_t bytes)
     return std::rename(tmp.c_str(), path.c_str());
 }
 
+// 0: read `bytes` bytes; -1: missing or shorter (a writer renames complete files into place, so short = not ours yet)
 int read_file(const std::string &path, void *data, size_t bytes)
 {
     FILE *f = std::fopen(path.c_str(), "rb");
@@ -93,6 +90,37 @@ int read_file(const std::string &path, void *data, size_t bytes)
     return n == bytes ? 0 : -1;
 }
 
+double seconds_since(const std::chrono::steady_clock::time_point &t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void nap() { std::this_thread::sleep_for(std::chrono::microseconds(200)); }
+
+// fresh 64-bit token: /dev/urandom, else clock + pid (never 0: 0 marks "no token yet")
+unsigned long long fresh_token()
+{
+    unsigned long long t = 0;
+    if (FILE *f = std::fopen("/dev/urandom", "rb")) {
+        if (std::fread(&t, sizeof(t), 1, f) != 1) t = 0;
+        std::fclose(f);
+    }
+    if (!t) t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 6364136223846793005ull + (unsigned long long)getpid();
+    return t ? t : 1ull;
+}
+
+constexpr unsigned long long kMagic = 0x4450455f52445a31ull;   // "DPE_RDZ1"
+constexpr int kMaxRanks = 64;
+struct RendezvousFile {
+    unsigned long long magic, nonce;
+    long long nRanks;
+    unsigned long long token[kMaxRanks];
+    unsigned char id[128];   // ncclUniqueId (RCCL transport)
+};
+static_assert(sizeof(ncclUniqueId) <= 128, "the unique id travels in a 128-byte field");
+struct AckFile { unsigned long long nonce, token; };
+struct PayloadHeader { unsigned long long nonce, seq; };
+
 }  // namespace
 
 struct dpe_comm {
@@ -100,23 +128,101 @@ struct dpe_comm {
     ncclComm_t nccl = nullptr;
     bool ownsNccl = false;
     std::string dir;
+    unsigned long long nonce = 0;       // run identity agreed in the rendezvous (0: single rank, no files)
     unsigned long long seq = 0;
     std::vector<unsigned char> host;   // staging of the host-file transport
+    std::vector<std::string> mine;     // payload files this rank still has in the directory
 };
 
-// host-file transport: publish this rank's buffer as <dir>/<tag>.<seq>.<rank>, collect everybody's
+namespace {
+
+// Agrees on the run nonce (and, for RCCL, carries the unique id) through `dir`; see the file header.  timeoutS per phase.
+int rendezvous(dpe_comm *c, unsigned char *id /* [128] in (rank 0) / out */, double timeoutS)
+{
+    const std::string rdz = c->dir + "/rendezvous";
+    auto joinName = [&](int r) { return c->dir + "/join." + std::to_string(r); };
+    auto ackName = [&](int r) { return c->dir + "/ack." + std::to_string(r); };
+    const auto t0 = std::chrono::steady_clock::now();
+    if (c->rank == 0) {
+        (void)std::remove(rdz.c_str());   // whatever an earlier run left here is not ours
+        RendezvousFile f{};
+        f.magic = kMagic; f.nonce = fresh_token(); f.nRanks = c->nRanks;
+        memcpy(f.id, id, sizeof(f.id));
+        bool published = false;
+        while (true) {
+            bool changed = false, haveAll = true;
+            for (int r = 1; r < c->nRanks; ++r) {
+                unsigned long long t = 0;
+                if (read_file(joinName(r), &t, sizeof(t)) != 0 || t == 0) { haveAll = false; continue; }
+                if (t != f.token[r]) { f.token[r] = t; changed = true; }
+            }
+            if (haveAll && (changed || !published)) {
+                DPE_REQUIRE(write_atomic(rdz, &f, sizeof(f)) == 0, "[dpe_comm] cannot write %s", rdz.c_str());
+                published = true;
+            }
+            bool acked = published;
+            for (int r = 1; r < c->nRanks && acked; ++r) {
+                AckFile a{};
+                acked = read_file(ackName(r), &a, sizeof(a)) == 0 && a.nonce == f.nonce && a.token == f.token[r];
+            }
+            if (acked) break;
+            DPE_REQUIRE(seconds_since(t0) < timeoutS, "[dpe_comm] rank 0: %s after %.0f s in %s",
+                        haveAll ? "not every rank acknowledged the rendezvous" : "not every rank joined", timeoutS, c->dir.c_str());
+            nap();
+        }
+        c->nonce = f.nonce;
+        // everybody holds the nonce (and the id): the handshake files are done with
+        (void)std::remove(rdz.c_str());
+        for (int r = 1; r < c->nRanks; ++r) { (void)std::remove(joinName(r).c_str()); (void)std::remove(ackName(r).c_str()); }
+        return 0;
+    }
+    const unsigned long long token = fresh_token();
+    (void)std::remove(ackName(c->rank).c_str());
+    DPE_REQUIRE(write_atomic(joinName(c->rank), &token, sizeof(token)) == 0, "[dpe_comm] cannot write %s", joinName(c->rank).c_str());
+    RendezvousFile f{};
+    while (true) {
+        if (read_file(rdz, &f, sizeof(f)) == 0 && f.magic == kMagic && f.nRanks == c->nRanks && f.token[c->rank] == token) break;
+        DPE_REQUIRE(seconds_since(t0) < timeoutS, "[dpe_comm] rank %d: no rendezvous for this run at %s after %.0f s", c->rank, rdz.c_str(), timeoutS);
+        nap();
+    }
+    c->nonce = f.nonce;
+    memcpy(id, f.id, sizeof(f.id));
+    const AckFile a{f.nonce, token};
+    DPE_REQUIRE(write_atomic(ackName(c->rank), &a, sizeof(a)) == 0, "[dpe_comm] cannot write %s", ackName(c->rank).c_str());
+    return 0;
+}
+
+}  // namespace
+
+// host-file transport: publish this rank's buffer as <dir>/<tag>.<seq>.<rank> = {nonce, seq, payload}, collect everybody's.
+// A file of an earlier run under the same name carries another nonce: the reader keeps waiting for ours.
 static int hostfile_exchange(dpe_comm *c, const char *tag, const void *mine, size_t bytes, std::vector<unsigned char> &all)
 {
     const unsigned long long seq = c->seq++;
     auto name = [&](int r, unsigned long long s) { return c->dir + "/" + tag + "." + std::to_string(s) + "." + std::to_string(r); };
-    DPE_REQUIRE(write_atomic(name(c->rank, seq), mine, bytes) == 0, "[dpe_comm] cannot write %s", name(c->rank, seq).c_str());
+    std::vector<unsigned char> buf(sizeof(PayloadHeader) + bytes);
+    const PayloadHeader hdr{c->nonce, seq};
+    memcpy(buf.data(), &hdr, sizeof(hdr));
+    memcpy(buf.data() + sizeof(hdr), mine, bytes);
+    DPE_REQUIRE(write_atomic(name(c->rank, seq), buf.data(), buf.size()) == 0, "[dpe_comm] cannot write %s", name(c->rank, seq).c_str());
+    c->mine.push_back(name(c->rank, seq));
     all.resize(bytes * c->nRanks);
+    const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < c->nRanks; ++r) {
-        DPE_REQUIRE(wait_for_file(name(r, seq), bytes, 120.0), "[dpe_comm] rank %d: no data from rank %d (%s) after 120 s", c->rank, r,
-                    name(r, seq).c_str());
-        DPE_REQUIRE(read_file(name(r, seq), all.data() + bytes * r, bytes) == 0, "[dpe_comm] cannot read %s", name(r, seq).c_str());
+        while (true) {
+            PayloadHeader h{};
+            if (read_file(name(r, seq), buf.data(), buf.size()) == 0 && (memcpy(&h, buf.data(), sizeof(h)), h.nonce == c->nonce && h.seq == seq)) break;
+            DPE_REQUIRE(seconds_since(t0) < 120.0, "[dpe_comm] rank %d: no data of this run from rank %d (%s) after 120 s", c->rank, r,
+                        name(r, seq).c_str());
+            nap();
+        }
+        memcpy(all.data() + bytes * r, buf.data() + sizeof(PayloadHeader), bytes);
     }
-    if (seq >= 2) (void)std::remove(name(c->rank, seq - 2).c_str());   // everybody has passed exchange seq-2 by now (it needed seq-1 of all)
+    // everybody has passed exchange seq-2 by now (it needed seq-1 of all): this rank's files from then are unread
+    while (c->mine.size() > 2) {
+        (void)std::remove(c->mine.front().c_str());
+        c->mine.erase(c->mine.begin());
+    }
     return 0;
 }
 
@@ -125,26 +231,30 @@ extern "C" {
 int dpe_comm_create(int32_t rank, int32_t nRanks, const char *rendezvousPath, int32_t backend, dpe_comm **out)
 {
     DPE_REQUIRE(out && nRanks >= 1 && rank >= 0 && rank < nRanks, "[dpe_comm] create: bad rank %d of %d", rank, nRanks);
+    DPE_REQUIRE(nRanks <= kMaxRanks, "[dpe_comm] create: %d ranks (at most %d)", nRanks, kMaxRanks);
     DPE_REQUIRE(backend == DPE_COMM_RCCL || backend == DPE_COMM_HOSTFILES, "[dpe_comm] create: unknown backend %d", backend);
     DPE_REQUIRE(nRanks == 1 || (rendezvousPath && *rendezvousPath), "[dpe_comm] create: rendezvous directory missing");
     dpe_comm *c = new dpe_comm();
     c->rank = rank; c->nRanks = nRanks; c->backend = backend;
     c->dir = rendezvousPath ? rendezvousPath : "";
+    unsigned char idBytes[128] = {};
     if (backend == DPE_COMM_RCCL) {
         if (load_rccl()) { delete c; return -1; }
-        ncclUniqueId id;
-        const std::string idFile = c->dir + "/nccl_id";
         if (rank == 0) {
+            ncclUniqueId id;
             const ncclResult_t r = g_rccl.GetUniqueId(&id);
             if (r != ncclSuccess) { dpe::set_error("[dpe_comm] ncclGetUniqueId: %s", g_rccl.GetErrorString(r)); delete c; return -1; }
-            if (nRanks > 1 && write_atomic(idFile, &id, sizeof(id)) != 0) { dpe::set_error("[dpe_comm] cannot write %s", idFile.c_str()); delete c; return -1; }
-        } else {
-            if (!wait_for_file(idFile, sizeof(id), 120.0) || read_file(idFile, &id, sizeof(id)) != 0) {
-                dpe::set_error("[dpe_comm] rank %d: no unique id at %s after 120 s", rank, idFile.c_str());
-                delete c;
-                return -1;
-            }
+            memcpy(idBytes, &id, sizeof(id));
         }
+    }
+    if (nRanks > 1) {
+        double timeoutS = 120.0;
+        if (const char *e = getenv("DPE_COMM_TIMEOUT_S")) timeoutS = atof(e) > 0 ? atof(e) : timeoutS;
+        if (rendezvous(c, idBytes, timeoutS)) { delete c; return -1; }
+    }
+    if (backend == DPE_COMM_RCCL) {
+        ncclUniqueId id;
+        memcpy(&id, idBytes, sizeof(id));
         const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, nRanks, id, rank);
         if (r != ncclSuccess) { dpe::set_error("[dpe_comm] ncclCommInitRank: %s", g_rccl.GetErrorString(r)); delete c; return -1; }
         c->ownsNccl = true;
@@ -169,6 +279,12 @@ int dpe_comm_destroy(dpe_comm *c)
 {
     if (!c) return 0;
     if (c->nccl && c->ownsNccl) (void)g_rccl.CommDestroy(c->nccl);
+    // the last payload files of this rank: a peer may still be reading the newest one (it is stamped with this run's
+    // nonce, so a later run never mistakes it for its own), everything older is unread
+    while (c->mine.size() > 1) {
+        (void)std::remove(c->mine.front().c_str());
+        c->mine.erase(c->mine.begin());
+    }
     delete c;
     return 0;
 }

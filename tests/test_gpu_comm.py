@@ -34,16 +34,19 @@ def test_two_flow_ranks_on_one_gpu_equal_the_unsharded_flow(tmp_path):
     subprocess.check_call(base + ["--out", full], timeout=200)
     rdv = str(tmp_path / "rdv")
     os.makedirs(rdv)
-    outs = [str(tmp_path / ("X_rank%d.csv" % r)) for r in range(2)]
-    procs = [subprocess.Popen(base + ["--out", outs[r], "--ranks", "2", "--rank", str(r), "--rendezvous", rdv, "--comm", "files"],
-                              stderr=subprocess.PIPE, text=True) for r in range(2)]
-    for p in procs:
-        _, err = p.communicate(timeout=200)
-        assert p.returncode == 0, err[-2000:]
     ref = np.loadtxt(full, delimiter=",")
-    for o in outs:
-        assert np.array_equal(np.loadtxt(o, delimiter=","), ref)       # every rank decodes the same global ML point
     assert ref.shape == (W, 8)
+    # twice through the SAME rendezvous directory: the second run finds the first one's exchange files (same names, same
+    # sizes, stamped with another run's nonce) and must neither believe nor trip over them
+    for attempt in range(2):
+        outs = [str(tmp_path / ("X_run%d_rank%d.csv" % (attempt, r))) for r in range(2)]
+        procs = [subprocess.Popen(base + ["--out", outs[r], "--ranks", "2", "--rank", str(r), "--rendezvous", rdv, "--comm", "files"],
+                                  stderr=subprocess.PIPE, text=True) for r in range(2)]
+        for p in procs:
+            _, err = p.communicate(timeout=200)
+            assert p.returncode == 0, err[-2000:]
+        for o in outs:
+            assert np.array_equal(np.loadtxt(o, delimiter=","), ref)       # every rank decodes the same global ML point
 
 
 def test_flow_with_one_rccl_rank(tmp_path):
@@ -76,7 +79,17 @@ def test_comm_allreduce_max_through_python(tmp_path):
     c.close()
     a = torch.tensor([5, 1, 9, 2], dtype=torch.int64, device="cuda:0")
     b = torch.tensor([3, 7, 9, 8], dtype=torch.int64, device="cuda:0")
-    comms = [dpe.engine.Comm(r, 2, str(tmp_path), dpe.engine.Comm.HOSTFILES) for r in range(2)]
+    comms = [None, None]     # the rendezvous is a handshake: both ranks have to be in it at the same time
+
+    def make(r):
+        comms[r] = dpe.engine.Comm(r, 2, str(tmp_path), dpe.engine.Comm.HOSTFILES)
+
+    th = [threading.Thread(target=make, args=(r,)) for r in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(60)
+    assert all(comms)
     th = [threading.Thread(target=comms[r].allreduce_max_u64, args=(x.data_ptr(), 4)) for r, x in enumerate((a, b))]
     for x in th:
         x.start()
