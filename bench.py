@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 # What physically limits each kernel (rocprofv3 SQ counters, profiles/*_sq_counters.json): none of them
 # is HBM-bound -- the "hbm" roofline below is SURVEY 8(d)'s algorithmic-bytes convention, not the physical limiter.
-BOUND_PHYSICAL = {"bcm_scan_kernel": "valu", "bcs_bank_chip_kernel": "valu+lds", "bcs_bank16_kernel": "valu",
+BOUND_PHYSICAL = {"bcm_scan_kernel": "valu", "bcs_bank_chip_kernel": "valu+lds", "bcs_bank_chip2_kernel": "valu+lds", "bcs_bank16_kernel": "valu",
                   "bcs_bank_wide_kernel": "valu", "bcs_bank_kernel": "valu", "bcs_finalize_kernel": "latency",
                   "bcs_sum_kernel": "hbm"}
 
@@ -207,10 +207,11 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     cfg = dict({"R": dpe.workload.CONFIG_R, "H": dpe.workload.CONFIG_H, "M": dpe.workload.CONFIG_M}[name])
     fs, S, K, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["L"], cfg["B"]
     strong = name == "M"
-    W = args.windows if (args.windows and headline) else (32 if name == "H" else 256)
+    W = args.windows if (args.windows and headline) else (128 if name == "H" else 256)
     if not headline and args.extra_windows:
         W = args.extra_windows
     # --- inputs
+    distinct = W
     if cached is not None and cached["key"] == (fs, S, K, W):
         iq, cs, ce, bw = cached["data"]
     else:
@@ -424,7 +425,7 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "headline": bool(headline),
             "config": {"workload": cfg["name"], "samples_per_window": S, "svs": K, "grid_points_per_manifold_per_gpu": G,
-                       "grid_points_per_manifold_global": G_global, "manifolds": 2, "windows_per_step": W,
+                       "grid_points_per_manifold_global": G_global, "manifolds": 2, "windows_per_step": W, "distinct_windows": distinct,
                        "lag_half_width": L, "bin_half_width": B, "exchange": args.exchange if ctx.use_dist else "none",
                        "stage1": ("sharded by window + bank all-gather" if shard1 else "replicated") if ctx.use_dist else "local",
                        "scores_written": write_scores},
@@ -475,7 +476,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--windows", type=int, default=None, help="windows per step (batch resident in HBM); default 256 (R, M) / 32 (H)")
+    ap.add_argument("--windows", type=int, default=None, help="windows per step (batch resident in HBM); default 256 (R, M) / 128 (H)")
     ap.add_argument("--config", choices=["R", "H", "M"], default=None,
                     help="time only this configuration.  R = BASELINE.json configs[1] (the metric's configuration, the default "
                          "headline); H = configs[2] (25 Msps, 12 SVs, 1e5-point grids); M = configs[3] (1e6-point global grids, "

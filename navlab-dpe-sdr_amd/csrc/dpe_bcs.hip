@@ -829,6 +829,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
 }  // namespace dpe
 
 #include "dpe_bcs_chip.h"   // chip-boundary form of stage 1 (high sampling rates)
+#include "dpe_bcs_chip2.h"  // second form: lanes <-> chips in the prefix stage too (16 .. 25 samples per chip)
 #include "dpe_bcs_fft.h"    // full-length FFT form (fallback for very wide lag / bin windows)
 
 namespace dpe {
@@ -1064,6 +1065,9 @@ struct dpe_bcs {
     bool fuseAllowed = true;     // DPE_BCS_NO_FUSE=1: always the separate DC-sum kernel (A/B tests)
     bool chipAllowed = true;     // DPE_BCS_NO_CHIP=1: never the chip-boundary kernel (A/B tests)
     bool chipOK = false;         // create-time eligibility of the chip-boundary kernel (dpe_bcs_chip.h)
+    bool chip2Allowed = true;    // DPE_BCS_NO_CHIP2=1: never the lanes-as-chips form (dpe_bcs_chip2.h; A/B tests)
+    int chip2Resident = 0;       // co-resident waves of that kernel on the whole device
+    int chip2PForce = 0;         // DPE_BCS_CHIP2_P at create: passes per tile of that kernel (experiments)
     int nPassChip = 0, nBlkAlloc = 0;
     // full-length FFT fallback (dpe_bcs_fft.h): lag windows beyond DPE_MAX_LAG_HALF_WIDTH, bin windows beyond the moment
     // expansion, or DPE_BCS_FORCE_FFT=1 at create (A/B tests)
@@ -1208,6 +1212,9 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         h->chipResident = 12 * cus;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bcs_bank_chip_kernel<6>, 64, 0) == hipSuccess && nb > 0)
             h->chipResident = nb * cus;
+        h->chip2Resident = 11 * cus;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bcs_bank_chip2_kernel<6, 24>, 64, 0) == hipSuccess && nb > 0)
+            h->chip2Resident = nb * cus;
     }
     h->part_d = dev_alloc<float2>(W * K * h->nBlkAlloc * 2 * (2 * h->LH + 1));
     h->mom_d = dev_alloc<float2>(W * K * 2 * h->nSub * kNMomMax);
@@ -1257,6 +1264,8 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
     h->fuseAllowed = getenv("DPE_BCS_NO_FUSE") == nullptr;
     h->chipAllowed = getenv("DPE_BCS_NO_CHIP") == nullptr;
+    h->chip2Allowed = getenv("DPE_BCS_NO_CHIP2") == nullptr;
+    if (const char *e = getenv("DPE_BCS_CHIP2_P")) h->chip2PForce = atoi(e);
     if (const char *e = getenv("DPE_BCS_CHIP_TPB")) h->chipTpbForce = atoi(e);
     if (const char *e = getenv("DPE_BCS_TPB16")) h->tpb16Force = atoi(e);
     if (const char *e = getenv("DPE_BCS_CHIP_DBG")) h->chipDbg = atoi(e);
@@ -1321,6 +1330,19 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     bool chip = h->chipOK && h->chipAllowed;
     for (int i = 0; chip && i < nWindows * nChan; ++i)
         if (6.283185307179586 * std::fabs(chan_host[i].carrierFrequency) > 0.25 * chan_host[i].codeFrequency) chip = false;
+    // second form of the chip kernel (dpe_bcs_chip2.h): every chip 16 .. 25 samples long, and the nav-bit boundary
+    // (BCS_NavBitBoundary :247-253) on a chip boundary of the replica (:347-349) -- it is, unless fp64 rounding separates them
+    bool chip2 = chip && h->chip2Allowed;
+    double stepMax = 0.0;
+    int c2L1 = 0;
+    for (int i = 0; chip2 && i < nWindows * nChan; ++i) {
+        const BcsChanDev &d = h->chan_h[i];
+        const int l1 = (int)d.invStep;   // chips of l1 or l1 + 1 samples; instantiated for 24 (25 Msps) and 19 (20 Msps)
+        if (i == 0) c2L1 = l1;
+        if (l1 != c2L1 || (l1 != 24 && l1 != 19)) chip2 = false;
+        if (d.hasFlip && (int)std::fma((double)d.idxNext, d.codeStep, d.rc) == (int)std::fma((double)(d.idxNext - 1), d.codeStep, d.rc)) chip2 = false;
+        if (d.codeStep > stepMax) stepMax = d.codeStep;
+    }
     h->lastW = nWindows;
     h->lastK = nChan;
     if (h->fftMode) {
@@ -1449,7 +1471,29 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         chipNMom = (std::pow(thc, 4) / 24.0 < 1e-7) ? 4 : 6;
     }
     const int nBlk = chip ? (h->nPassChip + tpb - 1) / tpb : (nTiles + tpb - 1) / tpb;
-    h->lastKernel = chip ? "bcs_bank_chip_kernel" : use16 ? "bcs_bank16_kernel" : wide ? "bcs_bank_wide_kernel" : "bcs_bank_kernel";
+    // second form: a tile = the chips that start inside a nominal range of Lt samples, at most P passes of k2Own chips
+    int c2Lt = 0, c2nBlk = 0, c2NMom = 6;
+    if (chip2) {
+        const double thetaB = 6.283185307179586 * h->cfg.binHalfWidth / (double)h->C;
+        const double halfMax = std::pow(2e-7 * 720.0, 1.0 / 6.0) / thetaB;   // 6-moment Taylor radius (samples)
+        long long best = -1;
+        for (int P = 1; P <= 64; ++P) {
+            const int Lt = (int)std::floor((double)(k2Own * P - 2) / stepMax);
+            if (Lt < 64 || 0.5 * Lt + 26.0 > halfMax) continue;
+            const int nb = (S + Lt - 1) / Lt;
+            if (nb > h->nBlkAlloc) continue;
+            if (h->chip2PForce > 0 && P != h->chip2PForce) continue;
+            const long long waves = (long long)nb * nChan * nWindows;
+            const long long cost = 100 * ((waves + h->chip2Resident - 1) / h->chip2Resident) * P + 6 * nb;
+            if (best < 0 || cost < best) { best = cost; c2Lt = Lt; c2nBlk = nb; }
+        }
+        if (c2Lt == 0) chip2 = false;
+        else {
+            const double thc = thetaB * (0.5 * c2Lt + 26.0);
+            c2NMom = (std::pow(thc, 4) / 24.0 < 1e-7) ? 4 : 6;
+        }
+    }
+    h->lastKernel = chip2 ? "bcs_bank_chip2_kernel" : chip ? "bcs_bank_chip_kernel" : use16 ? "bcs_bank16_kernel" : wide ? "bcs_bank_wide_kernel" : "bcs_bank_kernel";
     const dim3 grid(nBlk, nChan, nWindows), block(256);
     // single windows (<= 37 (window, channel) pairs) with a dense stage-1 kernel: no separate DC-sum launch, the
     // sums ride along in the bank kernel (FUSE) and the finalize kernel applies the mean
@@ -1486,16 +1530,27 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     const int chunkLags = chip ? 64 : 65;
     const int nSideChunks = chip ? (h->cfg.lagHalfWidth > 31 ? (h->cfg.lagHalfWidth - 31 + 63) / 64 : 0)
                                  : (h->cfg.lagHalfWidth > 32 ? (h->cfg.lagHalfWidth - 32 + 64) / 65 : 0);
-    const int nMomUse = chip ? chipNMom : h->nMom;
     for (int chunk = 0; chunk <= 2 * nSideChunks; ++chunk) {
     const int lagShift = chunk == 0 ? 0 : ((chunk + 1) / 2) * chunkLags * ((chunk & 1) ? 1 : -1);
+    const bool c2 = chip2 && lagShift == 0;   // the second form produces the centre chunk; side chunks of a wider window use the first
+    const int nMomUse = c2 ? c2NMom : chip ? chipNMom : h->nMom;
+    const int nBlkUse = c2 ? c2nBlk : nBlk;
+    const int momLenUse = c2 ? c2Lt : chip ? tpb * kPass : kSub;
     h->prof.begin(1, stream);
 #define DPE_LAUNCH_BANK(LHV)            \
     do {                                \
         if (h->nMom == 4) DPE_LAUNCH_BANK2(LHV, 4); \
         else DPE_LAUNCH_BANK2(LHV, 6);  \
     } while (0)
-    if (chip) {
+    if (c2) {
+        const dim3 cgrid(((c2nBlk * nWindows + 7) / 8) * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
+#define DPE_LAUNCH_CHIP2(NM, LV)                                                                                               \
+    hipLaunchKernelGGL((bcs_bank_chip2_kernel<NM, LV>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
+                       nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->part_d, h->mom_d)
+        if (c2L1 == 24) { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, 24); else DPE_LAUNCH_CHIP2(6, 24); }
+        else { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, 19); else DPE_LAUNCH_CHIP2(6, 19); }
+#undef DPE_LAUNCH_CHIP2
+    } else if (chip) {
         const dim3 cgrid(((nBlk * nWindows + 7) / 8) * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
 #define DPE_LAUNCH_CHIP(NM)                                                                                                    \
     hipLaunchKernelGGL((bcs_bank_chip_kernel<NM>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
@@ -1543,8 +1598,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     if (const char *e = getenv("DPE_BCS_FAT")) fatFinalize = nBinBlk <= 4 && e[0] == '1';   // experiments
     const dim3 fgrid((fatFinalize || lagShift != 0) ? 1 : 1 + nBinBlk, nChan, nWindows);
 #define DPE_LAUNCH_FIN(NM, FS)                                                                                          \
-    hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, chip ? nBlk : h->nSub, nBlk, h->LH, \
-                       h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, chip ? tpb * kPass : kSub, chip ? 64 : 65, h->C, h->chan_d, h->part_d, h->mom_d,  \
+    hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, chip ? nBlkUse : h->nSub, nBlkUse, h->LH, \
+                       h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, momLenUse, chip ? 64 : 65, h->C, h->chan_d, h->part_d, h->mom_d,  \
                        h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels, h->momRep_d, h->sums_d, sumSlotsUsed)
     const bool fuseFin = fuse && lagShift == 0;
     if (nMomUse == 4) { if (fuseFin) DPE_LAUNCH_FIN(4, true); else DPE_LAUNCH_FIN(4, false); }

@@ -1,0 +1,366 @@
+// dpe_bcs_chip2.h -- stage 1 for high sampling rates, second form: LANES <-> CHIPS in the prefix stage as well.
+// Included by dpe_bcs.hip after dpe_bcs_chip.h (whose helpers it shares).
+//
+// Reference semantics (cudarecv/modules/src/batchcorrscores.cu): corr[l] = sum_n b[n] r[(n-l) mod S] with b = raw * wipe
+// (:277-305, :402) and r the +-1 code replica (:323-372), both nav-bit sides (:237-258); carrier path
+// c[n] = (raw[n] - mean) wipe[n] r[n] -> zero-padded C-point FFT (:422-452, :1179).
+//
+// bcs_bank_chip_kernel (dpe_bcs_chip.h) gives every lane 17 consecutive samples and then needs three more mappings per
+// pass (chips for the boundary positions, chips again for the Doppler moments -- which re-read every prefix value from
+// LDS for the first moment of each chip -- and lags for the gather).  Here a lane owns one CHIP of the replica:
+//   * its L1 or L1 + 1 samples (L1 = floor(fs / fc), 16 .. 24) are accumulated in the lane's own rotating frame,
+//     u_i = u_(i-1) + raw_i T_i  (T_i = exp(-j 2 pi i fi / fs): two packed FMAs per sample), together with the running sum of
+//     the u_i: zeroth AND first moment of the chip come out of registers (Abel summation) -- no second pass over LDS;
+//   * one 64-lane scan of the chip totals gives every chip its offset; Q = w_chip u_i + offset goes to LDS (two packed FMAs
+//     and one ds_write_b64 per sample) as the pass-local prefix array, centred (Q runs from -T/2 to +T/2: half the magnitude,
+//     half the fp32 rounding of the boundary differences under a DC offset);
+//   * the chip boundaries ARE the lanes' first samples: positions, replica values and sign changes need no second mapping;
+//     lag sums as in the first form, corr_pass[l] = (r_first + r_last) T/2 + sum_i J_i Q[e_i + l] with lanes <-> the 64 lags.
+// A pass = 57 chips (lanes 3 .. 59); lanes 0 .. 2 and 60 .. 63 carry the chips either side of the pass whose boundaries the
+// +-32-lag window still reaches (two before and three after are needed where the window wraps around circularly and the
+// partial chips at its ends are short) -- they own no samples.  The circular wrap and the nav-bit boundary need no special
+// path: a lane beyond the window's last chip takes the chip the circular continuation puts there, and the two nav-bit
+// sides are two masked copies of the replica values (the host only selects this kernel when the nav-bit boundary falls on
+// a chip boundary, which it does unless fp64 rounding separates BCS_NavBitBoundary :247-253 from the chip index :347-349).
+// A wave walks the passes of one TILE: the chips that start inside [blk Lt, (blk+1) Lt); the tile's moment block is taken
+// about the centre of that nominal range, so bcs_finalize_kernel sees the layout of the first form (momLen = Lt).
+// Per pass of ~1400 samples: ~370 VALU + ~60 LDS instructions against 448 + 78 per 1088 samples of the first form.
+#pragma once
+
+namespace dpe {
+
+#ifndef DPE_C2_WAVES
+#define DPE_C2_WAVES 3
+#endif
+#ifndef DPE_C2_GB
+#define DPE_C2_GB 8
+#endif
+constexpr int k2Own0 = 3;      // first owner lane
+constexpr int k2Own = 57;      // owner lanes per pass
+constexpr int k2MaxL1 = 24;    // L1 = floor(fs / fc) <= 24: chips of at most 25 samples
+constexpr int k2MinL1 = 16;    // the margins reach +-32 samples: two regular chips must cover them
+constexpr int k2Pad = 64;
+constexpr int k2QLen = k2Pad + k2Own * (k2MaxL1 + 1) + 1 + 64;
+
+template <int kNMom, int L1>
+__global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
+                                                               int S, int K, int nW, int Lt, int nBlk, int nSumBlk,
+                                                               const BcsChanDev *__restrict__ chan,
+                                                               const long long *__restrict__ sums,
+                                                               const int8_t *__restrict__ chipTable,
+                                                               float2 *__restrict__ part, float2 *__restrict__ mom)
+{
+    constexpr int NL = 65;   // partial layout shared with the other stage-1 kernels: entry j <-> lag j - 32 (j = 64 unused)
+    __shared__ float2 sQ[k2QLen];
+    __shared__ __align__(16) float2 sRot[32];
+    __shared__ float2 sList[64 + 8];   // flips of a pass: {J, byte offset into sQ}
+
+    // Block -> (window, tile, SV), XCD-aware as in the first form: the K blocks of a tile are congruent mod 8
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x >> 3, k = slot % K, tg = (slot / K) * 8 + (blockIdx.x & 7);
+    if (tg >= nBlk * nW) return;
+    const int w = tg / nBlk, blk = tg - w * nBlk;
+    (void)pb;
+    const BcsChanDev ch = params_ptr(chan, inl)[(size_t)w * K + k];
+    const int8_t *chips = chipTable + (ch.prn - 1) * 1024;
+    float mRe, mIm;
+    window_mean(sums, w, nSumBlk, S, mRe, mIm);
+    const f2 meanv = f2{mRe, mIm};
+    const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);
+
+    // chip index of replica index m (phases are >= 0: the truncating conversion is the floor, :347-349)
+    auto chip_at = [&](int m) -> int { return (int)fma((double)m, ch.codeStep, ch.rc); };
+    // first replica index of chip c: min { m : chip_at(m) >= c }
+    auto first_index = [&](int c) -> int {
+        const double md = ceil(((double)c - ch.rc) * ch.invStep);
+        int m = (int)md;
+        if ((int)fma(md - 1.0, ch.codeStep, ch.rc) >= c) m -= 1;
+        else if ((int)fma(md, ch.codeStep, ch.rc) < c) m += 1;
+        return m;
+    };
+    static_assert(L1 >= k2MinL1 && L1 <= k2MaxL1, "chips of L1 or L1 + 1 samples, L1 = floor(fs / fc) (the host checks every channel)");
+    const int c0 = __builtin_amdgcn_readfirstlane(chip_at(0)), cEnd = __builtin_amdgcn_readfirstlane(chip_at(S - 1));
+    const int Nc = cEnd - c0 + 1;                                            // chips (partial ones included) of the window
+    // the tile's chips: those that START inside [blk Lt, (blk + 1) Lt) -- the window's first, partial chip starts at 0
+    const int cLo = blk == 0 ? c0 : __builtin_amdgcn_readfirstlane(chip_at(blk * Lt - 1)) + 1;
+    const int cHi = blk == nBlk - 1 ? cEnd + 1 : __builtin_amdgcn_readfirstlane(chip_at((blk + 1) * Lt - 1)) + 1;
+    const int nPassT = (cHi - cLo + k2Own - 1) / k2Own;
+
+    // ---- once per block: the SV's twiddles T_i (i < 26), the two centre twiddles of regular chips
+    if (lane < 28) {
+        const double a = lane < 26 ? (double)lane : (lane == 26 ? 0.5 * (double)(L1 - 1) : 0.5 * (double)L1);
+        double ph = a * ch.carrStep;
+        ph -= floor(ph);
+        const f2 t = wipe_seed((float)ph);
+        sRot[lane] = make_float2(t.x, t.y);
+    }
+    float2 *momOut = mom + ((((size_t)w * K + k) * 2) * nBlk + blk) * kNMom;   // [side][nBlk][kNMom]
+    const size_t momSide = (size_t)nBlk * kNMom;
+    __builtin_amdgcn_wave_barrier();
+    const f2 thA = f2{sRot[26].x, sRot[26].y}, thB = f2{sRot[27].x, sRot[27].y};
+
+    const int qLaneBytes = 8 * ((k2Pad - 32) + lane);   // byte offset in sQ of lag (lane - 32)'s entry for a boundary at the pass start
+    const float phi = (float)(6.283185307179586476925286766559 * ch.carrStep);   // wipe-off phase step per sample (rad)
+    // DC-mean sums over a chip of len samples about its centre: G0 = sum exp(-j phi d) (real), j G1 = sum d exp(-j phi d)
+    auto mean_sums = [&](float fl, float &G0, float &G1) {
+        const float l2 = fl * fl, h2 = 0.25f * phi * phi;
+        G0 = fl * (1.f - (l2 - 1.f) * h2 * (1.f / 6.f) * (1.f - (3.f * l2 - 7.f) * h2 * (1.f / 60.f)));
+        G1 = -phi * fl * (l2 - 1.f) * (1.f / 12.f) * (1.f - phi * phi * (3.f * l2 - 7.f) * (1.f / 120.f));
+    };
+    float G0a, G1a, G0b, G1b;
+    mean_sums((float)L1, G0a, G1a);
+    mean_sums((float)(L1 + 1), G0b, G1b);
+    const float xOrigin = 0.5f * (float)(Lt - 1);   // moment abscissa origin relative to the tile's nominal start blk Lt
+
+    f2 accS[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};   // lag sums of the two nav-bit sides, lane <-> lag
+    f2 M[kNMom];                                  // per-lane moment sums of the current side
+#pragma unroll
+    for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
+    int curSide = 0, flushed = 0;
+    auto flush = [&](int side) {   // reduce the lanes' moment sums and store the (tile, side) block
+        flushed |= 1 << side;
+        float mm[2 * kNMom];
+#pragma unroll
+        for (int p = 0; p < kNMom; ++p) { mm[2 * p] = M[p].x; mm[2 * p + 1] = M[p].y; }
+        dpp_sum_lane63(mm);
+        if (lane == 63) {
+#pragma unroll
+            for (int p = 0; p < kNMom; ++p) momOut[side * momSide + p] = make_float2(mm[2 * p], mm[2 * p + 1]);
+        }
+#pragma unroll
+        for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
+    };
+    auto add_moments = [&](f2 E0, f2 E1, float xb) {   // a chip's zeroth / first moment about its own centre xb
+        M[0] += E0;
+        f2 xp = E0 * xb;
+        f2 xq = E1;
+#pragma unroll
+        for (int p = 1; p < kNMom; ++p) {
+            M[p] += xp + xq * (float)p;
+            xp *= xb;
+            xq *= xb;
+        }
+    };
+
+    // ---- lane state of a pass: chip c = cBase - k2Own0 + lane, circularly continued beyond the window's ends
+    int eN = 0, offN = 0, lenN = 0, eAN = 0, eBN = 0;
+    int8_t rN = 0;
+    bool ownN = false, edgeN = false;
+    int raw[L1], rawX = 0;
+    auto setup = [&](int cBase) {
+        const int c = cBase - k2Own0 + lane;
+        int cw = c, off = 0;
+        if (c < c0) { cw = c + Nc; off = -S; }
+        else if (c > cEnd) { cw = c - Nc; off = S; }
+        const int e = (cw == c0) ? 0 : first_index(cw);   // the window's first chip begins before sample 0: clipped
+        eN = e + off;
+        offN = off;
+        rN = chips[cw % kLCA];
+        const int nOwn = (cHi - cBase < k2Own) ? cHi - cBase : k2Own;
+        const int eNext = __builtin_amdgcn_update_dpp(0, eN, 0x130, 0xf, 0xf, true);   // wave_shl:1 -> lane + 1
+        ownN = lane >= k2Own0 && lane < k2Own0 + nOwn;
+        lenN = ownN ? eNext - eN : 0;
+        eAN = __builtin_amdgcn_readlane(eN, k2Own0);
+        eBN = __builtin_amdgcn_readlane(eN, k2Own0 + nOwn);
+        // regular pass: every owner has L1 or L1 + 1 samples and may read L1 + 1 of them without leaving the window
+        edgeN = __ballot(ownN && ((lenN != L1 && lenN != L1 + 1) || eN + L1 + 1 > S)) != 0ull;
+    };
+    auto fetch = [&]() {
+        if (!edgeN) {
+            int eb = ownN ? eN : 0;
+            const int *px = x + eb;
+#pragma unroll
+            for (int i = 0; i < L1; ++i) raw[i] = px[i];
+            rawX = px[L1];
+        } else {
+            asm volatile("" ::: "memory");   // (keeps the two forms apart: merged, every load carries its own selected address)
+            const int eb = ownN ? eN : 0;
+#pragma unroll
+            for (int i = 0; i < L1; ++i) raw[i] = x[(eb + i < S) ? eb + i : S - 1];
+            rawX = x[(eb + L1 < S) ? eb + L1 : S - 1];
+            asm volatile("" ::: "memory");
+        }
+    };
+    setup(cLo);
+    fetch();
+
+    for (int p = 0; p < nPassT; ++p) {
+        const int e = eN, off = offN, len = lenN, eA = eAN, eB = eBN;
+        const bool own = ownN, edge = edgeN;
+        const float r = (float)rN;
+        const int sd = (ch.hasFlip && e - off >= ch.idxNext) ? 1 : 0;
+
+        // ---- 1. the chip's samples in the lane's rotating frame: u_i, and vv = sum of all u_i (first moment, by Abel summation)
+        f2 u[L1], uX, run = f2{0.f, 0.f}, vv = f2{0.f, 0.f};
+        {
+            const float2 tX = sRot[L1];
+            // (twiddles: two per 16-byte broadcast read (wave-uniform address), fetched four slots at a time -- all twelve reads
+            // up front would hold 48 registers beside the 50 of u[])
+            auto slots = [&](auto edgeTag) {
+                constexpr bool kEdge = decltype(edgeTag)::value;
+#pragma unroll
+                for (int g = 0; g < (L1 + 3) / 4; ++g) {
+                    const float4 ta = reinterpret_cast<const float4 *>(sRot)[2 * g], tb = reinterpret_cast<const float4 *>(sRot)[2 * g + 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * g + j;
+                        if (i < L1) {
+                            const float4 t4 = j < 2 ? ta : tb;
+                            const f2 tt = (j & 1) ? f2{t4.z, t4.w} : f2{t4.x, t4.y};
+                            const int rv = (!kEdge || i < len) ? raw[i] : 0;
+                            const f2 si = f2{(float)(short)(rv & 0xFFFF), (float)(rv >> 16)};
+                            run = cmul_add(si, tt, run);
+                            u[i] = run;
+                            vv += run;
+                        }
+                    }
+                    // keeps the next group's twiddle reads and sample conversions behind this group's arithmetic: hoisted
+                    // to the top they would hold ~100 registers beside the 50 of u[]
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (!edge) slots(std::false_type{});
+            else slots(std::true_type{});
+            const int rv = len > L1 ? rawX : 0;
+            const f2 si = f2{(float)(short)(rv & 0xFFFF), (float)(rv >> 16)};
+            run = cmul_add(si, f2{tX.x, tX.y}, run);
+            uX = run;
+            vv += run;
+        }
+        // ---- 2. chip offsets: wipe-off at the chip's first sample, 64-lane scan of the chip totals, Q -> LDS (centred)
+        double ph = fma((double)(own ? e : 0), ch.carrStep, ch.ri);
+        ph -= floor(ph);
+        const f2 wl = wipe_seed((float)ph);
+        f2 tot = cmul(wl, run);
+        tot = own ? tot : f2{0.f, 0.f};
+        float incRe = tot.x, incIm = tot.y;
+        wave_scan_incl2(incRe, incIm);
+        const f2 T = f2{readlane_f(incRe, 63), readlane_f(incIm, 63)};
+        const f2 half = T * 0.5f;
+        const f2 qoff = f2{incRe, incIm} - tot - half;
+        sQ[lane] = make_float2(-half.x, -half.y);                           // lower clamp pad: entries 0 .. k2Pad
+        if (lane == 0) sQ[k2Pad] = make_float2(-half.x, -half.y);
+        sQ[k2Pad + (eB - eA) + 1 + lane] = make_float2(half.x, half.y);     // upper clamp pad
+        if (own) {
+            float2 *q = sQ + k2Pad + (e - eA) + 1;
+            auto store = [&](auto edgeTag) {
+                constexpr bool kEdge = decltype(edgeTag)::value;
+#pragma unroll
+                for (int i = 0; i < L1; ++i) {
+                    if (!kEdge || i < len) {
+                        const f2 v = cmul_add(wl, u[i], qoff);
+                        q[i] = make_float2(v.x, v.y);
+                    }
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four products in flight, not twenty-four)
+                }
+            };
+            if (!edge) store(std::false_type{});
+            else store(std::true_type{});
+            if (len > L1) {
+                const f2 v = cmul_add(wl, uX, qoff);
+                q[L1] = make_float2(v.x, v.y);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // same-wave DS operations complete in order; this only pins the compiler
+        // ---- the next pass's chips and samples: issued here (u[] is dead, its registers take the samples), they arrive under
+        // the moments and the gather of this pass
+        if (p + 1 < nPassT) {
+            setup(cLo + (p + 1) * k2Own);
+            fetch();
+        }
+
+        // ---- 3. Doppler moments of the owned chips, from registers
+        {
+            const float lenf = (float)len;
+            // first moment about the chip centre: w ((L1 + 1 + (1 - len) / 2) u_last - vv)   (vv holds L1 + 1 terms; slots beyond
+            // the chip repeat u_last)
+            const float kf = (float)(L1 + 1) + 0.5f * (1.f - lenf);
+            const f2 D1 = cmul(wl, run * kf - vv);
+            f2 wc;
+            float G0, G1;
+            if (!edge) {
+                wc = cmul(wl, len == L1 ? thA : thB);
+                G0 = len == L1 ? G0a : G0b;
+                G1 = len == L1 ? G1a : G1b;
+            } else {
+                double pc = fma((double)(own ? e : 0) + 0.5 * (double)(len - 1), ch.carrStep, ch.ri);
+                pc -= floor(pc);
+                wc = wipe_seed((float)pc);
+                mean_sums(lenf, G0, G1);
+            }
+            const f2 mw = cmul(meanv, wc);
+            const float rOwn = own ? r : 0.f;
+            const f2 E0 = (tot - mw * G0) * rOwn;
+            const f2 E1 = (D1 - f2{-mw.y, mw.x} * G1) * rOwn;
+            const float xb = (float)(e - blk * Lt) - xOrigin + 0.5f * (lenf - 1.f);
+            const bool any0 = __ballot(own && sd == 0) != 0ull, any1 = __ballot(own && sd == 1) != 0ull;
+            if (any0) {
+                const float m0 = sd == 0 ? 1.f : 0.f;
+                add_moments(E0 * m0, E1 * m0, xb);
+            }
+            if (any1) {
+                if (curSide == 0) { flush(0); curSide = 1; }
+                const float m1 = sd == 1 ? 1.f : 0.f;
+                add_moments(E0 * m1, E1 * m1, xb);
+            }
+        }
+
+        // ---- 4. lag sums per nav-bit side: the flips among the boundaries the lag window reaches
+        const bool inReach = lane >= 1 && e > eA - 32 && e < eB + 32;
+        const unsigned long long rm = __ballot(inReach);
+        const int firstIn = __builtin_ctzll(rm), lastIn = 63 - __builtin_clzll(rm);
+        // sides present among the chips in reach (and the one before them, whose value enters the first difference): a pass
+        // away from the nav-bit boundary has one
+        const unsigned long long near = rm | (rm >> 1);
+        const unsigned long long s1m = __ballot(sd != 0) & near;
+        const int sideFirst = (s1m == near) ? 1 : 0, sideLast = (s1m != 0ull) ? 1 : 0;
+        for (int s = sideFirst; s <= sideLast; ++s) {
+            const float rs = (sd == s) ? r : 0.f;
+            const float rsPrev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x138, 0xf, 0xf, true));   // wave_shr:1 -> lane - 1
+            const float J = inReach ? rsPrev - rs : 0.f;
+            const unsigned long long bm = __ballot(J != 0.f);
+            const float rF = readlane_f(rs, firstIn - 1), rL = readlane_f(rs, lastIn);
+            const int nb = __builtin_popcountll(bm);
+            {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+                if ((bm >> lane) & 1ull) sList[rank] = make_float2(J, __builtin_bit_cast(float, 8 * (e - eA)));
+                if (lane < 8) sList[nb + lane] = make_float2(0.f, 0.f);
+                __builtin_amdgcn_wave_barrier();
+            }
+            f2 acc = f2{0.f, 0.f};
+            constexpr int GB = DPE_C2_GB;   // list entries per batch of independent LDS reads
+            for (int i0 = 0; i0 < nb; i0 += GB) {
+                float2 ent[GB], qv[GB];
+#pragma unroll
+                for (int j = 0; j < GB; ++j) ent[j] = sList[i0 + j];
+#pragma unroll
+                for (int j = 0; j < GB; ++j)
+                    qv[j] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(sQ) + (qLaneBytes + __builtin_bit_cast(int, ent[j].y)));
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    const f2 ej = f2{ent[j].x, ent[j].y}, qj = f2{qv[j].x, qv[j].y};
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(qj), "v"(ej));   // acc += q * J (J = low half of the entry)
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the next side / pass rewrites the list
+            // end terms: the centred prefix is -T/2 before the first and +T/2 behind the last boundary in reach
+            const float rEnds = rF + rL;
+            acc = __builtin_elementwise_fma(half, f2{rEnds, rEnds}, acc);
+            accS[0] += s == 0 ? acc : f2{0.f, 0.f};
+            accS[1] += s == 1 ? acc : f2{0.f, 0.f};
+        }
+        __builtin_amdgcn_wave_barrier();   // the next pass overwrites sQ
+    }
+    flush(curSide);
+    for (int side = 0; side < 2; ++side)   // a side without samples in this tile: zero block
+        if (!((flushed >> side) & 1) && lane < kNMom) momOut[side * momSide + lane] = make_float2(0.f, 0.f);
+    // ---- block partial of the lag sums (one wave: nothing to reduce)
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        float2 *o = part + ((((size_t)w * K + k) * nBlk + blk) * 2 + side) * NL;
+        o[lane] = make_float2(accS[side].x, accS[side].y);
+        if (lane == 0) o[64] = make_float2(0.f, 0.f);
+    }
+}
+
+}  // namespace dpe

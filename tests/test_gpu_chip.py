@@ -36,6 +36,7 @@ def _banks(case, L, B, env=None):
     bcs.profile(True)
     bcs.Update(d, cs)
     prof = bcs.profile(False)
+    prof["kernel"] = bcs.stage1_kernel
     bcs.Stop()
     return code, carr, info, prof
 
@@ -44,19 +45,21 @@ def _check(case, L, B, tol=TOL):
     from oracle import oracle as o
     code, carr, info, _ = _banks(case, L, B)
     code0, carr0, info0, _ = _banks(case, L, B, {"DPE_BCS_NO_CHIP": "1"})
+    code1, carr1, info1, p1 = _banks(case, L, B, {"DPE_BCS_NO_CHIP2": "1"})     # the first form of the chip kernel
+    assert p1["kernel"] != "bcs_bank_chip2_kernel"
     worst = 0.0
     for wi, w in enumerate(case["wins"]):
         s = w["start"]
         for k in range(case["K"]):
             c, f, inf = o.bcs_sv(w["iq"], case["fs"], int(s["prn"][k]), s["rc"][k], s["ri"][k], s["fc"][k], s["fi"][k],
                                  int(s["cp"][k]), int(s["cp_ref"][k]), -L, L, -B, B, case["C"])
-            for got, ref in ((code[wi][k], c), (carr[wi][k], f), (code0[wi][k], c), (carr0[wi][k], f)):
+            for got, ref in ((code[wi][k], c), (carr[wi][k], f), (code0[wi][k], c), (carr0[wi][k], f), (code1[wi][k], c), (carr1[wi][k], f)):
                 err = np.abs(got - ref).max() / np.abs(ref).max()
                 worst = max(worst, err)
                 assert err < tol, "window %d SV %d: rel err %.3g" % (wi, k, err)
             assert info[0][wi, k] == inf["idx_next"] and bool(info[1][wi, k]) == inf["no_flip_larger"]
-            assert bool(info0[1][wi, k]) == inf["no_flip_larger"]
-        assert info[2][wi] == info0[2][wi] == inf["mean"]          # DC mean: exact integer sums in both paths
+            assert bool(info0[1][wi, k]) == inf["no_flip_larger"] and bool(info1[1][wi, k]) == inf["no_flip_larger"]
+        assert info[2][wi] == info0[2][wi] == info1[2][wi] == inf["mean"]          # DC mean: exact integer sums in both paths
     return worst
 
 
@@ -78,8 +81,10 @@ def test_chip_kernel_really_runs_and_is_selected_for_config_h():
     cfg = dpe.workload.CONFIG_H
     case = helpers.make_case(seed=21, fs=cfg["fs"], S=cfg["S"], K=cfg["K"], G=64, amp=cfg["amp"], W=4)
     _, _, _, p1 = _banks(case, cfg["L"], cfg["B"])
+    _, _, _, p2 = _banks(case, cfg["L"], cfg["B"], {"DPE_BCS_NO_CHIP2": "1"})
     _, _, _, p0 = _banks(case, cfg["L"], cfg["B"], {"DPE_BCS_NO_CHIP": "1"})
-    print("bank ms: chip %.4f, per-sample %.4f" % (p1["bcs_bank"][0], p0["bcs_bank"][0]))
+    print("bank ms: chip2 %.4f, chip %.4f, per-sample %.4f" % (p1["bcs_bank"][0], p2["bcs_bank"][0], p0["bcs_bank"][0]))
+    assert p1["kernel"] == "bcs_bank_chip2_kernel" and p2["kernel"] == "bcs_bank_chip_kernel"     # 24.4 samples per chip: lanes <-> chips
     assert p1["bcs_bank"][0] < 0.8 * p0["bcs_bank"][0]
     worst = _check(case, cfg["L"], cfg["B"])
     print("config H (4 windows) worst rel err", worst)
@@ -108,9 +113,15 @@ def test_chip_kernel_every_pass_per_block_count_gives_the_same_banks():
     """The moment block is the wave's tile of tpb passes (finalize is told its length): tpb = 1, 3 and the default must
     agree to fp32 rounding, nav-bit boundary inside a tile included."""
     case = helpers.make_case(seed=18, fs=25e6, S=250000, K=3, G=64, amp=80.0, flips=[True, False, True])
+    ref_code, ref_carr, _, _ = _banks(case, 31, 16, {"DPE_BCS_NO_CHIP2": "1"})
+    for tpb in ("1", "3", "7"):
+        code, carr, _, _ = _banks(case, 31, 16, {"DPE_BCS_CHIP_TPB": tpb, "DPE_BCS_NO_CHIP2": "1"})
+        for k in range(3):
+            assert np.abs(code[0][k] - ref_code[0][k]).max() < TOL * np.abs(ref_code[0][k]).max()
+            assert np.abs(carr[0][k] - ref_carr[0][k]).max() < TOL * np.abs(ref_carr[0][k]).max()
     ref_code, ref_carr, _, _ = _banks(case, 31, 16)
     for tpb in ("1", "3", "7"):
-        code, carr, _, _ = _banks(case, 31, 16, {"DPE_BCS_CHIP_TPB": tpb})
+        code, carr, _, _ = _banks(case, 31, 16, {"DPE_BCS_CHIP_TPB": tpb, "DPE_BCS_CHIP2_P": tpb})
         for k in range(3):
             assert np.abs(code[0][k] - ref_code[0][k]).max() < TOL * np.abs(ref_code[0][k]).max()
             assert np.abs(carr[0][k] - ref_carr[0][k]).max() < TOL * np.abs(ref_carr[0][k]).max()
