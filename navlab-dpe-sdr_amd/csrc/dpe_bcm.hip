@@ -431,6 +431,7 @@ struct dpe_bcm {
     double *wsum_d = nullptr;   // [W][2][split][5] per-block weighted sums
     unsigned long long *keys_h = nullptr, *oob_h = nullptr;   // pinned mirrors, filled by async copies at the end of Update
     unsigned lastSplit[2] = {0, 0};
+    int splitForce = 0;                     // -DDPE_EXPERIMENTS builds only: DPE_BCM_SPLIT at create
     static constexpr unsigned kMaxSplit = 4096;
     size_t wsumHalf = 0;
     // referencePair mode (dpe_bcm_config): active only when S / 2 is a power of two
@@ -462,7 +463,7 @@ static int upload_grid(const double *src, int64_t G, std::vector<double> &keep, 
 
 // Blocks along x per window: ~4096 blocks in flight overall for batches, a multiple of 8 (XCD round robin, see the
 // kernel) and never more than the number of 1024-point tiles.
-static unsigned scan_split(long long G, int nWindows)
+static unsigned scan_split(long long G, int nWindows, int forced)
 {
     const long long nTiles = (G + dpe::kPtsPerBlock - 1) / dpe::kPtsPerBlock;
     long long s = 4096 / nWindows;
@@ -477,7 +478,7 @@ static unsigned scan_split(long long G, int nWindows)
         const long long cap = 768 / nWindows > 24 ? 768 / nWindows : 24;
         if (s > cap) s = cap;
     }
-    if (const char *e = getenv("DPE_BCM_SPLIT")) s = atoi(e);   // experiments
+    if (forced > 0) s = forced;   // (-DDPE_EXPERIMENTS builds: DPE_BCM_SPLIT, read at create)
     if (s < 8) s = 8;
     s = (s + 7) / 8 * 8;
     if (s > nTiles) s = nTiles;
@@ -741,6 +742,9 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->oob_h = h->keys_h + 2 * W;
     for (size_t i = 0; i < 4 * W + 8; ++i) h->keys_h[i] = 0ull;
     h->pollAllowed = getenv("DPE_BCM_NO_POLL") == nullptr;
+#ifdef DPE_EXPERIMENTS
+    if (const char *e = getenv("DPE_BCM_SPLIT")) h->splitForce = atoi(e) > 0 && atoi(e) <= (int)dpe_bcm::kMaxSplit ? atoi(e) : 0;
+#endif
     h->sv_h = h->svBase_h;
     const auto finish = [&]() -> int {   // a failure from here on must not leak the handle
         for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -842,8 +846,8 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
         }
     }
     h->lastW = nWindows;
-    h->lastSplit[0] = scan_split(h->cfg.posGridSize, nWindows);
-    h->lastSplit[1] = scan_split(h->cfg.velGridSize, nWindows);
+    h->lastSplit[0] = scan_split(h->cfg.posGridSize, nWindows, h->splitForce);
+    h->lastSplit[1] = scan_split(h->cfg.velGridSize, nWindows, h->splitForce);
     // Two key / counter sets alternate between Updates: this call reduces into set `cur` (zero since it
     // was cleared by the previous call's position scan, or by create) and clears the other one.
     // (h->cur only advances once the launch is enqueued: a call that fails earlier must not skip a clearing)

@@ -1075,7 +1075,8 @@ struct dpe_bcs {
     hipfftHandle planS3 = 0, planS2 = 0, planC = 0;   // length S: batch 3 chunk K (forward) / 2 chunk K (inverse); length C: batch chunk K
     int fftChunkW = 1;
     float2 *fftWork_d = nullptr;
-    int chipDbg = 0;                   // DPE_BCS_CHIP_DBG: skips parts of the chip kernel (timing experiments; wrong results)
+    int chipDbg = 0;                   // -DDPE_EXPERIMENTS builds only, DPE_BCS_CHIP_DBG: skips parts of the chip kernel (timing; wrong results)
+    int fatForce = -1;                 // -DDPE_EXPERIMENTS builds only, DPE_BCS_FAT at create: finalize block shape (0 split, 1 fat)
     int chipTpbForce = 0;              // DPE_BCS_CHIP_TPB at create: passes per wave of the chip kernel (experiments)
     int tpb16Force = 0;                // DPE_BCS_TPB16 at create: tiles per block of the 16-samples-per-lane kernel (experiments)
     int resident16 = 1024;             // co-resident blocks of the 16-samples-per-lane kernel on the whole device
@@ -1268,7 +1269,10 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     if (const char *e = getenv("DPE_BCS_CHIP2_P")) h->chip2PForce = atoi(e);
     if (const char *e = getenv("DPE_BCS_CHIP_TPB")) h->chipTpbForce = atoi(e);
     if (const char *e = getenv("DPE_BCS_TPB16")) h->tpb16Force = atoi(e);
+#ifdef DPE_EXPERIMENTS   // ablation switches: never in the product library (the first one makes the banks wrong)
     if (const char *e = getenv("DPE_BCS_CHIP_DBG")) h->chipDbg = atoi(e);
+    if (const char *e = getenv("DPE_BCS_FAT")) h->fatForce = e[0] == '1' ? 1 : 0;
+#endif
     *out = h;
     return 0;
 }
@@ -1595,7 +1599,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     // side chunks of a wide lag window: one block per (window, SV), code-bank entries only
     // (crossover measured in round 2: 96 / 128 (window, SV) pairs are faster split, 192 / 256 / 384 fat -- H at 32 windows 0.0205 -> 0.0113 ms)
     bool fatFinalize = nBinBlk <= 4 && (long long)nChan * nWindows >= 192;
-    if (const char *e = getenv("DPE_BCS_FAT")) fatFinalize = nBinBlk <= 4 && e[0] == '1';   // experiments
+    if (h->fatForce >= 0) fatFinalize = nBinBlk <= 4 && h->fatForce == 1;   // (experiment builds)
     const dim3 fgrid((fatFinalize || lagShift != 0) ? 1 : 1 + nBinBlk, nChan, nWindows);
 #define DPE_LAUNCH_FIN(NM, FS)                                                                                          \
     hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, chip ? nBlkUse : h->nSub, nBlkUse, h->LH, \

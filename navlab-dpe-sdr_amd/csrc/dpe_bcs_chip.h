@@ -62,7 +62,7 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 
 template <int kNMom>
 __global__ __launch_bounds__(64, 4) void bcs_bank_chip_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
-                                                              int S, int K, int nW, int nPass, int tpb, int nBlk, int nSumBlk, int lagShift, int dbg,
+                                                              int S, int K, int nW, int nPass, int tpb, int nBlk, int nSumBlk, int lagShift, int dbgArg,
                                                               const BcsChanDev *__restrict__ chan,
                                                               const long long *__restrict__ sums,
                                                               const int8_t *__restrict__ chipTable,
@@ -87,7 +87,13 @@ __global__ __launch_bounds__(64, 4) void bcs_bank_chip_kernel(BcsParamBlock pb, 
     window_mean(sums, w, nSumBlk, S, mRe, mIm);
     const f2 meanv = f2{mRe, mIm};
     const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);
-    const bool doMom = lagShift == 0 && !(dbg & 1);   // dbg: timing experiments only (DPE_BCS_CHIP_DBG), results are then wrong
+#ifdef DPE_EXPERIMENTS
+    const int dbg = dbgArg;   // timing ablations (DPE_BCS_CHIP_DBG): stages are skipped, the results are then wrong
+#else
+    constexpr int dbg = 0;    // the product library has no such switch
+    (void)dbgArg;
+#endif
+    const bool doMom = lagShift == 0 && !(dbg & 1);
 
     // ---- once per block: lower clamp pad (Q = 0 at and before the pass start), the SV's twiddles T_i, zeroed moment slots
     sQ[lane] = make_float2(0.f, 0.f);
