@@ -230,7 +230,13 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     write_scores = (not args.no_scores) or args.exchange == "scores"
     # --- stage-1 sharding by window
     # (the 1-rank RCCL self-test keeps the all-gather in the loop: a gather over one rank is a copy through the same calls)
-    shard1 = ctx.use_dist and args.stage1 == "sharded" and W % world == 0
+    if ctx.use_dist and args.stage1 == "sharded" and W % world != 0:
+        # (no silent fallback to replicated stage 1: the line would describe another exchange than the one asked for)
+        if rank == 0:
+            sys.stderr.write("bench.py: --stage1 sharded needs the %d windows of a step to divide over the %d ranks "
+                             "(use --windows / --extra-windows, or --stage1 replicated)\n" % (W, world))
+        sys.exit(2)
+    shard1 = ctx.use_dist and args.stage1 == "sharded"
     Wl = W // world if shard1 else W
     w0 = rank * Wl if shard1 else 0
     iq_d = torch.from_numpy(np.ascontiguousarray(iq[w0:w0 + Wl])).to(dev)     # inputs resident in HBM before the timed region
@@ -359,6 +365,7 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     else:
         res = bcm.results()
     assert all(np.isfinite(r["zVal"]).all() for r in res)
+    fixes = [[int(r["posIndex"]), int(r["velIndex"]), float(r["posScore"]), float(r["velScore"])] for r in res[:16]]
     if world == 1:
         assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res), "bank window too narrow"
 
@@ -441,6 +448,9 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
                          "note": "algorithmic bytes (SURVEY 8d) over the kernel's HIP-event time; bound_physical names the "
                                  "measured limiter (SQ counters under profiles/), the kernels are not HBM-bound"},
             "kernels_ms_per_step": kernels_ms, "stage1_kernel": stage1,
+            # the decoded ML grid points (global indices, scores) of the last step's first windows: the same for every rank
+            # count that scans the same global grid (config M), which is what the multi-rank tests compare
+            "fixes": fixes,
         }
         if pcie_value is not None:
             out["pcie_inclusive_value"] = pcie_value

@@ -6,8 +6,10 @@
 //   dpe_flow --samples f.dat --handoff handoff.csv --out X.csv [--fs 2.5e6] [--T 0.02] [--iters 3000]
 //            [--grid-dim 25] [--spacing 1.0] [--grid-type 0|2] [--load-grid rngrid.csv] [--lpower 1]
 //            [--init-delta dx dy dz dt]
-//            [--ranks N --rank r --rendezvous DIR [--comm rccl|files] [--device d]]   one flow per GPU: grid shard r of N,
-//                                                arg-max exchanged through dpe_bcm_exchange_keys (RCCL, or host files for tests)
+//            [--ranks N --rank r --rendezvous DIR [--comm rccl|files] [--device d] [--shard-stage1]]
+//                                                one flow per GPU: grid shard r of N, arg-max exchanged through
+//                                                dpe_bcm_exchange_keys (RCCL, or host files for tests); --shard-stage1: each
+//                                                flow correlates K / N of the channels, dpe_bcs_allgather_banks completes the banks
 //   dpe_flow --dump-grid <type> <dim> <spacing> <out.bin>        (grid builders only, no GPU)
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +32,7 @@ int main(int argc, char **argv)
     int ranks = 1, rank = 0, device = -1;
     double fs = 2.5e6, T = 0.02;
     int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
-    bool useGraph = false, timing = false, enableEkf = false;
+    bool useGraph = false, timing = false, enableEkf = false, shardStage1 = false;
     float spacing = 1.0f, delta[4] = {0, 0, 0, 0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -83,6 +85,7 @@ int main(int argc, char **argv)
         else if (a == "--comm") { commName = next(); ++i; }
         else if (a == "--device") { device = std::atoi(next()); ++i; }
         else if (a == "--graph") { useGraph = true; }
+        else if (a == "--shard-stage1") { shardStage1 = true; }
         else if (a == "--timing") { timing = true; }
         else if (a == "--ekf") { enableEkf = true; }
         else if (a == "--init-delta") { next(4); for (int j = 0; j < 4; ++j) delta[j] = (float)std::atof(argv[i + 1 + j]); i += 4; }
@@ -151,6 +154,13 @@ int main(int argc, char **argv)
         CHECK(flow.SetModParam("BatchCorrManifold", "ShardCount", ranks));
         CHECK(flow.SetModParam("BatchCorrManifold", "CommBackend", commName == "files" ? DPE_COMM_HOSTFILES : DPE_COMM_RCCL));
         CHECK(flow.SetModParam("BatchCorrManifold", "CommRendezvous", rendezvous.c_str()));
+        if (shardStage1) {
+            CHECK(flow.SetModParam("BatchCorrScores", "ShardStage1", true));
+            CHECK(flow.SetModParam("BatchCorrScores", "ShardRank", rank));
+            CHECK(flow.SetModParam("BatchCorrScores", "ShardCount", ranks));
+            CHECK(flow.SetModParam("BatchCorrScores", "CommBackend", commName == "files" ? DPE_COMM_HOSTFILES : DPE_COMM_RCCL));
+            CHECK(flow.SetModParam("BatchCorrScores", "CommRendezvous", rendezvous.c_str()));
+        }
     }
     CHECK(flow.SetModParam("BatchCorrScores", "LagHalfWidth", L));
     CHECK(flow.SetModParam("BatchCorrScores", "BinHalfWidth", B));

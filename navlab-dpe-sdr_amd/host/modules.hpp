@@ -22,6 +22,7 @@
 #include <fstream>
 #include <mutex>
 #include <sstream>
+#include <sys/stat.h>
 #include <thread>
 
 #include "../../include/dpe_hip.h"
@@ -283,6 +284,14 @@ class BatchCorrScores : public Module {
         InsertParam("BinHalfWidth", &binHalf, INT_t, sizeof(int), sizeof(int));
         InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
         InsertParam("SyncOutputs", &syncOutputs, BOOL_t, sizeof(bool), sizeof(bool));
+        // multi-GPU (one flow per GPU, SURVEY 8e "shard SVs in stage 1 and all-gather the banks"): with ShardStage1 this flow
+        // correlates channels [ShardRank K / ShardCount, (ShardRank + 1) K / ShardCount) and dpe_bcs_allgather_banks fills the
+        // full banks the ports point at.  A closed loop has one window per Update, so the stage-1 shard is by channel.
+        InsertParam("ShardStage1", &shardStage1, BOOL_t, sizeof(bool), sizeof(bool));
+        InsertParam("ShardRank", &shardRank, INT_t, sizeof(int), sizeof(int));
+        InsertParam("ShardCount", &shardCount, INT_t, sizeof(int), sizeof(int));
+        InsertParam("CommBackend", &commBackend, INT_t, sizeof(int), sizeof(int));          // DPE_COMM_RCCL / DPE_COMM_HOSTFILES
+        InsertParam("CommRendezvous", commRendezvous, CHAR_t, sizeof(commRendezvous), 0);
     }
     ~BatchCorrScores() override { Stop(); }
     int Start(void *) override
@@ -294,6 +303,29 @@ class BatchCorrScores : public Module {
         cfg.samplingFrequency = *(double *)inputs[9]->Data;               // :754
         cfg.lagHalfWidth = lagHalf; cfg.binHalfWidth = binHalf;
         cfg.maxWindows = 1; cfg.maxChannels = DPE_MAX_CHAN;
+        S = cfg.samplesPerWindow;
+        sharded = shardStage1 && shardCount > 1;
+        if (sharded) {
+            if (shardRank < 0 || shardRank >= shardCount) DPE_MOD_FAIL("Start: ShardRank " << shardRank << " not in [0, " << shardCount << ")");
+            // The channel count is known at the first Update (cuChanMgr starts after this module, as in the reference, where
+            // the plans are made there: batchcorrscores.cu:991-1038): the handle for this rank's share is created then.  The
+            // ports point at the gathered banks from the start.
+            cfgKeep = cfg;
+            long long nfft = 8;
+            while (nfft / 8 < (long long)S) nfft <<= 1;                       // batchcorrscores.cu:761
+            carrSTot = (int)nfft;
+            const int64_t nLag = 2 * lagHalf + 1, nBin = 2 * binHalf + 1;
+            if (dpe_device_alloc((void **)&codeAll, sizeof(float) * 2 * DPE_MAX_CHAN * nLag) ||
+                dpe_device_alloc((void **)&carrAll, sizeof(float) * 2 * DPE_MAX_CHAN * nBin)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+            const std::string dir = std::string(commRendezvous) + "/stage1";   // a rendezvous of its own beside BatchCorrManifold's
+            (void)::mkdir(dir.c_str(), 0777);
+            if (dpe_comm_create(shardRank, shardCount, dir.c_str(), commBackend, &comm)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+            UpdateOutput(0, (uint32_t)nLag, (void *)codeAll, lagHalf);
+            UpdateOutput(1, (uint32_t)nBin, (void *)carrAll, binHalf);
+            UpdateOutput(2, 1, &carrSTot, 0);
+            Started = true;
+            return 0;
+        }
         if (dpe_bcs_create(&cfg, &h)) return -1;
         dpe_bcs_set_graph(h, useGraph ? 1 : 0);
         const float *code, *carr; int32_t nLag, nBin; int64_t nfft;
@@ -302,7 +334,6 @@ class BatchCorrScores : public Module {
         UpdateOutput(0, (uint32_t)nLag, (void *)code, lagHalf);   // AuxValue carries the half width
         UpdateOutput(1, (uint32_t)nBin, (void *)carr, binHalf);
         UpdateOutput(2, 1, &carrSTot, 0);
-        S = cfg.samplesPerWindow;
         Started = true;
         return 0;
     }
@@ -323,6 +354,24 @@ class BatchCorrScores : public Module {
             ch[k].reserved = 0;
         }
         dpe_stream_t st = flow_stream(flowStream);
+        if (sharded) {
+            if (K % shardCount) DPE_MOD_FAIL("Update: ShardStage1 needs the " << K << " channels to divide over " << shardCount << " ranks");
+            const int Kl = K / shardCount;
+            if (!h) {
+                cfgKeep.maxChannels = Kl;       // the gathered rows are then channel-major: rank r's block holds channels r Kl ...
+                if (dpe_bcs_create(&cfgKeep, &h)) { Stop(); return -1; }
+                shardK = K;
+            }
+            if (K != shardK) DPE_MOD_FAIL("Update: channel count changed from " << shardK << " to " << K << " under ShardStage1");
+            if (dpe_bcs_update(h, (const int16_t *)inputs[0]->Data, S, 1, Kl, ch + shardRank * Kl, st) ||
+                dpe_bcs_allgather_banks(h, comm, codeAll, carrAll, st)) {
+                std::cerr << "[" << ModuleName << "] Update: " << dpe_last_error() << std::endl;
+                Stop();
+                return -1;
+            }
+            if (syncOutputs && dpe_stream_synchronize(st)) { Stop(); return -1; }
+            return 0;
+        }
         if (dpe_bcs_update(h, (const int16_t *)inputs[0]->Data, S, 1, K, ch, st)) { Stop(); return -1; }
         // The reference synchronises here (:1192-1195).  The banks are consumed by BatchCorrManifold on the
         // same flow stream, so stream order already guarantees they are complete there; not waiting lets
@@ -335,6 +384,10 @@ class BatchCorrScores : public Module {
     {
         if (!Started) return 0;
         dpe_bcs_destroy(h);
+        if (comm) dpe_comm_destroy(comm);
+        if (codeAll) dpe_device_free(codeAll);
+        if (carrAll) dpe_device_free(carrAll);
+        comm = nullptr; codeAll = carrAll = nullptr;
         h = nullptr;
         Started = false;
         return 0;
@@ -343,6 +396,12 @@ class BatchCorrScores : public Module {
   private:
     dpe_bcs *h = nullptr;
     bool Started = false;
+    bool shardStage1 = false, sharded = false;
+    int shardRank = 0, shardCount = 1, commBackend = DPE_COMM_RCCL, shardK = 0;
+    char commRendezvous[512] = "";
+    dpe_comm *comm = nullptr;
+    dpe_bcs_config cfgKeep = {};
+    float *codeAll = nullptr, *carrAll = nullptr;
     int lagHalf = 8, binHalf = 48, carrSTot = 0, S = 0;
     bool useGraph = false;  // replay the per-window launch sequence as one hipGraph (dpe_hip.h; measured slower)
     bool syncOutputs = false;

@@ -14,13 +14,51 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST = ["--steps", "2", "--warmup", "1", "--clock-warmup-s", "0", "--min-batch-s", "0.01", "--batches", "2", "--no-cpu-baseline"]
 
 
-def _launch(port, extra, nproc=2):
+def _launch(port, extra, nproc=2, expect_rc=0, timeout=300):
     env = dict(os.environ, DPE_BENCH_BACKEND="gloo", DPE_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + FAST + extra
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    if expect_rc:
+        assert r.returncode != 0
+        return r.stderr
     assert r.returncode == 0, r.stderr[-3000:]
     return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_eight_ranks_default_invocation_matches_one_rank():
+    """What the driver launches on an 8-GPU node -- the default invocation with --gpus 8 (M strong scaling, then the R headline,
+    weak scaling) -- with all eight ranks on this box's one GPU and gloo carrying the exchange: 8-way partition arithmetic of both
+    grids, stage 1 sharded over 8 ranks (one window each), key all-reduce.  Config M scans the same global grid whatever the rank
+    count, so its decoded fixes must be those of the one-rank run."""
+    lines = _launch(29571, ["--windows", "8", "--extra-windows", "8"], nproc=8, timeout=900)
+    assert len(lines) == 2, lines
+    m, d = lines
+    assert m["n_gpus"] == 8 and m["scaling"] == "strong" and m["config"]["stage1"].startswith("sharded")
+    assert m["config"]["grid_points_per_manifold_global"] == 1000000 and m["config"]["grid_points_per_manifold_per_gpu"] == 125000
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["stage1"].startswith("sharded")
+    assert d["config"]["grid_points_per_manifold_global"] == 8 * 390625 and d["config"]["grid_points_per_manifold_per_gpu"] == 390625
+    assert d["config"]["windows_per_step"] == 8 and d["value"] > 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DPE_BENCH_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "M", "--windows", "8"] + FAST
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert one["n_gpus"] == 1 and one["config"]["grid_points_per_manifold_per_gpu"] == 1000000
+    # rank 0 of 8 decodes the 1-rank run's ML points.  (Stage 1 runs with another tile partition when a rank holds one window
+    # instead of eight: banks agree to fp32 rounding, so a window whose two best grid points tie within that rounding may pick
+    # the other one -- its score then still agrees.)
+    same = 0
+    for a, b in zip(m["fixes"], one["fixes"]):
+        assert abs(a[2] - b[2]) <= 2e-6 * abs(b[2]) and abs(a[3] - b[3]) <= 2e-6 * abs(b[3])
+        same += (a[0] == b[0]) + (a[1] == b[1])
+    assert len(m["fixes"]) == 8 and same >= 14
+
+
+def test_windows_must_divide_over_the_ranks():
+    """--stage1 sharded with a window count the ranks do not divide: exit status 2 and a message, not a silent fallback."""
+    err = _launch(29572, ["--config", "R", "--windows", "3"], nproc=2, expect_rc=2)
+    assert "divide over the 2 ranks" in err
 
 
 @pytest.mark.parametrize("exchange,port", [("keys", 29561), ("scores", 29562)])

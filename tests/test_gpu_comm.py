@@ -49,6 +49,29 @@ def test_two_flow_ranks_on_one_gpu_equal_the_unsharded_flow(tmp_path):
             assert np.array_equal(np.loadtxt(o, delimiter=","), ref)       # every rank decodes the same global ML point
 
 
+def test_two_flow_ranks_with_stage1_sharded_by_channel(tmp_path):
+    """--shard-stage1: each flow correlates 4 of the 8 channels and dpe_bcs_allgather_banks (host-file transport here)
+    completes the banks both grid shards are scored against; the fixes are the unsharded flow's."""
+    W = 3
+    dat, ho = _inputs(tmp_path, W)
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
+    base = [exe, "--samples", dat, "--handoff", ho, "--iters", str(W), "--grid-dim", "9", "--spacing", "1.0"]
+    full = str(tmp_path / "X_full.csv")
+    subprocess.check_call(base + ["--out", full], timeout=200)
+    rdv = str(tmp_path / "rdv")
+    os.makedirs(rdv)
+    outs = [str(tmp_path / ("X_s1_rank%d.csv" % r)) for r in range(2)]
+    procs = [subprocess.Popen(base + ["--out", outs[r], "--ranks", "2", "--rank", str(r), "--rendezvous", rdv, "--comm", "files",
+                                      "--shard-stage1"], stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=200)
+        assert p.returncode == 0, err[-2000:]
+    ref = np.loadtxt(full, delimiter=",")
+    for o in outs:
+        assert np.array_equal(np.loadtxt(o, delimiter=","), ref)
+    assert os.path.isdir(os.path.join(rdv, "stage1"))        # the stage-1 exchange really had its own rendezvous
+
+
 def test_flow_with_one_rccl_rank(tmp_path):
     """--ranks 1 --comm rccl: ncclCommInitRank + ncclAllReduce(MAX, uint64) through the C-ABI on the box's GPU."""
     W = 3
