@@ -13,8 +13,9 @@
  *  - BatchCorrScores produces WINDOWED score banks (code lags [-L,+L] about the fftshift
  *    centre S/2, Doppler bins [-B,+B] about C/2) in fp32 instead of the dense K*S / K*C
  *    complex128 arrays; dpe_bcs_export_dense() writes the reference layout on request;
- *  - per-channel parameters are passed from HOST memory (the reference keeps them in
- *    device arrays written by cuChanMgr kernels, dpeflow.cpp:169-191).
+ *  - per-channel parameters are passed from HOST memory by dpe_bcs_update / dpe_bcm_update (any number of windows per
+ *    call); dpe_bcs_update_dev / dpe_bcm_update_dev take them, for one window, from the DEVICE arrays the reference's
+ *    cuChanMgr kernels write (dpeflow.cpp:169-191).
  */
 #ifndef DPE_HIP_H_
 #define DPE_HIP_H_
@@ -109,6 +110,25 @@ int dpe_bcs_destroy(dpe_bcs *h);                                   /* BatchCorrS
 int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples,
                    int32_t nWindows, int32_t nChan, const dpe_chan_start *chan_host,
                    dpe_stream_t stream);
+/* The same for ONE window with the channel parameters where the reference keeps them: in DEVICE arrays written by cuChanMgr
+ * (dpeflow.cpp:169-176; BatchCorrScores captures the pointers once, batchcorrscores.cu:991-1004).  A one-block kernel derives
+ * the per-channel constants on the device in fp64 (same expressions as the host form), so a host that keeps the reference's
+ * cuChanMgr needs no device-to-host copy per window.  Uses the per-sample stage-1 kernels (the chip-boundary forms are
+ * selected from the channel values, which the host does not see here). */
+typedef struct dpe_bcs_ports_dev {
+    const double *codePhaseStart;      /* [K] chips   (input 2) */
+    const double *carrierPhaseStart;   /* [K] cycles  (input 3) */
+    const double *codeFrequency;       /* [K] chips/s (input 4) */
+    const double *carrierFrequency;    /* [K] Hz      (input 5) */
+    const int32_t *cpElapsedStart;     /* [K]         (input 6) */
+    const int32_t *cpReference;        /* [K]         (input 7) */
+    const uint8_t *validPRNs;          /* [K] PRN numbers 1..37 (input 1) */
+} dpe_bcs_ports_dev;
+int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, const dpe_bcs_ports_dev *ports_dev_ptrs,
+                       dpe_stream_t stream);
+/* Input check of the last dpe_bcs_update_dev (synchronises): bit 0 = a PRN outside 1..37 (clamped), bit 1 = a non-positive
+ * code frequency or negative code phase.  0 = clean. */
+int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream);
 /* Output ports CodeScores / CarrScores / NumFFTPoints (batchcorrscores.cu:696-698,869-874).
  * codeBank_dev: float2 [maxWindows][maxChannels][2L+1]; entry j = reference
  * codeCorrOut_d[k*S + S/2 - L + j].  carrBank_dev: float2 [..][..][2B+1]; entry j = reference
@@ -206,6 +226,27 @@ int dpe_bcm_destroy(dpe_bcm *h);                                   /* ::Stop :24
 int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev,
                    int32_t nWindows, int32_t nChan, const dpe_bcm_window *win_host,
                    const dpe_chan_end *chan_host, dpe_stream_t stream);
+/* One window with the inputs where the reference keeps them: DEVICE arrays of cuChanMgr / cuEKF (dpeflow.cpp:178-191,212;
+ * captured once at batchcorrmanifold.cu:2512-2533, xCurrkk1 re-read per Update :2540); rxTime is a host scalar in the
+ * reference too (:2536-2537).  A one-block kernel forms the per-SV expansion coefficients in fp64 on the device (the centre
+ * index as a compensated sum where the host form uses long double); the scan runs with its range clamps on, since the host
+ * cannot prove the indices inside the banks.  Not with referencePair. */
+typedef struct dpe_bcm_ports_dev {
+    const double *xCurrkk1;            /* [8]  (input 2) */
+    const double *enu2ecef;            /* [9]  row-major (input 12) */
+    const double *satStates;           /* [K][dimT][8] batch satellite states (input 4); entry dimT/2 is read (:1775) */
+    const double *codePhaseEnd;        /* [K]  (input 14) */
+    const double *codeFrequency;       /* [K]  (input 8) */
+    const double *carrierFrequency;    /* [K]  (input 9) */
+    const int32_t *cpRefTOW;           /* [K]  (input 16) */
+    const int32_t *cpElapsedEnd;       /* [K]  (input 17) */
+    const int32_t *cpRef;              /* [K]  (input 18) */
+    const int32_t *dopplerSign;        /* [1]  (input 10) */
+    int32_t dimT;                      /* entries of the time grid */
+    int32_t reserved;
+} dpe_bcm_ports_dev;
+int dpe_bcm_update_dev(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nChan,
+                       const dpe_bcm_ports_dev *ports_dev_ptrs, double rxTime, dpe_stream_t stream);
 /* Waits for the last Update (single windows without the weighted-mean estimator: polls the sequence word the kernel writes
  * behind the results in pinned memory; otherwise synchronises `stream`) and returns the per-window ML results (zVal/RVal ports; RVal is the
  * 8x8 identity the reference writes, :2003-2011,2055-2063).  results: [nWindows]. */

@@ -379,6 +379,77 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
     }
 }
 
+// Device-resident inputs (dpe_bcm_update_dev): the per-SV coefficients of both manifolds from the reference's own port arrays
+// on the device (cuChanMgr / cuEKF outputs, dpeflow.cpp:178-191,212; captured once by the reference at
+// batchcorrmanifold.cu:2512-2540) -- what the host loop of dpe_bcm_update computes, in fp64.  The host form carries the centre
+// index in long double because rxTime - pr / C (rxTime ~ 4e5 s) rounds at 5.8e-11 s in fp64; here the same difference is kept
+// as an unevaluated sum (TwoSum), which is more than the 64-bit significand gives.  One block, thread <-> channel; thread 0
+// also leaves the window's frame (xCurrkk1, ENU2ECEFMat, DopplerSign) in pinned host memory for dpe_bcm_results.
+struct BcmPortsDev {
+    const double *x, *R, *sat, *rcEnd, *fc, *fi;
+    const int *cpRefTOW, *cpElaEnd, *cpRef, *dopplerSign;
+    int dimT;
+};
+struct BcmDevWin {   // pinned mirror of the window inputs of a device-parameter Update
+    double xCurrkk1[8], enu2ecef[9];
+    int dopplerSign, bad;
+};
+#pragma clang fp contract(off)
+__global__ void bcm_prep_kernel(BcmPortsDev p, int K, double rxTime, double fs, double Cf, int S, int L, int B, long long C,
+                                BcmSvDev *__restrict__ svPos, BcmSvDev *__restrict__ svVel, BcmDevWin *__restrict__ hostWin)
+{
+    const int k = threadIdx.x;
+    const double *c = p.x, *R = p.R;
+    const int ds = p.dopplerSign[0];
+    if (k == 0) {
+        for (int i = 0; i < 8; ++i) hostWin->xCurrkk1[i] = c[i];
+        for (int i = 0; i < 9; ++i) hostWin->enu2ecef[i] = R[i];
+        hostWin->dopplerSign = ds;
+        hostWin->bad = (ds == 1 || ds == -1) ? 0 : 1;
+    }
+    if (k >= K) return;
+    const double *s = p.sat + ((size_t)k * p.dimT + p.dimT / 2) * 8;                      // mid-time entry, :1775
+    const double dx = s[0] - c[0], dy = s[1] - c[1], dz = s[2] - c[2];                    // :1779-1781
+    const double range = sqrt(dx * dx + dy * dy + dz * dz);                               // :1782
+    const double ux = dx / range, uy = dy / range, uz = dz / range;
+    const double ue = R[0] * ux + R[3] * uy + R[6] * uz;                                  // R^T u
+    const double un = R[1] * ux + R[4] * uy + R[7] * uz;
+    const double uu = R[2] * ux + R[5] * uy + R[8] * uz;
+    // position manifold, centre index (:1783-1791)
+    const double pr = range - kC * s[3] + c[3];
+    const double t = pr / kC;
+    const double hi = rxTime - t, bb = hi - rxTime;
+    double lo = (rxTime - (hi - bb)) + (-t - bb);                                         // rxTime - t = hi + lo exactly
+    const double d1 = hi - (double)p.cpRefTOW[k];                                         // exact: both are multiples of ulp(rxTime)
+    const double n = (double)(p.cpElaEnd[k] - p.cpRef[k]);
+    const double pn = n * kTCA;
+    lo -= fma(n, kTCA, -pn);                                                              // the product's own rounding
+    const double cfd = (d1 - pn) + lo;
+    const double fck = p.fc[k];
+    const double rc0 = cfd * kFCA - p.rcEnd[k];
+    const double basePos = (fs / fck) * (-rc0) + (double)S / 2.0;
+    BcmSvDev a;
+    a.ue = (float)ue; a.un = (float)un; a.uu = (float)uu;
+    a.g = (float)(fs * kFCA / (fck * kC));
+    a.h = (float)(0.5 / range);
+    a.idx0 = (float)(basePos - (double)(S / 2 - L));
+    a.pad0 = a.pad1 = 0.f;
+    svPos[k] = a;
+    // velocity manifold, centre index (:1917-1936)
+    const double ex = c[4] - kOEDot * c[1], ey = c[5] + kOEDot * c[0], ez = c[6];
+    const double lrr = ux * (ex - s[4]) + uy * (ey - s[5]) + uz * (ez - s[6]);
+    const double fbc = kFL1 * ((lrr - c[7]) / kC + s[7]) / ds;
+    const double baseVel = (Cf / fs) * (fbc - p.fi[k]) + Cf / 2.0;
+    const double gv = (Cf / fs) * kFL1 / (kC * ds);
+    BcmSvDev v;
+    v.ue = (float)ue; v.un = (float)un; v.uu = (float)uu;
+    v.g = (float)(-gv);
+    v.idx0 = (float)(baseVel - (double)(C / 2 - B));
+    v.h = (float)(-gv * ue); v.pad0 = (float)(-gv * un); v.pad1 = (float)(-gv * uu);
+    svVel[k] = v;
+}
+#pragma clang fp contract(fast)
+
 // referencePair mode: arg-max of the position manifold re-derived from the (host-patched) score array.
 __global__ void bcm_zero_pos_keys_kernel(unsigned long long *__restrict__ keys, int nWindows)
 {
@@ -442,6 +513,8 @@ struct dpe_bcm {
     std::vector<double> refWsum;            // [W][5] corrections of the weighted sums (patched - scanned score at offset x,y,z,t)
     long long refPatched = 0;               // points patched by the last Update (diagnostic)
     std::vector<dpe_bcm_window> win_h;
+    dpe::BcmDevWin *devWin_h = nullptr, *devWin_hd = nullptr;   // pinned: window frame of a device-parameter Update (written by bcm_prep_kernel)
+    bool lastDev = false;
     int lastW = 0;
     double posExtent = 0, velExtent = 0;
     dpe::KernelProfiler prof;  // slot 0: the fused position + velocity scan
@@ -722,6 +795,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
     if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->wsum_d ||
         hipHostMalloc((void **)&h->svBase_h, dpe_bcm::kStaging * 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->devWin_h, sizeof(BcmDevWin), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->keys_h, (4 * W + 8) * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
         dpe_bcm_destroy(h);
@@ -754,6 +828,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
         DPE_CHECK_HIP(hipMemset(h->done_d, 0, sizeof(unsigned int)));
         DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->keys_hd, h->keys_h, 0));
         DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->svBase_hd, h->svBase_h, 0));
+        DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->devWin_hd, h->devWin_h, 0));
         return 0;
     };
     if (finish()) {
@@ -772,6 +847,7 @@ int dpe_bcm_destroy(dpe_bcm *h)
     for (void *b : bufs) (void)hipFree(b);
     if (h->svBase_h) (void)hipHostFree(h->svBase_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
+    if (h->devWin_h) (void)hipHostFree(h->devWin_h);
     if (h->refBank_h) (void)hipHostFree(h->refBank_h);
     if (h->refPatch_h) (void)hipHostFree(h->refPatch_h);
     for (hipEvent_t e : h->stagingFree)
@@ -781,22 +857,26 @@ int dpe_bcm_destroy(dpe_bcm *h)
     return 0;
 }
 
-int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nWindows, int32_t nChan,
-                   const dpe_bcm_window *win_host, const dpe_chan_end *chan_host, dpe_stream_t stream_)
+// win_host == nullptr: one window whose coefficients bcm_prep_kernel has already written to h->sv_d on `stream`
+// (dpe_bcm_update_dev) -- nothing the host decides below may then depend on their values.
+static int bcm_update_impl(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nWindows, int32_t nChan,
+                           const dpe_bcm_window *win_host, const dpe_chan_end *chan_host, dpe_stream_t stream_)
 {
     using namespace dpe;
-    DPE_REQUIRE(h && codeBank_dev && carrBank_dev && win_host && chan_host, "[BatchCorrManifold] Update: null argument");
+    const bool dev = win_host == nullptr;
+    DPE_REQUIRE(h && codeBank_dev && carrBank_dev, "[BatchCorrManifold] Update: null argument");
     DPE_REQUIRE(nWindows >= 1 && nWindows <= h->cfg.maxWindows, "[BatchCorrManifold] Update: nWindows %d out of range", nWindows);
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrManifold] Update: nChan %d out of range", nChan);
     hipStream_t stream = (hipStream_t)stream_;
     const int S = h->cfg.samplesPerWindow, L = h->cfg.lagHalfWidth, B = h->cfg.binHalfWidth;
     const int maxK = h->cfg.maxChannels, W = h->cfg.maxWindows;
     const double fs = h->cfg.samplingFrequency, Cf = (double)h->cfg.numFFTPoints;
-    bool posInside = true, velInside = true;   // every index provably inside the banks?
+    bool posInside = !dev, velInside = !dev;   // every index provably inside the banks?  (device parameters: not known here)
+    h->lastDev = dev;
     h->slot = (h->slot + 1) % dpe_bcm::kStaging;          // next staging block; an Update kStaging calls ago may still be copying it
     DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree[h->slot]));
     h->sv_h = h->svBase_h + (size_t)h->slot * 2 * h->cfg.maxWindows * h->cfg.maxChannels;
-    for (int w = 0; w < nWindows; ++w) {
+    for (int w = 0; !dev && w < nWindows; ++w) {
         const dpe_bcm_window &win = win_host[w];
         DPE_REQUIRE(win.dopplerSign == 1 || win.dopplerSign == -1, "[BatchCorrManifold] Update: dopplerSign must be +/-1");
         h->win_h[w] = win;
@@ -855,7 +935,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     unsigned long long *keys = h->keys_d + (size_t)use * 4 * W, *oob = keys + 2 * W;
     unsigned long long *other = h->keys_d + (size_t)(use ^ 1) * 4 * W;
     GraphCache::Guard graphGuard{h->graphs, stream};
-    if (h->graphs.enabled && !h->prof.enabled && !h->refPair) {
+    if (h->graphs.enabled && !h->prof.enabled && !h->refPair && !dev) {
         const int rc = h->graphs.begin({codeBank_dev, carrBank_dev, 0, nWindows, nChan,
                                         (posInside ? 1 : 0) | (velInside ? 2 : 0) | (use << 2) | (h->slot << 8), stream}, stream);
         DPE_REQUIRE(rc >= 0, "[BatchCorrManifold] Update: hipGraph capture/replay failed");
@@ -868,9 +948,10 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     }
     // one window: coefficients as kernel arguments of the scans (a captured graph would freeze them, so
     // that path copies); batches: one copy covers both manifolds' coefficient blocks
-    const bool inlineParams = nWindows == 1 && !h->graphs.capturing;
+    const bool inlineParams = nWindows == 1 && !h->graphs.capturing && !dev;
     BcmParamBlock pb{};
-    if (inlineParams) {
+    if (dev) {}
+    else if (inlineParams) {
         memcpy(pb.s[0], h->sv_h, sizeof(BcmSvDev) * nChan);
         memcpy(pb.s[1], h->sv_h + (size_t)W * maxK, sizeof(BcmSvDev) * nChan);
     } else {
@@ -922,6 +1003,32 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
     return 0;
 }
 
+int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nWindows, int32_t nChan,
+                   const dpe_bcm_window *win_host, const dpe_chan_end *chan_host, dpe_stream_t stream)
+{
+    DPE_REQUIRE(win_host && chan_host, "[BatchCorrManifold] Update: null argument");
+    return bcm_update_impl(h, codeBank_dev, carrBank_dev, nWindows, nChan, win_host, chan_host, stream);
+}
+
+int dpe_bcm_update_dev(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nChan, const dpe_bcm_ports_dev *ports,
+                       double rxTime, dpe_stream_t stream)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && ports, "[BatchCorrManifold] Update: null argument");
+    DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrManifold] Update: nChan %d out of range", nChan);
+    DPE_REQUIRE(!h->refPair, "[BatchCorrManifold] Update: referencePair re-evaluates points on the host and needs the host form of the inputs");
+    DPE_REQUIRE(ports->xCurrkk1 && ports->enu2ecef && ports->satStates && ports->codePhaseEnd && ports->codeFrequency &&
+                ports->carrierFrequency && ports->cpRefTOW && ports->cpElapsedEnd && ports->cpRef && ports->dopplerSign && ports->dimT >= 1,
+                "[BatchCorrManifold] Update: a device port pointer is null / dimT < 1");
+    const BcmPortsDev p = {ports->xCurrkk1, ports->enu2ecef, ports->satStates, ports->codePhaseEnd, ports->codeFrequency, ports->carrierFrequency,
+                           ports->cpRefTOW, ports->cpElapsedEnd, ports->cpRef, ports->dopplerSign, ports->dimT};
+    const size_t W = h->cfg.maxWindows, maxK = h->cfg.maxChannels;
+    hipLaunchKernelGGL(bcm_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, rxTime, h->cfg.samplingFrequency,
+                       (double)h->cfg.numFFTPoints, h->cfg.samplesPerWindow, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, (long long)h->cfg.numFFTPoints,
+                       h->sv_d, h->sv_d + W * maxK, h->devWin_hd);
+    return bcm_update_impl(h, codeBank_dev, carrBank_dev, 1, nChan, nullptr, nullptr, stream);
+}
+
 int dpe_bcm_set_graph(dpe_bcm *h, int32_t enable)
 {
     DPE_REQUIRE(h, "[BatchCorrManifold] set_graph: null handle");
@@ -964,6 +1071,12 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
     }
     if (!arrived) DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int W = h->lastW;
+    if (h->lastDev) {   // the window's frame came from device arrays: bcm_prep_kernel left it in pinned memory ahead of the scan
+        DPE_REQUIRE(!h->devWin_h->bad, "[BatchCorrManifold] results: DopplerSign on the device is not +/-1");
+        memcpy(h->win_h[0].xCurrkk1, h->devWin_h->xCurrkk1, sizeof(double) * 8);
+        memcpy(h->win_h[0].enu2ecef, h->devWin_h->enu2ecef, sizeof(double) * 9);
+        h->win_h[0].dopplerSign = h->devWin_h->dopplerSign;
+    }
     const unsigned long long *keys = h->keys_h, *oob = h->oob_h;
     std::vector<double> ws;   // per-block weighted sums: fetched only when the estimator is on (this call sits on the
                               // closed loop's critical path: no 300 KB of scratch per window otherwise)

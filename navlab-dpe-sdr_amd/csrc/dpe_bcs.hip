@@ -1041,6 +1041,47 @@ __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finali
     }
 }
 
+// Device-resident channel parameters (dpe_bcs_update_dev): what the host loop of dpe_bcs_update computes per channel, from
+// the reference's own port arrays on the device (cuChanMgr's outputs, dpeflow.cpp:169-176; captured once by the reference at
+// batchcorrscores.cu:991-1004).  One block; fp64 throughout, expression for expression the host form.  status: bit 0 = a PRN
+// outside 1..37 (clamped so that the kernels stay inside the chip table), bit 1 = a non-positive code frequency / negative phase.
+struct BcsPortsDev {
+    const double *rc, *ri, *fc, *fi;
+    const int *cpEla, *cpRef;
+    const unsigned char *prn;
+};
+#pragma clang fp contract(off)
+__global__ void bcs_prep_kernel(BcsPortsDev p, int K, double fs, int S, BcsChanDev *__restrict__ out, int *__restrict__ status)
+{
+    const int k = threadIdx.x;
+    if (k == 0) *status = 0;
+    __syncthreads();
+    if (k >= K) return;
+    BcsChanDev d;
+    int bad = 0, prn = p.prn[k];
+    if (prn < 1 || prn > kPrnMax) { bad |= 1; prn = prn < 1 ? 1 : kPrnMax; }
+    const double fc = p.fc[k], rc = p.rc[k];
+    if (!(fc > 0.0) || !(rc >= 0.0)) bad |= 2;
+    d.rc = rc;
+    d.codeStep = fc / fs;
+    d.ri = p.ri[k];
+    d.carrStep = p.fi[k] / fs;
+    d.fc = fc;
+    d.fi = p.fi[k];
+    d.invStep = fs / fc;
+    const double ang = -6.283185307179586476925286766559 * d.carrStep;
+    d.rotRe = (float)cos(ang);
+    d.rotIm = (float)sin(ang);
+    const int since = (((p.cpEla[k] - p.cpRef[k]) % 20) + 20) % 20;                       // BCS_NavBitBoundary :247-253
+    d.idxNext = (int)(floor((kLCA * (20 - since) - rc) * (fs / fc)) + 1);
+    d.hasFlip = (d.idxNext > 0 && d.idxNext < S) ? 1 : 0;
+    d.prn = prn;
+    d.pad = 0;
+    out[k] = d;
+    if (bad) atomicOr(status, bad);
+}
+#pragma clang fp contract(fast)
+
 // Dense export in the reference layout (complex128, fft-shifted rows), zero outside the banks.
 __global__ void bcs_export_kernel(const float2 *__restrict__ bank, int n, long long rowLen, long long centre, int K,
                                   int maxK, int half, double2 *__restrict__ dense)
@@ -1097,6 +1138,8 @@ struct dpe_bcs {
     float2 *part_d = nullptr, *mom_d = nullptr, *momRep_d = nullptr, *codeBank_d = nullptr, *carrBank_d = nullptr;
     int *info_d = nullptr;
     int lastW = 0, lastK = 0, lastSumBlocks = 1;
+    bool lastDev = false;              // the last Update took its channel parameters from device arrays (dpe_bcs_update_dev)
+    int *status_d = nullptr;           // that form's input check, written by bcs_prep_kernel
     const char *lastKernel = "";   // stage-1 kernel of the last Update (dpe_bcs_stage1_kernel)
     std::vector<int32_t> idxNext_h;
     dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
@@ -1223,7 +1266,8 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->codeBank_d = dev_alloc<float2>(W * K * (2 * cfg->lagHalfWidth + 1));
     h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
     h->info_d = dev_alloc<int>(W * K);
-    if (!h->tTable_d || !h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
+    h->status_d = dev_alloc<int>(1);
+    if (!h->status_d || !h->tTable_d || !h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
         !h->info_d || hipHostMalloc((void **)&h->chanBase_h, dpe_bcs::kStaging * W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrScores] create: device allocation failed");
         dpe_bcs_destroy(h);
@@ -1280,7 +1324,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
 int dpe_bcs_destroy(dpe_bcs *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d};
+    void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
     if (h->havePlans) { (void)hipfftDestroy(h->planS3); (void)hipfftDestroy(h->planS2); (void)hipfftDestroy(h->planC); }
@@ -1292,11 +1336,14 @@ int dpe_bcs_destroy(dpe_bcs *h)
     return 0;
 }
 
-int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples, int32_t nWindows,
-                   int32_t nChan, const dpe_chan_start *chan_host, dpe_stream_t stream_)
+// chan_host == nullptr: the channel parameters of this (single-window) call are already in h->chan_d, written by
+// bcs_prep_kernel earlier on `stream` (dpe_bcs_update_dev) -- nothing the host decides below may then depend on their values.
+static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples, int32_t nWindows,
+                           int32_t nChan, const dpe_chan_start *chan_host, dpe_stream_t stream_)
 {
     using namespace dpe;
-    DPE_REQUIRE(h && samples_dev && chan_host, "[BatchCorrScores] Update: null argument");
+    const bool dev = chan_host == nullptr;
+    DPE_REQUIRE(h && samples_dev, "[BatchCorrScores] Update: null argument");
     DPE_REQUIRE(nWindows >= 1 && nWindows <= h->cfg.maxWindows, "[BatchCorrScores] Update: nWindows %d out of range", nWindows);
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrScores] Update: nChan %d out of range", nChan);
     const int S = h->cfg.samplesPerWindow;
@@ -1307,7 +1354,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     h->slot = (h->slot + 1) % dpe_bcs::kStaging;
     DPE_CHECK_HIP(hipEventSynchronize(h->stagingFree[h->slot]));
     h->chan_h = h->chanBase_h + (size_t)h->slot * h->cfg.maxWindows * h->cfg.maxChannels;
-    for (int i = 0; i < nWindows * nChan; ++i) {
+    h->lastDev = dev;
+    for (int i = 0; !dev && i < nWindows * nChan; ++i) {
         const dpe_chan_start &c = chan_host[i];
         DPE_REQUIRE(c.prn >= 1 && c.prn <= kPrnMax, "[BatchCorrScores] Update: PRN %d out of range", c.prn);
         DPE_REQUIRE(c.codeFrequency > 0 && c.codePhaseStart >= 0, "[BatchCorrScores] Update: bad code phase/frequency");
@@ -1331,7 +1379,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         h->idxNext_h[i] = d.idxNext;
     }
     // chip-boundary kernel: the closed-form DC term of a chip needs 2 pi |fi| / fc <= 0.25 (|fi| below ~40 kHz)
-    bool chip = h->chipOK && h->chipAllowed;
+    bool chip = h->chipOK && h->chipAllowed && !dev;   // (its eligibility is a property of the channel values: host form only)
     for (int i = 0; chip && i < nWindows * nChan; ++i)
         if (6.283185307179586 * std::fabs(chan_host[i].carrierFrequency) > 0.25 * chan_host[i].codeFrequency) chip = false;
     // second form of the chip kernel (dpe_bcs_chip2.h): every chip 16 .. 25 samples long, and the nav-bit boundary
@@ -1356,7 +1404,8 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         const int sumBlocks = sum_blocks(S, nWindows);
         h->lastSumBlocks = sumBlocks;
         h->lastKernel = "hipfft full-lag path (bcs_fft_*_kernel)";
-        if (h->graphs.capturing) DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
+        if (dev) {}
+        else if (h->graphs.capturing) DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
         else upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
         DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
         h->prof.begin(0, stream);
@@ -1407,7 +1456,7 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
         return 0;
     }
     // the per-kernel event timing and the graph replay exclude each other
-    const bool useGraph = h->graphs.enabled && !h->prof.enabled;
+    const bool useGraph = h->graphs.enabled && !h->prof.enabled && !dev;
     GraphCache::Guard graphGuard{h->graphs, stream};
     const int sumBlocks = sum_blocks(S, nWindows);
     if (useGraph) {
@@ -1422,13 +1471,13 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     // few channels (the per-window call of a running receiver): parameters travel as kernel arguments of
     // the bank / finalize kernels; batches go through one H2D copy from the pinned staging block.  A
     // captured graph would freeze by-value arguments, so the graph path always copies.
-    const int inl = (!h->graphs.capturing && nWindows * nChan <= DPE_MAX_CHAN) ? 1 : 0;
+    const int inl = (!dev && !h->graphs.capturing && nWindows * nChan <= DPE_MAX_CHAN) ? 1 : 0;
     BcsParamBlock pb{};
     if (inl) memcpy(pb.c, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan);
     // (batches: the DC-sum kernel below carries the parameter upload; a captured graph keeps a copy node)
     else if (h->graphs.capturing)
         DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
-    const bool upInSum = !inl && !h->graphs.capturing;
+    const bool upInSum = !dev && !inl && !h->graphs.capturing;
     const int vecOK = (((uintptr_t)samples_dev & 15) == 0 && (windowStrideSamples % 4) == 0) ? 1 : 0;
     // |lag| <= 32 windows: boundary-difference kernel when a sub-tile holds few chip boundaries
     // (~128 codeStep per lag step against 4 x 65 dense FMAs per lane), else a dense kernel
@@ -1618,6 +1667,35 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
     return 0;
 }
 
+int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples, int32_t nWindows,
+                   int32_t nChan, const dpe_chan_start *chan_host, dpe_stream_t stream)
+{
+    DPE_REQUIRE(chan_host, "[BatchCorrScores] Update: null argument");
+    return bcs_update_impl(h, samples_dev, windowStrideSamples, nWindows, nChan, chan_host, stream);
+}
+
+int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, const dpe_bcs_ports_dev *ports, dpe_stream_t stream)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && samples_dev && ports, "[BatchCorrScores] Update: null argument");
+    DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrScores] Update: nChan %d out of range", nChan);
+    DPE_REQUIRE(ports->codePhaseStart && ports->carrierPhaseStart && ports->codeFrequency && ports->carrierFrequency &&
+                ports->cpElapsedStart && ports->cpReference && ports->validPRNs, "[BatchCorrScores] Update: a device port pointer is null");
+    const BcsPortsDev p = {ports->codePhaseStart, ports->carrierPhaseStart, ports->codeFrequency, ports->carrierFrequency,
+                           ports->cpElapsedStart, ports->cpReference, ports->validPRNs};
+    hipLaunchKernelGGL(bcs_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, h->cfg.samplingFrequency,
+                       h->cfg.samplesPerWindow, h->chan_d, h->status_d);
+    return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
+}
+
+int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h && status && h->lastDev, "[BatchCorrScores] dev_status: no device-parameter Update yet");
+    DPE_CHECK_HIP(hipMemcpyAsync(status, h->status_d, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 int dpe_bcs_set_graph(dpe_bcs *h, int32_t enable)
 {
     DPE_REQUIRE(h, "[BatchCorrScores] set_graph: null handle");
@@ -1671,7 +1749,11 @@ int dpe_bcs_read_info(dpe_bcs *h, int32_t *idxNext, int32_t *noFlipLarger, doubl
     DPE_REQUIRE(h && h->lastW > 0, "[BatchCorrScores] read_info: no update yet");
     DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int n = h->lastW * h->lastK;
-    if (idxNext) memcpy(idxNext, h->idxNext_h.data(), sizeof(int32_t) * n);
+    if (idxNext && h->lastDev) {   // the parameters never were on the host: fetch what bcs_prep_kernel derived
+        std::vector<dpe::BcsChanDev> c((size_t)n);
+        DPE_CHECK_HIP(hipMemcpy(c.data(), h->chan_d, sizeof(dpe::BcsChanDev) * n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) idxNext[i] = c[i].idxNext;
+    } else if (idxNext) memcpy(idxNext, h->idxNext_h.data(), sizeof(int32_t) * n);
     if (noFlipLarger) DPE_CHECK_HIP(hipMemcpy(noFlipLarger, h->info_d, sizeof(int) * n, hipMemcpyDeviceToHost));
     if (mean) {
         using dpe::kSumSlots;

@@ -29,6 +29,7 @@ EXPORTS = [
     "dpe_hbm_ceiling", "dpe_bcs_stage1_kernel",
     "dpe_set_device", "dpe_comm_create", "dpe_comm_wrap_nccl", "dpe_comm_destroy", "dpe_comm_rank", "dpe_comm_allreduce_max_u64",
     "dpe_comm_allgather", "dpe_bcm_exchange_keys", "dpe_bcs_allgather_banks",
+    "dpe_bcs_update_dev", "dpe_bcs_dev_status", "dpe_bcm_update_dev",
 ]
 
 
@@ -40,6 +41,17 @@ class BcsConfig(C.Structure):
     _fields_ = [("samplesPerWindow", C.c_int32), ("lagHalfWidth", C.c_int32), ("binHalfWidth", C.c_int32),
                 ("maxWindows", C.c_int32), ("maxChannels", C.c_int32), ("reserved", C.c_int32),
                 ("samplingFrequency", C.c_double)]
+
+
+class BcsPortsDev(C.Structure):     # dpe_bcs_ports_dev: device pointers to the reference's port arrays
+    _fields_ = [(n, C.c_void_p) for n in ("codePhaseStart", "carrierPhaseStart", "codeFrequency", "carrierFrequency",
+                                          "cpElapsedStart", "cpReference", "validPRNs")]
+
+
+class BcmPortsDev(C.Structure):     # dpe_bcm_ports_dev
+    _fields_ = [(n, C.c_void_p) for n in ("xCurrkk1", "enu2ecef", "satStates", "codePhaseEnd", "codeFrequency",
+                                          "carrierFrequency", "cpRefTOW", "cpElapsedEnd", "cpRef", "dopplerSign")] + \
+               [("dimT", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ChanStart(C.Structure):
@@ -251,6 +263,21 @@ class BatchCorrScores:
         self._W, self._K = W, K
         return 0
 
+    def UpdateDev(self, Samples, n_chan, ports, stream=None):
+        """One window with the channel parameters in DEVICE arrays (dpe_bcs_update_dev): ports = {field: device pointer}
+        with the fields of dpe_bcs_ports_dev."""
+        if not self.Started:
+            raise DpeError("[BatchCorrScores] Error: Update() Failed due to batch correlator not initialized")
+        p = BcsPortsDev(**{k: _ptr(v).value for k, v in ports.items()})
+        _check(lib().dpe_bcs_update_dev(self._h, _ptr(Samples), C.c_int32(n_chan), C.byref(p), _stream(stream)))
+        self._W, self._K = 1, int(n_chan)
+        return 0
+
+    def dev_status(self, stream=None):
+        st = C.c_int32()
+        _check(lib().dpe_bcs_dev_status(self._h, C.byref(st), _stream(stream)))
+        return st.value
+
     def set_graph(self, enable=True):
         """Replay repeated Updates as one hipGraph launch (needs a created stream, see dpe_hip.h)."""
         _check(lib().dpe_bcs_set_graph(self._h, C.c_int32(1 if enable else 0)))
@@ -389,6 +416,20 @@ class BatchCorrManifold:
                                     chan.ctypes.data_as(C.POINTER(ChanEnd)), _stream(stream)))
         self._W = W
         keys = C.c_void_p()   # the key sets alternate between Updates: refresh the device pointer
+        _check(lib().dpe_bcm_keys(self._h, C.byref(keys)))
+        self.Keys = keys.value
+        return 0
+
+    def UpdateDev(self, CodeScores, CarrScores, n_chan, ports, dim_t, rx_time, stream=None):
+        """One window with the inputs in DEVICE arrays (dpe_bcm_update_dev): ports = {field: device pointer} with the
+        pointer fields of dpe_bcm_ports_dev."""
+        if not self.Started:
+            raise DpeError("[BatchCorrManifold] Error: Update() Failed due to module not initialized")
+        p = BcmPortsDev(dimT=int(dim_t), reserved=0, **{k: _ptr(v).value for k, v in ports.items()})
+        _check(lib().dpe_bcm_update_dev(self._h, _ptr(CodeScores), _ptr(CarrScores), C.c_int32(n_chan), C.byref(p),
+                                        C.c_double(rx_time), _stream(stream)))
+        self._W = 1
+        keys = C.c_void_p()
         _check(lib().dpe_bcm_keys(self._h, C.byref(keys)))
         self.Keys = keys.value
         return 0

@@ -83,6 +83,83 @@ def test_dp_iteration_vs_reference_fixture(golden, oracle):
     bcs.Stop()
 
 
+def test_device_resident_ports_match_the_host_form(golden, oracle):
+    """dpe_bcs_update_dev / dpe_bcm_update_dev: the channel parameters where the reference keeps them -- device arrays in
+    the layout of cuChanMgr's ports (dpeflow.cpp:169-191), the full SatStates batch included -- on the O7 state.  The
+    one-block prep kernels derive in fp64 on the device what the host form derives on the host: banks within fp32
+    rounding of the host form (libm vs device cos/sin in one rotation constant), scores, arg-max and fix the same, and
+    the reference fixture's assertions hold for this form too."""
+    import torch
+    g = golden("o7_dp_iteration")
+    ho = dpe.handoff.read_handoff(helpers.HANDOFF)
+    K, fs, S = 8, float(g["fs"]), int(g["S"])
+    cm = oracle.ChanMgr(ho["prn_list"], ho["rc"], ho["ri"], ho["fc"], ho["fi"], ho["cp"], ho["cp_timestamp"],
+                        ho["TOW"], ho["eph"], ho["rxTime"], 0.02)
+    pos, vel = dpe.synth.spread_grid()
+    tg = np.unique(pos[:, 3])
+    X = ho["X_ECEF"]
+    batch, R = cm.start(X, X, tg)
+    L, B = 8, 48
+    dev = torch.device("cuda:0")
+    iq_d = torch.from_numpy(g["iq"]).to(dev)
+
+    def make():
+        bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=1, max_channels=K)
+        bcs.Start()
+        bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B, max_channels=K)
+        bcm.Start()
+        return bcs, bcm
+
+    # host form
+    bcs, bcm = make()
+    cs = dpe.engine.chan_start_array(ho["prn_list"], cm.rcStart, cm.riStart, cm.fc, cm.fi, cm.cpElaStart, cm.cpRef)
+    ce = dpe.engine.chan_end_array(batch[:, tg.size // 2], cm.rcEnd, cm.fc, cm.fi, cm.cpRefTOW, cm.cpElaEnd, cm.cpRef)
+    bw = dpe.engine.bcm_window_array(X[None, :], R[None, :], [cm.rxTime])
+    bcs.Update(iq_d, cs)
+    bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+    r0 = bcm.results()[0]
+    code0, carr0 = bcs.read_banks()
+    info0 = bcs.read_info()
+    ps0, vs0 = bcm.read_scores()
+    bcm.Stop(); bcs.Stop()
+
+    # device form: every port array on the device, in the reference's types
+    def d(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dt)).to(dev)
+    keep = dict(rc=d(cm.rcStart, np.float64), ri=d(cm.riStart, np.float64), fc=d(cm.fc, np.float64), fi=d(cm.fi, np.float64),
+                ela=d(cm.cpElaStart, np.int32), ref=d(cm.cpRef, np.int32), prn=d(ho["prn_list"], np.uint8),
+                x=d(X, np.float64), R=d(np.asarray(R).ravel(), np.float64), sat=d(batch, np.float64), rcE=d(cm.rcEnd, np.float64),
+                tow=d(cm.cpRefTOW, np.int32), elaE=d(cm.cpElaEnd, np.int32), ds=d([1], np.int32))
+    assert batch.shape == (K, tg.size, 8)
+    bcs, bcm = make()
+    bcs.UpdateDev(iq_d, K, dict(codePhaseStart=keep["rc"], carrierPhaseStart=keep["ri"], codeFrequency=keep["fc"],
+                                carrierFrequency=keep["fi"], cpElapsedStart=keep["ela"], cpReference=keep["ref"], validPRNs=keep["prn"]))
+    bcm.UpdateDev(bcs.CodeScores, bcs.CarrScores, K,
+                  dict(xCurrkk1=keep["x"], enu2ecef=keep["R"], satStates=keep["sat"], codePhaseEnd=keep["rcE"], codeFrequency=keep["fc"],
+                       carrierFrequency=keep["fi"], cpRefTOW=keep["tow"], cpElapsedEnd=keep["elaE"], cpRef=keep["ref"], dopplerSign=keep["ds"]),
+                  tg.size, cm.rxTime)
+    r1 = bcm.results()[0]
+    assert bcs.dev_status() == 0
+    code1, carr1 = bcs.read_banks()
+    info1 = bcs.read_info()
+    ps1, vs1 = bcm.read_scores()
+    for k in range(K):
+        assert np.abs(code1[0][k] - code0[0][k]).max() < 2e-7 * np.abs(code0[0][k]).max()
+        assert np.abs(carr1[0][k] - carr0[0][k]).max() < 2e-7 * np.abs(carr0[0][k]).max()
+    assert np.array_equal(info1[0], info0[0]) and np.array_equal(info1[1], info0[1]) and np.array_equal(info1[2], info0[2])
+    assert np.abs(ps1[0] - ps0[0]).max() < 1e-6 * ps0[0].max() and np.abs(vs1[0] - vs0[0]).max() < 1e-6 * vs0[0].max()
+    assert r1["posIndex"] == r0["posIndex"] == int(g["argmax_pos"]) and r1["velIndex"] == r0["velIndex"] == int(g["argmax_vel"])
+    assert np.array_equal(r1["zVal"], r0["zVal"]) and r1["posOutOfWindow"] == 0 and r1["velOutOfWindow"] == 0
+    assert np.abs(vs1[0][::97] - g["vel_every97"]).max() < TOL * g["vel_every97"].max()
+    assert np.abs(ps1[0][::97] - g["pos_every97"]).max() < helpers.POS_REF_NOISE * g["pos_every97"].max()
+    # a PRN outside 1..37 on the device is clamped and reported, never an out-of-table read
+    keep["prn"][0] = 99
+    bcs.UpdateDev(iq_d, K, dict(codePhaseStart=keep["rc"], carrierPhaseStart=keep["ri"], codeFrequency=keep["fc"],
+                                carrierFrequency=keep["fi"], cpElapsedStart=keep["ela"], cpReference=keep["ref"], validPRNs=keep["prn"]))
+    assert bcs.dev_status() & 1
+    bcm.Stop(); bcs.Stop()
+
+
 @pytest.mark.parametrize("kw,L,B", [
     (dict(seed=1, S=12500, K=4, G=5000, amp=200.0), 8, 32),                       # ragged grid (not /1024)
     (dict(seed=2, S=50000, K=8, G=20000, amp=48.0), 8, 48),                       # 45 dB-Hz
