@@ -173,9 +173,11 @@ typedef struct dpe_bcm_config {
                                  * differs from the continuous interpolation (batchcorrmanifold.cu:1798-1812): when an fp64 index
                                  * sits one rounding step below 2^m, idx + 1 rounds UP and the two neighbours are two apart, both
                                  * with weight ~1.  Only possible for the first channel and only when S / 2 is a power of two;
-                                 * the Update then re-evaluates the affected grid points in fp64 on the host, patches their
-                                 * scores and re-derives the arg-max (synchronous; needs writeScores).  0 (default): the
-                                 * continuous interpolation everywhere.  No effect when S / 2 is not a power of two. */
+                                 * the Update then finds the affected grid points with one device pass, re-evaluates them in fp64
+                                 * on the host, patches their scores with one scatter launch and re-derives the arg-max
+                                 * (synchronous: a few stream waits per Update, cost proportional to the number of affected points
+                                 * -- a handful; no fixed limit; needs writeScores and the host form of the inputs).  0 (default):
+                                 * the continuous interpolation everywhere.  No effect when S / 2 is not a power of two. */
     int32_t reserved;
 } dpe_bcm_config;
 
@@ -257,6 +259,10 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream);
  * pitch - gridSize floats behind a row are never written. */
 int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velScores_dev);
 int dpe_bcm_scores_pitch(dpe_bcm *h, int64_t *posPitch, int64_t *velPitch);
+/* The port in the reference's own type -- ConfigOutput(3, "PosScores", DOUBLE_t, GRID, ...), batchcorrmanifold.cu:2300, read by
+ * a DataLogger tap (datalogger.cu:215-278): window `window`'s scores as dense fp64 rows [gridSize] (either pointer may be NULL).
+ * Asynchronous on `stream`, after the Update that produced them. */
+int dpe_bcm_export_scores_f64(dpe_bcm *h, int32_t window, double *posScores_dev, double *velScores_dev, dpe_stream_t stream);
 /* Packed arg-max keys of the LAST update (two sets alternate: query after every Update), device uint64 [maxWindows][2] (pos,vel):
  * (score bits << 32) | (0xFFFFFFFF - globalIndex): an integer max over shards reproduces
  * the "first maximum" tie-break of thrust::max_element (:2589-2590).  For RCCL all-reduce. */

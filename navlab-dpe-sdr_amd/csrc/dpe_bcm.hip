@@ -16,6 +16,7 @@
 //
 // HBM traffic per window per manifold: 16 B/point grid read (float4, coalesced) + 4 B/point score
 // write; banks (K x (2L+1) float4 pairs) and SV coefficients live in LDS.
+#include <algorithm>
 #include <atomic>
 
 #include "dpe_common.h"
@@ -450,7 +451,46 @@ __global__ void bcm_prep_kernel(BcmPortsDev p, int K, double rxTime, double fs, 
 }
 #pragma clang fp contract(fast)
 
-// referencePair mode: arg-max of the position manifold re-derived from the (host-patched) score array.
+// PosScores in the reference's port type: one dense fp64 row (ConfigOutput(3, "PosScores", DOUBLE_t, GRID, ...), :2300)
+__global__ void bcm_export_f64_kernel(const float *__restrict__ row, long long G, double *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += (long long)gridDim.x * blockDim.x) out[i] = (double)row[i];
+}
+
+// referencePair mode, step 1: grid points whose FIRST-channel index lies within `tol` entries of the centre lag (bank entry L)
+// -- the only ones the reference's floor(idx) / floor(idx + 1) pair can treat differently (see ref_pair_fixup).  Candidates
+// are appended as (window << 40 | point); cand[0] counts them (it may run past the capacity: the host then grows the list).
+__global__ __launch_bounds__(256) void bcm_refpair_candidates_kernel(const float4 *__restrict__ grid, long long G, const BcmSvDev *__restrict__ sv,
+                                                                     int maxK, int L, double tol, unsigned long long *__restrict__ cand,
+                                                                     unsigned long long capacity)
+{
+    const int w = blockIdx.y;
+    const BcmSvDev p0 = sv[(size_t)w * maxK];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < G; i += (long long)gridDim.x * 256) {
+        const float4 g = grid[i];
+        const double a = (double)p0.ue * g.x + (double)p0.un * g.y + (double)p0.uu * g.z;
+        const double q = (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z;
+        const double idx0 = (double)p0.idx0 + (double)p0.g * ((double)g.w - a + (q - a * a) * (double)p0.h);
+        if (fabs(idx0 - (double)L) <= tol) {
+            const unsigned long long slot = atomicAdd(&cand[0], 1ull);
+            if (slot < capacity) cand[1 + slot] = ((unsigned long long)w << 40) | (unsigned long long)i;
+        }
+    }
+}
+
+// step 3: the re-evaluated scores go in with one launch; the scores they replace come back (weighted-mean correction)
+__global__ void bcm_patch_kernel(float *__restrict__ scores, long long pitch, const unsigned long long *__restrict__ where,
+                                 const float *__restrict__ value, float *__restrict__ old, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long wi = where[j];
+    float *dst = scores + (size_t)(wi >> 40) * pitch + (size_t)(wi & ((1ull << 40) - 1));
+    old[j] = *dst;
+    *dst = value[j];
+}
+
+// step 4: arg-max of the position manifold re-derived from the patched score array.
 __global__ void bcm_zero_pos_keys_kernel(unsigned long long *__restrict__ keys, int nWindows)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,7 +549,11 @@ struct dpe_bcm {
     bool compact = false;                   // 12-byte LDS bank entries (the banks of all channels would not fit otherwise)
     bool refPair = false;
     float2 *refBank_h = nullptr;            // pinned copy of the code banks of the last Update
-    float *refPatch_h = nullptr;            // pinned staging of patched scores
+    unsigned long long *refCand_d = nullptr;   // [1 + refCap] candidate list of the device prefilter (entry 0: count)
+    unsigned long long refCap = 0;
+    unsigned long long *refWhere_d = nullptr;  // [refPatchCap] patches: (window << 40 | point), value, replaced value
+    float *refValue_d = nullptr, *refOld_d = nullptr;
+    size_t refPatchCap = 0;
     std::vector<double> refWsum;            // [W][5] corrections of the weighted sums (patched - scanned score at offset x,y,z,t)
     long long refPatched = 0;               // points patched by the last Update (diagnostic)
     std::vector<dpe_bcm_window> win_h;
@@ -662,57 +706,99 @@ static int ref_pair_fixup(dpe_bcm *h, const float *codeBank_dev, int nWindows, i
     const int maxK = h->cfg.maxChannels, W = h->cfg.maxWindows;
     const long long G = h->cfg.posGridSize;
     const double fs = h->cfg.samplingFrequency;
+    h->refPatched = 0;
+    h->refWsum.assign((size_t)nWindows * 5, 0.0);
+    // ---- 1. candidates, on the device: one pass over the grid per window instead of W x G fp64 iterations on the host.
+    // The coefficients of this Update are in sv_d for batches; a single window passed them as kernel arguments: upload.
+    if (nWindows == 1) DPE_CHECK_HIP(hipMemcpyAsync(h->sv_d, h->sv_h, sizeof(BcmSvDev) * maxK, hipMemcpyHostToDevice, stream));
+    std::vector<unsigned long long> cand;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!h->refCand_d) {
+            if (h->refCap == 0) h->refCap = 1 << 16;
+            h->refCand_d = dev_alloc<unsigned long long>(1 + h->refCap);
+            DPE_REQUIRE(h->refCand_d, "[BatchCorrManifold] Update: referencePair: candidate list allocation failed (%llu entries)", h->refCap);
+        }
+        DPE_CHECK_HIP(hipMemsetAsync(h->refCand_d, 0, sizeof(unsigned long long), stream));
+        const unsigned gx = (unsigned)((G + 256 * 8 - 1) / (256 * 8));
+        hipLaunchKernelGGL(bcm_refpair_candidates_kernel, dim3(gx > 1024 ? 1024 : gx, nWindows), dim3(256), 0, stream, h->posGrid_d, G,
+                           h->sv_d, maxK, L, 5e-4, h->refCand_d, h->refCap);
+        unsigned long long n = 0;
+        DPE_CHECK_HIP(hipMemcpyAsync(&n, h->refCand_d, sizeof(n), hipMemcpyDeviceToHost, stream));
+        DPE_CHECK_HIP(hipStreamSynchronize(stream));
+        if (n > h->refCap) {   // more candidates than the list holds: grow it and run the pass again (nothing was modified yet)
+            DPE_REQUIRE(attempt == 0, "[BatchCorrManifold] Update: referencePair: candidate list overflow after growing");
+            (void)hipFree(h->refCand_d);
+            h->refCand_d = nullptr;
+            h->refCap = n + n / 4;
+            continue;
+        }
+        cand.resize((size_t)n);
+        if (n) DPE_CHECK_HIP(hipMemcpy(cand.data(), h->refCand_d + 1, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+        break;
+    }
+    if (cand.empty()) return 0;
+    std::sort(cand.begin(), cand.end());   // (the append order is not deterministic; the patches are)
+    // ---- 2. the reference's own expression (:1760-1816) for the candidates, fp64 on the host
     DPE_CHECK_HIP(hipMemcpyAsync(h->refBank_h, codeBank_dev, sizeof(float2) * (size_t)nWindows * maxK * nLag, hipMemcpyDeviceToHost, stream));
     DPE_CHECK_HIP(hipStreamSynchronize(stream));
-    h->refPatched = 0;
-    h->refWsum.assign((size_t)W * 5, 0.0);
-    struct Patch { int w; long long i; float sc; };
-    std::vector<Patch> patches;
-    for (int w = 0; w < nWindows; ++w) {
-        const BcmSvDev &p0 = h->sv_h[(size_t)(0 * W + w) * maxK + 0];          // first channel, position manifold
+    std::vector<unsigned long long> where;
+    std::vector<float> value;
+    for (unsigned long long wi : cand) {
+        const int w = (int)(wi >> 40);
+        const long long i = (long long)(wi & ((1ull << 40) - 1));
         const dpe_bcm_window &win = h->win_h[w];
-        for (long long i = 0; i < G; ++i) {
-            const double *g = h->posGrid_h.data() + 4 * i;
-            // prefilter: index of the first channel within 5e-4 samples of the centre lag (bank entry L)
-            const double a = (double)p0.ue * g[0] + (double)p0.un * g[1] + (double)p0.uu * g[2];
-            const double q = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
-            const double idx0 = (double)p0.idx0 + (double)p0.g * (g[3] - a + (q - a * a) * (double)p0.h);
-            if (std::fabs(idx0 - (double)L) > 5e-4) continue;
-            double idx, fi_, ci_;
-            if (!ref_pair_index(win, chan_host[(size_t)w * nChan], g, fs, S, 0, &idx, &fi_, &ci_)) continue;
-            if (ci_ - fi_ != 2.0) continue;                                   // the ordinary pair: the scan's value stands
-            double score = 0.0;
-            for (int k = 0; k < nChan; ++k) {
-                if (!ref_pair_index(win, chan_host[(size_t)w * nChan + k], g, fs, S, k, &idx, &fi_, &ci_)) continue;
-                const long long fin = (long long)fi_ - (long long)S * k - (S / 2 - L);
-                const long long cin = (long long)ci_ - (long long)S * k - (S / 2 - L);
-                if (fin < 0 || cin < 0 || fin >= nLag || cin >= nLag) continue;
-                const float2 *row = h->refBank_h + ((size_t)w * maxK + k) * nLag;
-                const double wc = idx - fi_, wf = ci_ - idx;                 // :1810-1811
-                const double vr = (double)row[cin].x * wc + (double)row[fin].x * wf;
-                const double vi = (double)row[cin].y * wc + (double)row[fin].y * wf;
-                score += std::pow(std::hypot(vr, vi), (double)h->cfg.lPower); // :1816
-            }
-            patches.push_back({w, i, (float)score});
+        const double *g = h->posGrid_h.data() + 4 * i;
+        double idx, fi_, ci_;
+        if (!ref_pair_index(win, chan_host[(size_t)w * nChan], g, fs, S, 0, &idx, &fi_, &ci_)) continue;
+        if (ci_ - fi_ != 2.0) continue;                                   // the ordinary pair: the scan's value stands
+        double score = 0.0;
+        for (int k = 0; k < nChan; ++k) {
+            if (!ref_pair_index(win, chan_host[(size_t)w * nChan + k], g, fs, S, k, &idx, &fi_, &ci_)) continue;
+            const long long fin = (long long)fi_ - (long long)S * k - (S / 2 - L);
+            const long long cin = (long long)ci_ - (long long)S * k - (S / 2 - L);
+            if (fin < 0 || cin < 0 || fin >= nLag || cin >= nLag) continue;
+            const float2 *row = h->refBank_h + ((size_t)w * maxK + k) * nLag;
+            const double wc = idx - fi_, wf = ci_ - idx;                 // :1810-1811
+            const double vr = (double)row[cin].x * wc + (double)row[fin].x * wf;
+            const double vi = (double)row[cin].y * wc + (double)row[fin].y * wf;
+            score += std::pow(std::hypot(vr, vi), (double)h->cfg.lPower); // :1816
+        }
+        where.push_back(wi);
+        value.push_back((float)score);
+    }
+    h->refPatched = (long long)where.size();
+    if (where.empty()) return 0;
+    // ---- 3. one upload, one scatter launch (the buffers grow with the patch count: no fixed limit)
+    const size_t n = where.size();
+    if (n > h->refPatchCap) {
+        (void)hipFree(h->refWhere_d); (void)hipFree(h->refValue_d); (void)hipFree(h->refOld_d);
+        h->refPatchCap = n + n / 4 + 256;
+        h->refWhere_d = dev_alloc<unsigned long long>(h->refPatchCap);
+        h->refValue_d = dev_alloc<float>(h->refPatchCap);
+        h->refOld_d = dev_alloc<float>(h->refPatchCap);
+        if (!h->refWhere_d || !h->refValue_d || !h->refOld_d) {
+            h->refPatchCap = 0;
+            set_error("[BatchCorrManifold] Update: referencePair: patch buffers (%zu entries) allocation failed; the published scores are the scan's, unpatched", n);
+            return -1;
         }
     }
-    h->refPatched = (long long)patches.size();
-    if (patches.empty()) return 0;
-    DPE_REQUIRE(patches.size() <= 65536, "[BatchCorrManifold] Update: referencePair: %zu points to patch (limit 65536)", patches.size());
-    for (size_t n = 0; n < patches.size(); ++n) {
-        const Patch &pt = patches[n];
-        float *dst = h->posScores_d + (size_t)pt.w * h->posPitch + pt.i;
-        float old = 0.f;
-        if (h->cfg.weightedMean) DPE_CHECK_HIP(hipMemcpy(&old, dst, sizeof(float), hipMemcpyDeviceToHost));
-        h->refPatch_h[n] = pt.sc;
-        DPE_CHECK_HIP(hipMemcpyAsync(dst, h->refPatch_h + n, sizeof(float), hipMemcpyHostToDevice, stream));
-        if (h->cfg.weightedMean) {
-            const double *g = h->posGrid_h.data() + 4 * pt.i;
-            const double d = (double)pt.sc - (double)old;
-            double *c = h->refWsum.data() + (size_t)pt.w * 5;
+    DPE_CHECK_HIP(hipMemcpyAsync(h->refWhere_d, where.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice, stream));
+    DPE_CHECK_HIP(hipMemcpyAsync(h->refValue_d, value.data(), sizeof(float) * n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(bcm_patch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, h->posScores_d, h->posPitch, h->refWhere_d,
+                       h->refValue_d, h->refOld_d, (int)n);
+    if (h->cfg.weightedMean) {
+        std::vector<float> old(n);
+        DPE_CHECK_HIP(hipMemcpyAsync(old.data(), h->refOld_d, sizeof(float) * n, hipMemcpyDeviceToHost, stream));
+        DPE_CHECK_HIP(hipStreamSynchronize(stream));
+        for (size_t j = 0; j < n; ++j) {
+            const int w = (int)(where[j] >> 40);
+            const double *g = h->posGrid_h.data() + 4 * (long long)(where[j] & ((1ull << 40) - 1));
+            const double d = (double)value[j] - (double)old[j];
+            double *c = h->refWsum.data() + (size_t)w * 5;
             c[0] += d; c[1] += d * g[0]; c[2] += d * g[1]; c[3] += d * g[2]; c[4] += d * g[3];
         }
     }
+    // ---- 4. arg-max from the patched scores
     hipLaunchKernelGGL(bcm_zero_pos_keys_kernel, dim3((nWindows + 63) / 64), dim3(64), 0, stream, keys_d, nWindows);
     const unsigned gx = (unsigned)((G + 256 * 16 - 1) / (256 * 16));
     hipLaunchKernelGGL(bcm_rekey_kernel, dim3(gx > 512 ? 512 : gx, nWindows), dim3(256), 0, stream, h->posScores_d, G, h->posPitch,
@@ -807,8 +893,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     allow_big_lds<0, true, false>();  allow_big_lds<1, true, false>();  allow_big_lds<2, true, false>();
     allow_big_lds<0, false, false>(); allow_big_lds<1, false, false>(); allow_big_lds<2, false, false>();
     if (h->refPair &&
-        (hipHostMalloc((void **)&h->refBank_h, W * K * (size_t)(2 * cfg->lagHalfWidth + 1) * sizeof(float2), hipHostMallocDefault) != hipSuccess ||
-         hipHostMalloc((void **)&h->refPatch_h, 65536 * sizeof(float), hipHostMallocDefault) != hipSuccess)) {
+        hipHostMalloc((void **)&h->refBank_h, W * K * (size_t)(2 * cfg->lagHalfWidth + 1) * sizeof(float2), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: host allocation failed");
         dpe_bcm_destroy(h);
         return -1;
@@ -849,7 +934,7 @@ int dpe_bcm_destroy(dpe_bcm *h)
     if (h->keys_h) (void)hipHostFree(h->keys_h);
     if (h->devWin_h) (void)hipHostFree(h->devWin_h);
     if (h->refBank_h) (void)hipHostFree(h->refBank_h);
-    if (h->refPatch_h) (void)hipHostFree(h->refPatch_h);
+    (void)hipFree(h->refCand_d); (void)hipFree(h->refWhere_d); (void)hipFree(h->refValue_d); (void)hipFree(h->refOld_d);
     for (hipEvent_t e : h->stagingFree)
         if (e) (void)hipEventDestroy(e);
     h->graphs.clear();
@@ -1138,6 +1223,21 @@ int dpe_bcm_scores(dpe_bcm *h, const float **posScores_dev, const float **velSco
     DPE_REQUIRE(h->cfg.writeScores, "[BatchCorrManifold] scores: created with writeScores=0");
     if (posScores_dev) *posScores_dev = h->posScores_d;
     if (velScores_dev) *velScores_dev = h->velScores_d;
+    return 0;
+}
+
+int dpe_bcm_export_scores_f64(dpe_bcm *h, int32_t window, double *posScores_dev, double *velScores_dev, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h && h->cfg.writeScores, "[BatchCorrManifold] export_scores_f64: created with writeScores=0");
+    DPE_REQUIRE(window >= 0 && window < h->lastW, "[BatchCorrManifold] export_scores_f64: bad window %d", window);
+    const long long Gp = h->cfg.posGridSize, Gv = h->cfg.velGridSize;
+    if (posScores_dev)
+        hipLaunchKernelGGL(dpe::bcm_export_f64_kernel, dim3((unsigned)((Gp + 1023) / 1024 > 1024 ? 1024 : (Gp + 1023) / 1024)), dim3(256), 0,
+                           (hipStream_t)stream, h->posScores_d + (size_t)window * h->posPitch, Gp, posScores_dev);
+    if (velScores_dev)
+        hipLaunchKernelGGL(dpe::bcm_export_f64_kernel, dim3((unsigned)((Gv + 1023) / 1024 > 1024 ? 1024 : (Gv + 1023) / 1024)), dim3(256), 0,
+                           (hipStream_t)stream, h->velScores_d + (size_t)window * h->velPitch, Gv, velScores_dev);
+    DPE_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

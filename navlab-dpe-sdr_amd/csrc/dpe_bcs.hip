@@ -1114,6 +1114,7 @@ struct dpe_bcs {
     // expansion, or DPE_BCS_FORCE_FFT=1 at create (A/B tests)
     bool fftMode = false, havePlans = false;
     hipfftHandle planS3 = 0, planS2 = 0, planC = 0;   // length S: batch 3 chunk K (forward) / 2 chunk K (inverse); length C: batch chunk K
+    int planK = 0;        // channels per window the plans are made for (the Update's nChan: re-planned when it changes)
     int fftChunkW = 1;
     float2 *fftWork_d = nullptr;
     int chipDbg = 0;                   // -DDPE_EXPERIMENTS builds only, DPE_BCS_CHIP_DBG: skips parts of the chip kernel (timing; wrong results)
@@ -1288,14 +1289,10 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
             h->fftChunkW = (int)chunk;
             h->fftWork_d = dev_alloc<float2>(chunk * perW);
             DPE_REQUIRE(h->fftWork_d, "[BatchCorrScores] create: FFT work buffer (%zu MB) allocation failed", chunk * perW * 8 >> 20);
-            int nS[1] = {S}, nC[1] = {(int)C};
             DPE_REQUIRE(C < (1ll << 31), "[BatchCorrScores] create: carrier transform length %lld too long for the FFT path", C);
-            const int b3 = (int)(3 * chunk * K), b2 = (int)(2 * chunk * K), b1 = (int)(chunk * K);
-            DPE_REQUIRE(hipfftPlanMany(&h->planS3, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b3) == HIPFFT_SUCCESS &&
-                        hipfftPlanMany(&h->planS2, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b2) == HIPFFT_SUCCESS &&
-                        hipfftPlanMany(&h->planC, 1, nC, nullptr, 1, (int)C, nullptr, 1, (int)C, HIPFFT_C2C, b1) == HIPFFT_SUCCESS,
-                        "[BatchCorrScores] create: hipfftPlanMany failed (S = %d, C = %lld, %d rows)", S, C, b1);
-            h->havePlans = true;
+            // (rows of a short last chunk / of unused channels are transformed but never read: keep them finite)
+            DPE_CHECK_HIP(hipMemset(h->fftWork_d, 0, chunk * perW * sizeof(float2)));
+            // the batched plans are made at the first Update, for the channel count actually used (and again when it changes)
         }
         return 0;
     };
@@ -1412,17 +1409,35 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples, S, h->sums_d,
                            (uint4 *)nullptr, (const uint4 *)nullptr, 0);
         h->prof.end(0, stream);
+        const int chunk = h->fftChunkW;
+        if (!h->havePlans || h->planK != nChan) {   // batched over the channels this host really tracks, not over maxChannels
+            if (h->havePlans) { (void)hipfftDestroy(h->planS3); (void)hipfftDestroy(h->planS2); (void)hipfftDestroy(h->planC); h->havePlans = false; }
+            int nS[1] = {S}, nC[1] = {(int)C};
+            const int b3 = 3 * chunk * nChan, b2 = 2 * chunk * nChan, b1 = chunk * nChan;
+            const bool ok3 = hipfftPlanMany(&h->planS3, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b3) == HIPFFT_SUCCESS;
+            const bool ok2 = ok3 && hipfftPlanMany(&h->planS2, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b2) == HIPFFT_SUCCESS;
+            const bool ok1 = ok2 && hipfftPlanMany(&h->planC, 1, nC, nullptr, 1, (int)C, nullptr, 1, (int)C, HIPFFT_C2C, b1) == HIPFFT_SUCCESS;
+            if (!ok1) {
+                if (ok3) (void)hipfftDestroy(h->planS3);
+                if (ok2) (void)hipfftDestroy(h->planS2);
+                set_error("[BatchCorrScores] Update: hipfftPlanMany failed (S = %d, C = %lld, %d rows)", S, C, b1);
+                return -1;
+            }
+            h->havePlans = true;
+            h->planK = nChan;
+        }
         h->prof.begin(1, stream);
         if (hipfftSetStream(h->planS3, stream) != HIPFFT_SUCCESS || hipfftSetStream(h->planS2, stream) != HIPFFT_SUCCESS ||
             hipfftSetStream(h->planC, stream) != HIPFFT_SUCCESS) {
+            h->prof.end(1, stream);
             set_error("[BatchCorrScores] Update: hipfftSetStream failed");
             return -1;
         }
-        const int chunk = h->fftChunkW;
         const size_t plane = (size_t)chunk * nChan * S;
         const int gxS = S / 256 < 64 ? (S / 256 > 0 ? S / 256 : 1) : 64;
 #define DPE_FFT_EXEC(plan, ptr, dir)                                                                                   \
     if (hipfftExecC2C(plan, (hipfftComplex *)(ptr), (hipfftComplex *)(ptr), dir) != HIPFFT_SUCCESS) {                 \
+        h->prof.end(1, stream);                                                                                        \
         set_error("[BatchCorrScores] Update: hipfftExecC2C failed");                                                   \
         return -1;                                                                                                     \
     }
@@ -1699,6 +1714,7 @@ int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream)
 int dpe_bcs_set_graph(dpe_bcs *h, int32_t enable)
 {
     DPE_REQUIRE(h, "[BatchCorrScores] set_graph: null handle");
+    DPE_REQUIRE(!(enable && h->fftMode), "[BatchCorrScores] set_graph: the full-length FFT form (this handle's lag / bin windows) is not captured as a hipGraph");
     h->graphs.enabled = enable != 0;
     if (!enable) h->graphs.clear();
     return 0;

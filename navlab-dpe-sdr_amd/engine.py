@@ -29,7 +29,7 @@ EXPORTS = [
     "dpe_hbm_ceiling", "dpe_bcs_stage1_kernel",
     "dpe_set_device", "dpe_comm_create", "dpe_comm_wrap_nccl", "dpe_comm_destroy", "dpe_comm_rank", "dpe_comm_allreduce_max_u64",
     "dpe_comm_allgather", "dpe_bcm_exchange_keys", "dpe_bcs_allgather_banks",
-    "dpe_bcs_update_dev", "dpe_bcs_dev_status", "dpe_bcm_update_dev",
+    "dpe_bcs_update_dev", "dpe_bcs_dev_status", "dpe_bcm_update_dev", "dpe_bcm_export_scores_f64",
 ]
 
 
@@ -466,6 +466,11 @@ class BatchCorrManifold:
         ps = d2h(self.PosScores, self._W * self.PosScoresPitch * 4, np.float32, stream).reshape(self._W, self.PosScoresPitch)[:, :Gp]
         vs = d2h(self.VelScores, self._W * self.VelScoresPitch * 4, np.float32, stream).reshape(self._W, self.VelScoresPitch)[:, :Gv]
         return np.ascontiguousarray(ps), np.ascontiguousarray(vs)
+
+    def export_scores_f64(self, window, pos_dev, vel_dev, stream=None):
+        """PosScores / its velocity twin as the reference's dense fp64 rows (dpe_bcm_export_scores_f64)."""
+        _check(lib().dpe_bcm_export_scores_f64(self._h, C.c_int32(window), _ptr(pos_dev) if pos_dev is not None else None,
+                                               _ptr(vel_dev) if vel_dev is not None else None, _stream(stream)))
 
     def set_graph(self, enable=True):
         """Replay repeated Updates as one hipGraph launch (needs a created stream, see dpe_hip.h)."""

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-6
 
 
-def _banks(case, L, B, force_fft=False):
+def _banks(case, L, B, force_fft=False, max_channels=None, timing=None):
     import torch
     iq, cs, _, _ = helpers.pack_gpu_inputs(case)
     W, K = cs.shape
@@ -21,11 +21,19 @@ def _banks(case, L, B, force_fft=False):
         os.environ["DPE_BCS_FORCE_FFT"] = "1"
     try:
         bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=L, bin_half_width=B,
-                                  max_windows=W, max_channels=K)
+                                  max_windows=W, max_channels=max_channels or K)
         bcs.Start()
     finally:
         os.environ.pop("DPE_BCS_FORCE_FFT", None)
-    bcs.Update(torch.from_numpy(iq).to("cuda:0"), cs)
+    d = torch.from_numpy(iq).to("cuda:0")
+    bcs.Update(d, cs)
+    if timing is not None:          # steady-state time of one Update (plans exist after the first)
+        torch.cuda.synchronize()
+        bcs.profile(True)
+        for _ in range(3):
+            bcs.Update(d, cs)
+        p = bcs.profile(False)
+        timing["ms"] = sum(v[0] for v in p.values()) / 3.0
     code, carr = bcs.read_banks()
     info = bcs.read_info()
     kern = bcs.stage1_kernel
@@ -52,6 +60,18 @@ def test_lag_window_of_400_samples():
     code, carr, info, kern = _banks(case, 400, 48)
     assert kern.startswith("hipfft")
     _check_vs_oracle(case, 400, 48, code, carr, info)
+
+
+def test_fft_path_at_config_h_scale():
+    """The fallback at BASELINE configs[2]'s lengths: S = 500000 (2^5 5^6), C = 4194304, L = 400 -- two of twelve possible
+    channels tracked, so the batched plans are made for two rows per plane, not twelve.  Banks vs the oracle's direct sums."""
+    case = helpers.make_case(seed=77, fs=25e6, S=500000, K=2, G=64, amp=60.0)
+    assert case["C"] == 4194304
+    t = {}
+    code, carr, info, kern = _banks(case, 400, 16, max_channels=12, timing=t)
+    assert kern.startswith("hipfft")
+    print("FFT form, S = 500000, C = 4194304, 2 channels: %.3f ms per window" % t["ms"])
+    _check_vs_oracle(case, 400, 16, code, carr, info)
 
 
 def test_bin_window_beyond_the_moment_expansion():

@@ -231,6 +231,32 @@ def test_dense_export_matches_reference_layout(golden):
     bcs.Stop()
 
 
+def test_pos_scores_port_in_the_reference_type():
+    """dpe_bcm_export_scores_f64: the PosScores port as the reference declares it (DOUBLE_t, GRID: one dense fp64 row,
+    batchcorrmanifold.cu:2300) for a chosen window of a batch whose fp32 rows are pitched."""
+    import torch
+    case = helpers.make_case(seed=31, S=12500, K=4, G=3001, amp=200.0, W=3)
+    iq, cs, ce, bw = helpers.pack_gpu_inputs(case)
+    L, B = 8, 32
+    bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=L, bin_half_width=B, max_windows=3, max_channels=4)
+    bcs.Start()
+    bcm = dpe.BatchCorrManifold(case["fs"], case["S"], bcs.NumFFTPoints, case["pos"], case["vel"], lag_half_width=L, bin_half_width=B,
+                                max_windows=3, max_channels=4)
+    bcm.Start()
+    bcs.Update(torch.from_numpy(iq).to("cuda:0"), cs)
+    bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
+    ps, vs = bcm.read_scores()
+    assert bcm.PosScoresPitch > 3001
+    p64 = torch.full((3001,), -1.0, dtype=torch.float64, device="cuda:0")
+    v64 = torch.full((3001,), -1.0, dtype=torch.float64, device="cuda:0")
+    bcm.export_scores_f64(2, p64, v64)
+    torch.cuda.synchronize()
+    assert np.array_equal(p64.cpu().numpy(), ps[2].astype(np.float64)) and np.array_equal(v64.cpu().numpy(), vs[2].astype(np.float64))
+    with pytest.raises(dpe.DpeError):
+        bcm.export_scores_f64(3, p64, None)
+    bcm.Stop(); bcs.Stop()
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
