@@ -12,8 +12,9 @@ path over a batch of `--windows` windows resident in HBM: BatchCorrScores (DC su
 BatchCorrManifold (pos scan, vel scan, fused arg-max) for every window, each with its own channel state.
 metric = manifold gridpoints x SVs correlated per second (both manifolds), whole job.
 
-Without --config the run first prints one line each for the other two configurations BASELINE.json names (same format,
-"headline": false):  H (configs[2]: 25 Msps, 12 SVs, 1e5-point grids; N = 1 only) and M (configs[3]: 1e6-point GLOBAL grids
+Without --config the run first prints one line each for the other configurations BASELINE.json names (same format,
+"headline": false):  acq (configs[4]: cold-start acquisition search, N = 1 only), H (configs[2]: 25 Msps, 12 SVs, 1e5-point
+grids; N = 1 only) and M (configs[3]: 1e6-point GLOBAL grids
 sharded over the N GPUs, strong scaling), then the headline line.
 
 N > 1: the grid dimension is sharded (R, H: each rank scores its own contiguous slice of an N-times larger global grid ->
@@ -126,55 +127,83 @@ def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0):
     return out
 
 
-def acq_main(mode):
-    """`bench.py --acq MODE`: coarse-acquisition timing on one MI355X (BASELINE.json configs[4] shape): 32 PRNs x
-    125 Doppler bins x all 2500 code delays of a 10 ms / 2.5 Msps window.  Prints one JSON line: search cells per second
-    (PRN x bin x delay), ms per window, and -- as its cpu_baseline leg -- the oracle's numpy fp64 restatement of the
-    reference's coarse_acquisition on a bounded sample.  Not the headline metric."""
+def acq_line(modes=("coherent", "textbook"), cpu_budget_s=5.0):
+    """Cold-start acquisition (BASELINE.json configs[4]) as a measured line: 32 PRNs x 125 Doppler bins x all
+    2500 code delays of a 10 ms / 2.5 Msps window, the whole search (wipe-off + fold, batched rocFFT transforms, spectrum
+    product, inverse transforms, |.| surface, per-delay maximum, peak statistics) timed between HIP events on its stream.
+    `value` = search cells (PRN x bin x delay) per second of the reference's coherent semantics (fixture O8); `modes` holds the
+    textbook "1 ms coherent x 10 non-coherent" form too (BASELINE's wording; not a reference algorithm).  Roofline: the
+    search is memory-bound by construction -- its batched transforms are 6e8 flop per window against 40 MB of surface -- so the
+    stanza prices the algorithmic bytes (samples read once + the |.| surface written once) against the HBM peak and quotes
+    the transform flop rate beside it.  cpu_baseline: the oracle's numpy restatement of coarse_acquisition on a bounded sample."""
     import torch
     import navlab_dpe_sdr_amd as dpe
-    fs, S = 2.5e6, 25000
+    fs, S, N = 2.5e6, 25000, 10
+    M = S // N
     ch = dpe.synth.random_channels(77, 6, prns=[3, 7, 11, 18, 22, 31])
     ch["cp_ref"] = ch["cp"].copy()
     iq = dpe.synth.gen_iq(78, fs, S, ch, amp=150.0, flip=np.zeros(6, dtype=bool))
     bins = np.arange(-62, 63) * 100.0
     prns = list(range(1, 33))
-    acq = dpe.Acquisition(fs, S, prns, bins, mode=mode, prn_chunk=32)
     d = torch.from_numpy(iq).to("cuda:0")
-    for _ in range(3):
-        acq.search(d)
-    torch.cuda.synchronize()
-    t = dpe.engine.HipEventTimer()
-    n = 20
-    t.start()
-    for _ in range(n):
-        acq.search(d)
-    t.stop()
-    ms = t.elapsed_ms() / n
-    res = acq.results()
-    acq.search_signal(d)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        acq.search_signal(d)                    # coarse + fine frequency, host-synchronous
-    ms_full = (time.perf_counter() - t0) / 5 * 1e3
-    t0 = time.perf_counter()
-    for _ in range(5):
-        acq.search(d); acq.results()
-    ms_coarse = (time.perf_counter() - t0) / 5 * 1e3
-    cells = len(prns) * bins.size * (S // 10)
-    out = {"metric": "acquisition search cells (PRN x Doppler bin x code delay) per second", "mode": mode,
-           "value": cells / (ms * 1e-3), "ms_per_window": ms, "x_realtime": 10.0 / ms,
-           "search_signal_ms_per_window": ms_full, "search_plus_results_ms": ms_coarse,
-           "found": sorted(r["prn"] for r in res if r["found"]), "truth": sorted(int(p) for p in ch["prn"])}
+    cells = len(prns) * bins.size * M
+    per_mode = {}
+    found = None
+    for mode in modes:
+        acq = dpe.Acquisition(fs, S, prns, bins, mode=mode, prn_chunk=32)
+        for _ in range(5):
+            acq.search(d)
+        torch.cuda.synchronize()
+        t = dpe.engine.HipEventTimer()
+        n = 50
+        t.start()
+        for _ in range(n):
+            acq.search(d)
+        t.stop()
+        ms = t.elapsed_ms() / n
+        res = acq.results()
+        acq.search_signal(d)                        # (the first call plans the fine-frequency transform)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            acq.search_signal(d)                    # coarse + statistics + fine frequency, host-synchronous
+        ms_full = (time.perf_counter() - t0) / 5 * 1e3
+        per_mode[mode] = {"ms_per_window": ms, "cells_per_s": cells / (ms * 1e-3), "search_signal_ms_per_window": ms_full}
+        if mode == modes[0]:
+            found = sorted(r["prn"] for r in res if r["found"])
+            assert found == sorted(int(p) for p in ch["prn"]), "acquisition did not find the simulated PRNs"
+        del acq
+    ms0 = per_mode[modes[0]]["ms_per_window"]
+    alg_bytes = 4.0 * S + 4.0 * cells                    # int16 I/Q once + the fp32 |.| surface once
+    n_fft = bins.size + len(prns) * bins.size            # forward (time-folded rows) + inverse transforms of length M
+    flops = n_fft * 5.0 * M * math.log2(M) + 6.0 * cells
+    out = {"metric": "acquisition search cells (PRN x Doppler bin x code delay) per second", "value": cells / (ms0 * 1e-3),
+           "unit": "cell/s", "n_gpus": 1, "ms_per_step": ms0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "headline": False,
+           "config": {"workload": "acq: cold-start acquisition, 32 PRNs x 125 Doppler bins (100 Hz) x 2500 code delays, 10 ms at 2.5 Msps "
+                                  "(BASELINE.json configs[4])", "mode": modes[0], "prns": len(prns), "bins": int(bins.size), "delays": M},
+           "x_realtime": 10.0 / ms0, "modes": per_mode, "found": found,
+           "roofline": {"bound": "hbm", "bound_physical": "launch latency + the 80 MB intermediate surface (Infinity-Cache resident)",
+                        "kernel": "dpe_acq_search (acq_wipe_fold + rocFFT fwd + acq_mul + rocFFT inv + acq_fold + colmax / peak / stats)",
+                        "achieved": alg_bytes / (ms0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / (ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms0,
+                        "transform_flops_per_window": flops, "achieved_TFLOPs": flops / (ms0 * 1e-3) / 1e12}}
     from oracle import oracle as o
     t0 = time.perf_counter()
     k = 0
-    while time.perf_counter() - t0 < 8.0:
-        o.coarse_acquisition(iq, fs, prns[k % 32], bins, coherent=(mode == "coherent"), mode="textbook" if mode == "textbook" else None)
+    while time.perf_counter() - t0 < cpu_budget_s:
+        o.coarse_acquisition(iq, fs, prns[k % 32], bins, coherent=True)
         k += 1
     dt = time.perf_counter() - t0
-    out["cpu_baseline"] = {"value": k * bins.size * (S // 10) / dt, "cores": 1, "kind": "port", "sample": "%d PRNs, %.1f s" % (k, dt)}
-    print(json.dumps(out))
+    out["cpu_baseline"] = {"value": k * bins.size * M / dt, "unit": "cell/s", "cores": 1, "kind": "port",
+                           "sample": "%d PRNs x 125 bins (numpy restatement of coarse_acquisition, fp64), %.1f s" % (k, dt)}
+    return out
+
+
+def acq_main(mode):
+    """`bench.py --acq MODE`: the acquisition line alone, for the chosen mode first."""
+    modes = (mode,) + tuple(m for m in ("coherent", "textbook") if m != mode)
+    print(json.dumps(acq_line(modes=modes if mode != "noncoherent" else (mode,), cpu_budget_s=8.0)))
 
 
 class Ctx:
@@ -556,6 +585,7 @@ def main():
     if args.config is None and not args.no_extras:
         extra_steps = min(args.steps, 20)
         if ctx.world == 1 and not ctx.use_dist:
+            emit(acq_line())                      # BASELINE.json configs[4]
             out, _ = run_workload("H", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
             emit(out)
         out, cached = run_workload("M", ctx, args, extra_steps, min(args.warmup, 2), headline=False)

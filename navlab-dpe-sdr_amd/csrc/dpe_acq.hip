@@ -6,13 +6,13 @@
 // (complex sum = "coherent", sum of magnitudes = "non-coherent"), then peak statistics
 // (cppr, cppm = peak / 10 %-trimmed mean, found <=> cppm > 2).
 //
-// Here: the bin loop becomes one batched FFT (rocFFT through hipFFT -- an FFT is intrinsic to a
+// Here: the bin loop becomes one batched FFT (rocFFT, called directly: dpe_fft.h -- an FFT is intrinsic to a
 // full code-delay search), the replica spectra (conj, 1/S folded in) are precomputed once per PRN at
 // create, and three small HIP kernels do wipe-off, spectrum multiply and fold + per-lag max over bins.
 // mode 0 / 1 = the reference's coherent / non-coherent semantics (pinned by fixture O8);
 // mode 2 = the textbook "1 ms coherent x N non-coherent" of BASELINE.json (NOT in the reference: parity
 // unpinned, checked against the oracle's own restatement only).
-#include <hipfft/hipfft.h>
+#include "dpe_fft.h"
 
 #include <algorithm>
 
@@ -385,8 +385,7 @@ struct dpe_acq {
     dpe_acq_config cfg;
     int S, N, M, B, P, len, chunk;   // len = FFT length (S in mode 1; M in modes 0 and 2)
     int SX;                          // samples per Doppler row after the wipe-off (M in mode 0: time-folded)
-    hipfftHandle planFwd = 0, planInv = 0;
-    bool haveFwd = false, haveInv = false;
+    dpe::FftPlan planFwd, planInv;
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
     float *surf_d = nullptr, *mp_d = nullptr;
     int *peakIdx_d = nullptr;   // [2][P]: max_code_idx, max_dopp_idx
@@ -394,7 +393,7 @@ struct dpe_acq {
     bool searched = false;
     // fine-frequency stage, allocated on first use
     int fineC = 0, fineLo = 0, fineHi = -1;
-    hipfftHandle planFine = 0;
+    dpe::FftPlan planFine;
     bool haveFine = false;
     float2 *F_d = nullptr, *fineVal_d = nullptr;
     int *fineIdx_d = nullptr;
@@ -403,23 +402,14 @@ struct dpe_acq {
     int8_t *chips_d = nullptr;
 };
 
-#define DPE_CHECK_FFT(expr)                                                                  \
-    do {                                                                                     \
-        hipfftResult r_ = (expr);                                                            \
-        if (r_ != HIPFFT_SUCCESS) {                                                          \
-            dpe::set_error("%s:%d: %s -> hipfft error %d", __FILE__, __LINE__, #expr, (int)r_); \
-            return -1;                                                                       \
-        }                                                                                    \
-    } while (0)
-
 extern "C" {
 
 int dpe_acq_destroy(dpe_acq *h)
 {
     if (!h) return 0;
-    if (h->haveFwd) hipfftDestroy(h->planFwd);
-    if (h->haveInv) hipfftDestroy(h->planInv);
-    if (h->haveFine) hipfftDestroy(h->planFine);
+    h->planFwd.destroy();
+    h->planInv.destroy();
+    h->planFine.destroy();
     void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->stats_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->stats_h) (void)hipHostFree(h->stats_h);
@@ -458,20 +448,11 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         dpe_acq_destroy(h);
         return -1;
     }
-    int n[1] = {h->len};
     const int batchFwd = (int)(B * (S / h->len)), batchInv = (int)(h->chunk * B * (S / h->len));
-    if (hipfftPlanMany(&h->planFwd, 1, n, nullptr, 1, h->len, nullptr, 1, h->len, HIPFFT_C2C, batchFwd) != HIPFFT_SUCCESS) {
-        set_error("[Acquisition] create: hipfftPlanMany(forward, n=%d, batch=%d) failed", h->len, batchFwd);
-        dpe_acq_destroy(h);
+    if (h->planFwd.create((size_t)h->len, (size_t)batchFwd, false) || h->planInv.create((size_t)h->len, (size_t)batchInv, true)) {
+        dpe_acq_destroy(h);   // (the message is rocFFT's, from dpe_fft.h)
         return -1;
     }
-    h->haveFwd = true;
-    if (hipfftPlanMany(&h->planInv, 1, n, nullptr, 1, h->len, nullptr, 1, h->len, HIPFFT_C2C, batchInv) != HIPFFT_SUCCESS) {
-        set_error("[Acquisition] create: hipfftPlanMany(inverse, n=%d, batch=%d) failed", h->len, batchInv);
-        dpe_acq_destroy(h);
-        return -1;
-    }
-    h->haveInv = true;
     // nominal-rate replica: chips[floor(n / fs * F_CA) mod 1023] (correlator.py:66, rawfile.py:164-166), fp64 on the host
     std::vector<float2> rep(P * (size_t)h->len);
     int8_t chips[kLCA];
@@ -488,17 +469,16 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             rep[p * h->len + i] = make_float2((float)acc, 0.f);
         }
     }
-    hipfftHandle pr = 0;
+    FftPlan pr;
     const auto finish = [&]() -> int {   // a failure here must leak neither the handle nor the temporary plan
         DPE_CHECK_HIP(hipMemcpy(h->Rc_d, rep.data(), sizeof(float2) * rep.size(), hipMemcpyHostToDevice));
-        DPE_CHECK_FFT(hipfftPlanMany(&pr, 1, n, nullptr, 1, h->len, nullptr, 1, h->len, HIPFFT_C2C, (int)P));
-        DPE_CHECK_FFT(hipfftExecC2C(pr, (hipfftComplex *)h->Rc_d, (hipfftComplex *)h->Rc_d, HIPFFT_FORWARD));
+        if (pr.create((size_t)h->len, P, false) || pr.exec(nullptr, h->Rc_d)) return -1;
         hipLaunchKernelGGL(acq_conj_scale_kernel, dim3(256), dim3(256), 0, 0, h->Rc_d, (long long)(P * h->len), 1.0f / (float)h->len);
         DPE_CHECK_HIP(hipDeviceSynchronize());
         return 0;
     };
     const int rc = finish();
-    if (pr) hipfftDestroy(pr);
+    pr.destroy();
     if (rc) {
         dpe_acq_destroy(h);
         return -1;
@@ -512,8 +492,6 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     using namespace dpe;
     DPE_REQUIRE(h && samples_dev, "[Acquisition] search: null argument");
     hipStream_t st = (hipStream_t)stream_;
-    DPE_CHECK_FFT(hipfftSetStream(h->planFwd, st));
-    DPE_CHECK_FFT(hipfftSetStream(h->planInv, st));
     const int S = h->SX, B = h->B, P = h->P, M = h->M;
     if (h->cfg.mode == 0)
         hipLaunchKernelGGL(acq_wipe_fold_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, samples_dev, M, h->N,
@@ -521,13 +499,13 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     else
         hipLaunchKernelGGL(acq_wipe_kernel, dim3((S + 1023) / 1024, B), dim3(256), 0, st, samples_dev, S, B, h->cfg.binStartHz,
                            h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d);
-    DPE_CHECK_FFT(hipfftExecC2C(h->planFwd, (hipfftComplex *)h->X_d, (hipfftComplex *)h->X_d, HIPFFT_FORWARD));
+    if (h->planFwd.exec(st, h->X_d)) return -1;
     for (int p0 = 0; p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
         hipLaunchKernelGGL(acq_mul_kernel, dim3((S + 1023) / 1024, B, pc), dim3(256), 0, st, h->X_d,
                            h->Rc_d + (size_t)p0 * h->len, S, h->len, B, h->Y_d);
         // a short last chunk still runs the full-batch plan over stale rows; they are never read
-        DPE_CHECK_FFT(hipfftExecC2C(h->planInv, (hipfftComplex *)h->Y_d, (hipfftComplex *)h->Y_d, HIPFFT_BACKWARD));
+        if (h->planInv.exec(st, h->Y_d)) return -1;
         // mode 0 arrives already folded: one term, |.|
         hipLaunchKernelGGL(acq_fold_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->Y_d, S, M,
                            h->cfg.mode == 0 ? 1 : h->N, h->cfg.mode == 0 ? 1 : 0, h->surf_d + (size_t)p0 * B * M);
@@ -603,8 +581,7 @@ static int fine_prepare(dpe_acq *h)
     std::vector<int8_t> chips((size_t)P * 1024, 0);
     for (int p = 0; p < P; ++p) gen_ca_code_host(h->cfg.prn[p], chips.data() + (size_t)p * 1024);
     DPE_CHECK_HIP(hipMemcpy(h->chips_d, chips.data(), chips.size(), hipMemcpyHostToDevice));
-    int n[1] = {(int)C};
-    DPE_CHECK_FFT(hipfftPlanMany(&h->planFine, 1, n, nullptr, 1, (int)C, nullptr, 1, (int)C, HIPFFT_C2C, P));
+    if (h->planFine.create((size_t)C, (size_t)P, false)) return -1;
     h->haveFine = true;
     return 0;
 }
@@ -628,8 +605,7 @@ int dpe_acq_fine(dpe_acq *h, const int16_t *samples_dev, const dpe_acq_result *c
     hipLaunchKernelGGL(acq_sum_kernel, dim3(32), dim3(256), 0, st, samples_dev, S, h->fineSums_d);
     hipLaunchKernelGGL(acq_fine_build_kernel, dim3((C + 1023) / 1024, P), dim3(256), 0, st, samples_dev, S, C,
                        h->cfg.samplingFrequency, h->fineChan_d, h->fineSums_d, h->chips_d, h->F_d);
-    DPE_CHECK_FFT(hipfftSetStream(h->planFine, st));
-    DPE_CHECK_FFT(hipfftExecC2C(h->planFine, (hipfftComplex *)h->F_d, (hipfftComplex *)h->F_d, HIPFFT_FORWARD));
+    if (h->planFine.exec(st, h->F_d)) return -1;
     hipLaunchKernelGGL(acq_fine_peak_kernel, dim3(P), dim3(256), 0, st, h->F_d, C, h->fineLo, h->fineHi, h->fineIdx_d, h->fineVal_d);
     DPE_CHECK_HIP(hipGetLastError());
     std::vector<int> idx(P);

@@ -1113,7 +1113,7 @@ struct dpe_bcs {
     // full-length FFT fallback (dpe_bcs_fft.h): lag windows beyond DPE_MAX_LAG_HALF_WIDTH, bin windows beyond the moment
     // expansion, or DPE_BCS_FORCE_FFT=1 at create (A/B tests)
     bool fftMode = false, havePlans = false;
-    hipfftHandle planS3 = 0, planS2 = 0, planC = 0;   // length S: batch 3 chunk K (forward) / 2 chunk K (inverse); length C: batch chunk K
+    dpe::FftPlan planS3, planS2, planC;   // rocFFT: length S, batch 3 chunk K (forward) / 2 chunk K (inverse); length C, batch chunk K
     int planK = 0;        // channels per window the plans are made for (the Update's nChan: re-planned when it changes)
     int fftChunkW = 1;
     float2 *fftWork_d = nullptr;
@@ -1324,7 +1324,7 @@ int dpe_bcs_destroy(dpe_bcs *h)
     void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
-    if (h->havePlans) { (void)hipfftDestroy(h->planS3); (void)hipfftDestroy(h->planS2); (void)hipfftDestroy(h->planC); }
+    h->planS3.destroy(); h->planS2.destroy(); h->planC.destroy();
     (void)hipFree(h->fftWork_d);
     for (hipEvent_t e : h->stagingFree)
         if (e) (void)hipEventDestroy(e);
@@ -1400,7 +1400,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         const int L = h->cfg.lagHalfWidth, B = h->cfg.binHalfWidth, maxK = h->cfg.maxChannels;
         const int sumBlocks = sum_blocks(S, nWindows);
         h->lastSumBlocks = sumBlocks;
-        h->lastKernel = "hipfft full-lag path (bcs_fft_*_kernel)";
+        h->lastKernel = "rocfft full-lag path (bcs_fft_*_kernel)";
         if (dev) {}
         else if (h->graphs.capturing) DPE_CHECK_HIP(hipMemcpyAsync(h->chan_d, h->chan_h, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyHostToDevice, stream));
         else upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
@@ -1411,35 +1411,22 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         h->prof.end(0, stream);
         const int chunk = h->fftChunkW;
         if (!h->havePlans || h->planK != nChan) {   // batched over the channels this host really tracks, not over maxChannels
-            if (h->havePlans) { (void)hipfftDestroy(h->planS3); (void)hipfftDestroy(h->planS2); (void)hipfftDestroy(h->planC); h->havePlans = false; }
-            int nS[1] = {S}, nC[1] = {(int)C};
-            const int b3 = 3 * chunk * nChan, b2 = 2 * chunk * nChan, b1 = chunk * nChan;
-            const bool ok3 = hipfftPlanMany(&h->planS3, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b3) == HIPFFT_SUCCESS;
-            const bool ok2 = ok3 && hipfftPlanMany(&h->planS2, 1, nS, nullptr, 1, S, nullptr, 1, S, HIPFFT_C2C, b2) == HIPFFT_SUCCESS;
-            const bool ok1 = ok2 && hipfftPlanMany(&h->planC, 1, nC, nullptr, 1, (int)C, nullptr, 1, (int)C, HIPFFT_C2C, b1) == HIPFFT_SUCCESS;
-            if (!ok1) {
-                if (ok3) (void)hipfftDestroy(h->planS3);
-                if (ok2) (void)hipfftDestroy(h->planS2);
-                set_error("[BatchCorrScores] Update: hipfftPlanMany failed (S = %d, C = %lld, %d rows)", S, C, b1);
-                return -1;
+            h->havePlans = false;
+            const size_t b3 = (size_t)3 * chunk * nChan, b2 = (size_t)2 * chunk * nChan, b1 = (size_t)chunk * nChan;
+            if (h->planS3.create((size_t)S, b3, false) || h->planS2.create((size_t)S, b2, true) || h->planC.create((size_t)C, b1, false)) {
+                h->planS3.destroy(); h->planS2.destroy(); h->planC.destroy();
+                return -1;   // (the message is rocFFT's, from dpe_fft.h)
             }
             h->havePlans = true;
             h->planK = nChan;
         }
         h->prof.begin(1, stream);
-        if (hipfftSetStream(h->planS3, stream) != HIPFFT_SUCCESS || hipfftSetStream(h->planS2, stream) != HIPFFT_SUCCESS ||
-            hipfftSetStream(h->planC, stream) != HIPFFT_SUCCESS) {
-            h->prof.end(1, stream);
-            set_error("[BatchCorrScores] Update: hipfftSetStream failed");
-            return -1;
-        }
         const size_t plane = (size_t)chunk * nChan * S;
         const int gxS = S / 256 < 64 ? (S / 256 > 0 ? S / 256 : 1) : 64;
-#define DPE_FFT_EXEC(plan, ptr, dir)                                                                                   \
-    if (hipfftExecC2C(plan, (hipfftComplex *)(ptr), (hipfftComplex *)(ptr), dir) != HIPFFT_SUCCESS) {                 \
-        h->prof.end(1, stream);                                                                                        \
-        set_error("[BatchCorrScores] Update: hipfftExecC2C failed");                                                   \
-        return -1;                                                                                                     \
+#define DPE_FFT_EXEC(plan, ptr)                  \
+    if ((plan).exec(stream, (void *)(ptr))) {    \
+        h->prof.end(1, stream);                  \
+        return -1;                               \
     }
         for (int w0 = 0; w0 < nWindows; w0 += chunk) {
             const int nw = nWindows - w0 < chunk ? nWindows - w0 : chunk;
@@ -1450,9 +1437,9 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
             else
                 hipLaunchKernelGGL((bcs_fft_prep_code_kernel<false>), dim3(gxS, nChan, nw), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples,
                                    S, nChan, chunk, w0, h->chan_d, h->chipTable_d, h->tTable_d, h->fftWork_d);
-            DPE_FFT_EXEC(h->planS3, h->fftWork_d, HIPFFT_FORWARD);
+            DPE_FFT_EXEC(h->planS3, h->fftWork_d);
             hipLaunchKernelGGL(bcs_fft_mul_kernel, dim3(2048), dim3(256), 0, stream, h->fftWork_d, plane);
-            DPE_FFT_EXEC(h->planS2, h->fftWork_d + plane, HIPFFT_BACKWARD);
+            DPE_FFT_EXEC(h->planS2, h->fftWork_d + plane);
             hipLaunchKernelGGL(bcs_fft_extract_code_kernel, dim3(nChan, nw), dim3(256), 0, stream, h->fftWork_d, plane, S, nChan, L, w0, maxK,
                                h->chan_d, h->codeBank_d, h->info_d);
             const int gxC = 256;
@@ -1462,7 +1449,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
             else
                 hipLaunchKernelGGL((bcs_fft_prep_carr_kernel<false>), dim3(gxC, nChan, nw), dim3(256), 0, stream, samples_dev, (long long)windowStrideSamples,
                                    S, C, nChan, w0, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->tTable_d, h->info_d, h->fftWork_d);
-            DPE_FFT_EXEC(h->planC, h->fftWork_d, HIPFFT_FORWARD);
+            DPE_FFT_EXEC(h->planC, h->fftWork_d);
             hipLaunchKernelGGL(bcs_fft_extract_carr_kernel, dim3(nChan, nw), dim3(256), 0, stream, h->fftWork_d, C, nChan, B, w0, maxK, h->carrBank_d);
         }
 #undef DPE_FFT_EXEC

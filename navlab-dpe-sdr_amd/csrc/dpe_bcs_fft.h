@@ -4,11 +4,11 @@
 // This IS the reference's formulation (cudarecv/modules/src/batchcorrscores.cu): wiped samples and both masked replicas
 // (:277-305, :323-372), forward transforms of length S, conj(F r) F b, inverse transform and 1/S (:1099-1144, :594), the
 // replica choice at lag 0 (:499-543); then (raw - mean) wipe x chosen replica zero-padded to C, one forward transform of
-// length C (:422-452, :1161-1180).  hipFFT C2C in fp32 (batched over the SVs and a chunk of windows); only the requested
+// length C (:422-452, :1161-1180).  rocFFT (called directly, dpe_fft.h) in fp32 (batched over the SVs and a chunk of windows); only the requested
 // window of lags / bins is copied into the banks, in the same layout the streaming kernels produce.
 #pragma once
 
-#include <hipfft/hipfft.h>
+#include "dpe_fft.h"
 
 namespace dpe {
 

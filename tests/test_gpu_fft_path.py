@@ -58,7 +58,7 @@ def test_lag_window_of_400_samples():
     """L = 400 > DPE_MAX_LAG_HALF_WIDTH: FFT path selected by itself; banks vs the oracle's direct sums."""
     case = helpers.make_case(seed=71, S=50000, K=4, G=64, amp=100.0, W=2)
     code, carr, info, kern = _banks(case, 400, 48)
-    assert kern.startswith("hipfft")
+    assert kern.startswith("rocfft")
     _check_vs_oracle(case, 400, 48, code, carr, info)
 
 
@@ -69,7 +69,7 @@ def test_fft_path_at_config_h_scale():
     assert case["C"] == 4194304
     t = {}
     code, carr, info, kern = _banks(case, 400, 16, max_channels=12, timing=t)
-    assert kern.startswith("hipfft")
+    assert kern.startswith("rocfft")
     print("FFT form, S = 500000, C = 4194304, 2 channels: %.3f ms per window" % t["ms"])
     _check_vs_oracle(case, 400, 16, code, carr, info)
 
@@ -78,7 +78,7 @@ def test_bin_window_beyond_the_moment_expansion():
     """S = 12500 -> C = 131072: the moment expansion takes B <= 37; B = 90 goes through the C-point transform."""
     case = helpers.make_case(seed=72, S=12500, K=3, G=64, amp=100.0)
     code, carr, info, kern = _banks(case, 8, 90)
-    assert kern.startswith("hipfft")
+    assert kern.startswith("rocfft")
     _check_vs_oracle(case, 8, 90, code, carr, info)
 
 
@@ -91,7 +91,7 @@ def test_fft_path_equals_the_streaming_kernels(kw, L, B):
     case = helpers.make_case(**kw)
     code, carr, info, kern = _banks(case, L, B, force_fft=True)
     code0, carr0, info0, kern0 = _banks(case, L, B)
-    assert kern.startswith("hipfft") and not kern0.startswith("hipfft")
+    assert kern.startswith("rocfft") and not kern0.startswith("rocfft")
     _check_vs_oracle(case, L, B, code, carr, info)
     for wi in range(case["W"]):
         for k in range(case["K"]):
