@@ -107,10 +107,18 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
             const float dr = c1.x - c0.x, di = c1.y - c0.y;
             const float eA = c0.x * c0.x + c0.y * c0.y, eB = 2.f * (c0.x * dr + c0.y * di), eC = dr * dr + di * di;
             if (COMPACT) { sF[3 * i] = eA; sF[3 * i + 1] = eB; sF[3 * i + 2] = eC; }
+#ifdef DPE_SCAN_SOA   // experiment (round 3, measured and dropped -- DESIGN.md 9): {A, B} as an 8-byte-stride array, C as a 4-byte-stride array behind it
+            else { reinterpret_cast<float2 *>(smem)[i] = make_float2(eA, eB); sF[2 * K * nEnt + i] = eC; }
+#else
             else sE[i] = make_float4(eA, eB, 0.f, eC);
+#endif
         } else {
             if (COMPACT) { sF[3 * i] = 0.f; sF[3 * i + 1] = 0.f; sF[3 * i + 2] = 0.f; }
+#ifdef DPE_SCAN_SOA
+            else { reinterpret_cast<float2 *>(smem)[i] = make_float2(0.f, 0.f); sF[2 * K * nEnt + i] = 0.f; }
+#else
             else sE[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
     }
     __syncthreads();
@@ -193,8 +201,13 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
                         const float *bf = sF + ((size_t)k * nEnt + e) * 3;
                         m2 = fmaf(wgt, fmaf(wgt, bf[2], bf[1]), bf[0]);
                     } else {
+#if defined(DPE_SCAN_SOA)
+                        const float2 ab = reinterpret_cast<const float2 *>(smem)[k * nEnt + e];
+                        m2 = fmaf(wgt, fmaf(wgt, sF[2 * K * nEnt + k * nEnt + e], ab.y), ab.x);
+#else
                         const float2 ab = *reinterpret_cast<const float2 *>(&bk[e]);
                         m2 = fmaf(wgt, fmaf(wgt, bk[e].w, ab.y), ab.x);
+#endif
                     }
                     if (LP == 1) c[j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(m2));    // raw v_sqrt_f32 (1 ulp)
                     else if (LP == 2) c[j] = m2;

@@ -419,7 +419,14 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs
     constexpr int NRR = 16 + 2 * LH;     // entries one lane touches
     static_assert((8 + 2 * LH) % 4 == 0 && LH <= 8, "a segment's replica window is read as float4s");
     __shared__ float sChips[2048];   // chips as +/-1.0f, periodically extended: sChips[i] = chip[i mod 1023]
-    __shared__ __align__(16) float sRep[4][NREP + 8];
+#ifdef DPE_B16_PAD   // experiment (round 3, measured and dropped -- DESIGN.md 9): every 16 replica entries take 20 floats -- a lane's float4 window reads then fall on 16 distinct 4-bank slots
+    constexpr int kRepLen = ((NREP + 8 + 15) / 16) * 20;
+#define DPE_PAD16(e) ((e) + 4 * ((e) >> 4))
+#else
+    constexpr int kRepLen = NREP + 8;
+#define DPE_PAD16(e) (e)
+#endif
+    __shared__ __align__(16) float sRep[4][kRepLen];
     __shared__ float2 sAcc[4][NL];
 
     // Block -> (window, tile group, SV), XCD-aware like the chip kernel's: the K blocks that read the same samples get linear
@@ -436,6 +443,8 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs
     window_mean(sums, w, nSumBlk, S, mRe, mIm);
     const f2 meanv = f2{mRe, mIm}, rotv = f2{ch.rotRe, ch.rotIm};
     const int16_t *x = iq + (size_t)w * winStride * 2;
+    const int padLane = DPE_PAD16(lane);   // (64 j + lane pads as pad(64 j) + pad(lane): 64 j is a multiple of 16)
+    (void)padLane;
     const float xbase = (float)(16 * (lane & 15)) - 127.5f;      // moment abscissa of the lane's first sample
     __syncthreads();
 
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs
                         // instead of running one after the other (the loop is latency, not issue)
                         static_assert(NREP >= 1024 && NREP < 1024 + 64, "sixteen full rounds of 64 entries and a partial one");
                         if constexpr (TABLE) {   // (the time-table form reads its sample times from memory: keep the short live range)
-                            for (int e = lane; e < NREP; e += 64) sRep[wave][e] = sChips[(int)code_phase<TABLE>(ch, tT, lo + e) + shift];
+                            for (int e = lane; e < NREP; e += 64) sRep[wave][DPE_PAD16(e)] = sChips[(int)code_phase<TABLE>(ch, tT, lo + e) + shift];
                         } else {
 #pragma unroll
                         for (int e0 = 0; e0 < 1024; e0 += 512) {
@@ -477,15 +486,15 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs
 #pragma unroll
                             for (int j = 0; j < 8; ++j) v[j] = sChips[(int)code_phase<TABLE>(ch, tT, lo + e0 + 64 * j + lane) + shift];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) sRep[wave][e0 + 64 * j + lane] = v[j];
+                            for (int j = 0; j < 8; ++j) sRep[wave][DPE_PAD16(e0 + 64 * j) + padLane] = v[j];
                         }
-                        if (1024 + lane < NREP) sRep[wave][1024 + lane] = sChips[(int)code_phase<TABLE>(ch, tT, lo + 1024 + lane) + shift];
+                        if (1024 + lane < NREP) sRep[wave][DPE_PAD16(1024) + padLane] = sChips[(int)code_phase<TABLE>(ch, tT, lo + 1024 + lane) + shift];
                         }
                     } else {
                         for (int e = lane; e < NREP; e += 64) {
                             const int m = lo + e;
                             const float r = sChips[(int)code_phase<TABLE>(ch, tT, m) + shift];
-                            sRep[wave][e] = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
+                            sRep[wave][DPE_PAD16(e)] = ((m >= ch.idxNext) == (side == 1)) ? r : 0.f;
                         }
                     }
                 } else {
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs
                         const double cph = code_phase<TABLE>(ch, tT, m);
                         const int ci = ((int)floor(cph)) % kLCA;
                         const int sd = ch.hasFlip ? (m >= ch.idxNext) : 0;
-                        sRep[wave][e] = (sd == side) ? sChips[ci] : 0.f;
+                        sRep[wave][DPE_PAD16(e)] = (sd == side) ? sChips[ci] : 0.f;
                     }
                 }
             }
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs
                     float rr[8 + 2 * LH];
 #pragma unroll
                     for (int q = 0; q < (8 + 2 * LH) / 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&sRep[wave][16 * lane + 8 * seg + 4 * q]);
+                        const float4 v = *reinterpret_cast<const float4 *>(&sRep[wave][DPE_PAD16(16 * lane + 8 * seg + 4 * q)]);
                         rr[4 * q] = v.x; rr[4 * q + 1] = v.y; rr[4 * q + 2] = v.z; rr[4 * q + 3] = v.w;
                     }
                     // Doppler wipe-off conj(exp(j 2 pi (fi t + ri))) (BCS_ComputeDopplerWipeoff :294-300): fp64 phase
@@ -632,6 +641,8 @@ __global__ __launch_bounds__(256, (LH <= 4 && !TABLE) ? kB16Blocks : 3) void bcs
 }
 
 // ------------------------------------------------------------------------------------------
+#undef DPE_PAD16
+
 // Wide lag windows (|lag| <= 32, i.e. high sampling rates where a chip spans many samples): instead of
 // 65 dense multiply-accumulates per sample, use that the replica is piecewise constant:
 //     corr[l+1] - corr[l] = sum_m J[m] b[(m + l) mod S],   J[m] = r[m-1] - r[m]
