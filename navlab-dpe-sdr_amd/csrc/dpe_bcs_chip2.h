@@ -16,7 +16,7 @@
 //     half the fp32 rounding of the boundary differences under a DC offset);
 //   * the chip boundaries ARE the lanes' first samples: positions, replica values and sign changes need no second mapping;
 //     lag sums as in the first form, corr_pass[l] = (r_first + r_last) T/2 + sum_i J_i Q[e_i + l] with lanes <-> the 64 lags.
-// A pass = 57 chips (lanes 3 .. 59); lanes 0 .. 2 and 60 .. 63 carry the chips either side of the pass whose boundaries the
+// A pass = 58 chips (lanes 3 .. 60); lanes 0 .. 2 and 61 .. 63 carry the chips either side of the pass whose boundaries the
 // +-32-lag window still reaches (two before and three after are needed where the window wraps around circularly and the
 // partial chips at its ends are short) -- they own no samples.  The circular wrap and the nav-bit boundary need no special
 // path: a lane beyond the window's last chip takes the chip the circular continuation puts there, and the two nav-bit
@@ -24,7 +24,7 @@
 // a chip boundary, which it does unless fp64 rounding separates BCS_NavBitBoundary :247-253 from the chip index :347-349).
 // A wave walks the passes of one TILE: the chips that start inside [blk Lt, (blk+1) Lt); the tile's moment block is taken
 // about the centre of that nominal range, so bcs_finalize_kernel sees the layout of the first form (momLen = Lt).
-// Per pass of ~1400 samples: ~370 VALU + ~60 LDS instructions against 448 + 78 per 1088 samples of the first form.
+// Per pass of ~1420 samples: 477 VALU + 83 LDS instructions (SQ counters) against 448 + 78 per 1088 samples of the first form.
 #pragma once
 
 namespace dpe {
@@ -36,7 +36,11 @@ namespace dpe {
 #define DPE_C2_GB 8
 #endif
 constexpr int k2Own0 = 3;      // first owner lane
-constexpr int k2Own = 57;      // owner lanes per pass
+#ifndef DPE_C2_OWN
+#define DPE_C2_OWN 58
+#endif
+constexpr int k2Own = DPE_C2_OWN;   // owner lanes per pass: lanes 3 .. 60 (measured at H: 58 owners at 11 blocks per CU 0.593 ms per 128 windows,
+                                    // 57 at 12 blocks 0.604, 50 at 13 blocks 0.635 -- lanes that own samples matter more than resident waves)
 constexpr int k2MaxL1 = 24;    // L1 = floor(fs / fc) <= 24: chips of at most 25 samples
 constexpr int k2MinL1 = 16;    // the margins reach +-32 samples: two regular chips must cover them
 constexpr int k2Pad = 64;
