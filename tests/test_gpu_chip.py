@@ -135,3 +135,34 @@ def test_chip_kernel_falls_back_when_not_eligible():
         ch = dict(w["start"])
         w["iq"] = dpe.synth.gen_iq(5, case["fs"], case["S"], ch, amp=100.0, flip=np.zeros(2, dtype=bool))
     _check(case, 31, 16)
+
+
+N_C2 = int(os.environ.get("DPE_FUZZ_CHIP2_CASES", "10"))
+
+
+@pytest.mark.parametrize("i", range(N_C2))
+def test_random_case_through_the_second_form(i):
+    """Seeded sweep aimed at bcs_bank_chip2_kernel: 20 / 25 Msps (19.5 / 24.4 samples per chip), window lengths that are
+    multiples of nothing (so the clipped first and last chips, the circular wrap inside the margins and partial last
+    passes of a tile all vary), 1 ... 12 SVs, 1 ... 3 windows, nav-bit boundary anywhere, lag windows 17 ... 31.  Banks of
+    the second form, of the first form and of the per-sample kernels against the oracle; the second form must be the one
+    that ran."""
+    rng = np.random.Generator(np.random.PCG64(424243 + i))
+    fs = float(rng.choice([20e6, 25e6]))
+    S = 2 * int(rng.integers(3000, 90001))
+    K = int(rng.choice([1, 2, 3, 5, 8, 12]))
+    W = int(rng.choice([1, 1, 2, 3]))
+    L = int(rng.integers(17, 32))
+    C = 8 * (1 << int(np.ceil(np.log2(S))))
+    b_max = int(np.floor((720 * 2e-7) ** (1.0 / 6.0) * C / (2 * np.pi * 127.5) * 0.999))
+    # (the chip kernels drop a chip's second-order term: (2 pi B / C x chip length)^2 / 24 < 5e-7, checked at create)
+    B = max(2, min(int(rng.choice([8, 12, 16, 24])), b_max, int(1.35e-4 * C / (2 * np.pi))))
+    case = helpers.make_case(seed=7000 + i, fs=fs, S=S, K=K, G=16, amp=float(rng.choice([40.0, 100.0])), W=W)
+    try:
+        _, _, _, p = _banks(case, L, B)
+        assert p["kernel"] == "bcs_bank_chip2_kernel"
+        worst = _check(case, L, B)
+    except Exception:
+        print("chip2 sweep case %d: fs %.0f S %d K %d W %d L %d B %d" % (i, fs, S, K, W, L, B))
+        raise
+    print("case %d worst rel err %.3g" % (i, worst))
