@@ -1155,6 +1155,18 @@ static void decode_key(unsigned long long key, float *score, int64_t *index)
     *index = (int64_t)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
 }
 
+// Device-parameter Updates: the window's frame (xCurrkk1, ENU2ECEFMat, DopplerSign) came from device arrays; bcm_prep_kernel
+// left a copy in pinned memory ahead of the scan, valid once the stream has been waited for (or the result polled).
+static int fetch_device_frame(dpe_bcm *h)
+{
+    if (!h->lastDev) return 0;
+    DPE_REQUIRE(!h->devWin_h->bad, "[BatchCorrManifold] results: DopplerSign on the device is not +/-1");
+    memcpy(h->win_h[0].xCurrkk1, h->devWin_h->xCurrkk1, sizeof(double) * 8);
+    memcpy(h->win_h[0].enu2ecef, h->devWin_h->enu2ecef, sizeof(double) * 9);
+    h->win_h[0].dopplerSign = h->devWin_h->dopplerSign;
+    return 0;
+}
+
 int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
 {
     DPE_REQUIRE(h && results && h->lastW > 0, "[BatchCorrManifold] results: no update yet");
@@ -1169,12 +1181,7 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
     }
     if (!arrived) DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int W = h->lastW;
-    if (h->lastDev) {   // the window's frame came from device arrays: bcm_prep_kernel left it in pinned memory ahead of the scan
-        DPE_REQUIRE(!h->devWin_h->bad, "[BatchCorrManifold] results: DopplerSign on the device is not +/-1");
-        memcpy(h->win_h[0].xCurrkk1, h->devWin_h->xCurrkk1, sizeof(double) * 8);
-        memcpy(h->win_h[0].enu2ecef, h->devWin_h->enu2ecef, sizeof(double) * 9);
-        h->win_h[0].dopplerSign = h->devWin_h->dopplerSign;
-    }
+    if (fetch_device_frame(h)) return -1;
     const unsigned long long *keys = h->keys_h, *oob = h->oob_h;
     std::vector<double> ws;   // per-block weighted sums: fetched only when the estimator is on (this call sits on the
                               // closed loop's critical path: no 300 KB of scratch per window otherwise)
@@ -1288,6 +1295,7 @@ int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWi
 {
     DPE_REQUIRE(h && keys_host && posGridGlobal && velGridGlobal && results, "[BatchCorrManifold] results_from_keys: null argument");
     DPE_REQUIRE(nWindows >= 1 && nWindows <= h->lastW, "[BatchCorrManifold] results_from_keys: bad nWindows");
+    if (fetch_device_frame(h)) return -1;   // (the reduced keys came through a synchronising copy: the scan has finished)
     for (int w = 0; w < nWindows; ++w) {
         dpe_bcm_result &r = results[w];
         DPE_REQUIRE(keys_host[2 * w] != 0 && keys_host[2 * w + 1] != 0,
