@@ -585,7 +585,10 @@ def main():
     if args.config is None and not args.no_extras:
         extra_steps = min(args.steps, 20)
         if ctx.world == 1 and not ctx.use_dist:
-            emit(acq_line())                      # BASELINE.json configs[4]
+            try:
+                emit(acq_line())                  # BASELINE.json configs[4]
+            except Exception as e:                # (an extra line must never cost the headline)
+                sys.stderr.write("bench.py: acquisition line failed: %r\n" % (e,))
             out, _ = run_workload("H", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
             emit(out)
         out, cached = run_workload("M", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
