@@ -9,8 +9,9 @@
 // pass (chips for the boundary positions, chips again for the Doppler moments -- which re-read every prefix value from
 // LDS for the first moment of each chip -- and lags for the gather).  Here a lane owns one CHIP of the replica:
 //   * its L1 or L1 + 1 samples (L1 = floor(fs / fc), 16 .. 24) are accumulated in the lane's own rotating frame,
-//     u_i = u_(i-1) + raw_i T_i  (T_i = exp(-j 2 pi i fi / fs): two packed FMAs per sample), together with the running sum of
-//     the u_i: zeroth AND first moment of the chip come out of registers (Abel summation) -- no second pass over LDS;
+//     u_i = u_(i-1) + raw_i T_(i-CI)  (T_j = exp(-j 2 pi j fi / fs) about the chip's middle sample CI: block constants in
+//     scalar registers, two packed FMAs per sample), together with the running sum of the u_i: zeroth AND first moment of
+//     the chip come out of registers (Abel summation) -- no second pass over LDS;
 //   * one 64-lane scan of the chip totals gives every chip its offset; Q = w_chip u_i + offset goes to LDS (two packed FMAs
 //     and one ds_write_b64 per sample) as the pass-local prefix array, centred (Q runs from -T/2 to +T/2: half the magnitude,
 //     half the fp32 rounding of the boundary differences under a DC offset);
@@ -45,6 +46,23 @@ constexpr int k2MaxL1 = 24;    // L1 = floor(fs / fc) <= 24: chips of at most 25
 constexpr int k2MinL1 = 16;    // the margins reach +-32 samples: two regular chips must cover them
 constexpr int k2Pad = 64;
 constexpr int k2QLen = k2Pad + k2Own * (k2MaxL1 + 1) + 1 + 64;
+
+// a * t + c and a * conj(t) + c with t a block constant in scalar registers (the lane-frame twiddles): two packed FMAs each
+#define DPE_C2_TWC "s"
+__device__ __forceinline__ f2 tw_mul_add(f2 a, f2 t, f2 c)
+{
+    f2 x, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(x) : "v"(a), DPE_C2_TWC(t), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), DPE_C2_TWC(t), "v"(x));
+    return r;
+}
+__device__ __forceinline__ f2 tw_conj_mul_add(f2 a, f2 t, f2 c)
+{
+    f2 x, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(x) : "v"(a), DPE_C2_TWC(t), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), DPE_C2_TWC(t), "v"(x));
+    return r;
+}
 
 template <int kNMom, int L1>
 __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
@@ -90,9 +108,14 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     const int cHi = blk == nBlk - 1 ? cEnd + 1 : __builtin_amdgcn_readfirstlane(chip_at((blk + 1) * Lt - 1)) + 1;
     const int nPassT = (cHi - cLo + k2Own - 1) / k2Own;
 
-    // ---- once per block: the SV's twiddles T_i (i < 26), the two centre twiddles of regular chips
+    // ---- once per block: the SV's twiddles.  The lane frame has its origin at sample CI of the chip, so the samples either
+    // side of it share T_j = exp(-j 2 pi j fi / fs), j = 1 .. CI (conjugated before the origin, none at it); they stay in
+    // scalar registers for the whole tile (as LDS reads inside the pass they were twelve exposed round trips: 0.594 -> 0.565 ms
+    // per 128 windows at H; in vector registers 0.567 at 160 instead of 136 VGPRs).  thA / thB: origin -> centre of a chip of
+    // L1 / L1 + 1 samples.
+    constexpr int CI = (L1 + 1) / 2;
     if (lane < 28) {
-        const double a = lane < 26 ? (double)lane : (lane == 26 ? 0.5 * (double)(L1 - 1) : 0.5 * (double)L1);
+        const double a = lane < 26 ? (double)lane : (lane == 26 ? 0.5 * (double)(L1 - 1) - (double)CI : 0.5 * (double)L1 - (double)CI);
         double ph = a * ch.carrStep;
         ph -= floor(ph);
         const f2 t = wipe_seed((float)ph);
@@ -102,6 +125,11 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     const size_t momSide = (size_t)nBlk * kNMom;
     __builtin_amdgcn_wave_barrier();
     const f2 thA = f2{sRot[26].x, sRot[26].y}, thB = f2{sRot[27].x, sRot[27].y};
+    f2 tw[CI + 1];
+#pragma unroll
+    for (int j = 0; j <= CI; ++j) {
+        tw[j] = f2{readlane_f(sRot[j].x, 0), readlane_f(sRot[j].y, 0)};
+    }
 
     const int qLaneBytes = 8 * ((k2Pad - 32) + lane);   // byte offset in sQ of lag (lane - 32)'s entry for a boundary at the pass start
     const float phi = (float)(6.283185307179586476925286766559 * ch.carrStep);   // wipe-off phase step per sample (rad)
@@ -200,42 +228,31 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
         // ---- 1. the chip's samples in the lane's rotating frame: u_i, and vv = sum of all u_i (first moment, by Abel summation)
         f2 u[L1], uX, run = f2{0.f, 0.f}, vv = f2{0.f, 0.f};
         {
-            const float2 tX = sRot[L1];
-            // (twiddles: two per 16-byte broadcast read (wave-uniform address), fetched four slots at a time -- all twelve reads
-            // up front would hold 48 registers beside the 50 of u[])
+            auto slot = [&](int rv, int i) {   // i is a literal after unrolling
+                const f2 si = f2{(float)(short)(rv & 0xFFFF), (float)(rv >> 16)};
+                if (i < CI) run = tw_conj_mul_add(si, tw[CI - i], run);
+                else if (i == CI) run += si;
+                else run = tw_mul_add(si, tw[i - CI], run);
+            };
             auto slots = [&](auto edgeTag) {
                 constexpr bool kEdge = decltype(edgeTag)::value;
 #pragma unroll
-                for (int g = 0; g < (L1 + 3) / 4; ++g) {
-                    const float4 ta = reinterpret_cast<const float4 *>(sRot)[2 * g], tb = reinterpret_cast<const float4 *>(sRot)[2 * g + 1];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 4 * g + j;
-                        if (i < L1) {
-                            const float4 t4 = j < 2 ? ta : tb;
-                            const f2 tt = (j & 1) ? f2{t4.z, t4.w} : f2{t4.x, t4.y};
-                            const int rv = (!kEdge || i < len) ? raw[i] : 0;
-                            const f2 si = f2{(float)(short)(rv & 0xFFFF), (float)(rv >> 16)};
-                            run = cmul_add(si, tt, run);
-                            u[i] = run;
-                            vv += run;
-                        }
-                    }
-                    // keeps the next group's twiddle reads and sample conversions behind this group's arithmetic: hoisted
-                    // to the top they would hold ~100 registers beside the 50 of u[]
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < L1; ++i) {
+                    slot((!kEdge || i < len) ? raw[i] : 0, i);
+                    u[i] = run;
+                    vv += run;
+                    // (keeps the later slots' sample conversions behind this group's arithmetic: hoisted they hold registers)
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             };
             if (!edge) slots(std::false_type{});
             else slots(std::true_type{});
-            const int rv = len > L1 ? rawX : 0;
-            const f2 si = f2{(float)(short)(rv & 0xFFFF), (float)(rv >> 16)};
-            run = cmul_add(si, f2{tX.x, tX.y}, run);
+            slot(len > L1 ? rawX : 0, L1);
             uX = run;
             vv += run;
         }
-        // ---- 2. chip offsets: wipe-off at the chip's first sample, 64-lane scan of the chip totals, Q -> LDS (centred)
-        double ph = fma((double)(own ? e : 0), ch.carrStep, ch.ri);
+        // ---- 2. chip offsets: wipe-off at the chip's frame origin, 64-lane scan of the chip totals, Q -> LDS (centred)
+        double ph = fma((double)((own ? e : 0) + CI), ch.carrStep, ch.ri);   // wipe-off at the lane frame's origin
         ph -= floor(ph);
         const f2 wl = wipe_seed((float)ph);
         f2 tot = cmul(wl, run);
@@ -335,6 +352,10 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
                 __builtin_amdgcn_wave_barrier();
             }
             f2 acc = f2{0.f, 0.f};
+            // (Measured in round 3 and dropped: an offsets-only list for passes with one side -- flips are +-2 and alternate --
+            // with two batches of reads in flight, offsets of batch b + 2 and prefix values of b + 1 issued before the adds of
+            // b: 0.578 against 0.565 ms per 128 windows at H, 0.571 with the compiler's own order.  The LDS array is 60 % busy;
+            // what a wave waits for is its queue, not one round trip.)
             constexpr int GB = DPE_C2_GB;   // list entries per batch of independent LDS reads
             for (int i0 = 0; i0 < nb; i0 += GB) {
                 float2 ent[GB], qv[GB];
