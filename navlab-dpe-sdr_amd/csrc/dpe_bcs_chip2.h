@@ -25,7 +25,7 @@
 // a chip boundary, which it does unless fp64 rounding separates BCS_NavBitBoundary :247-253 from the chip index :347-349).
 // A wave walks the passes of one TILE: the chips that start inside [blk Lt, (blk+1) Lt); the tile's moment block is taken
 // about the centre of that nominal range, so bcs_finalize_kernel sees the layout of the first form (momLen = Lt).
-// Per pass of ~1420 samples: 477 VALU + 83 LDS instructions (SQ counters) against 448 + 78 per 1088 samples of the first form.
+// Per pass of ~1420 samples: 478 VALU + 71 LDS instructions (SQ counters) against 448 + 78 per 1088 samples of the first form.
 #pragma once
 
 namespace dpe {
@@ -74,8 +74,7 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
 {
     constexpr int NL = 65;   // partial layout shared with the other stage-1 kernels: entry j <-> lag j - 32 (j = 64 unused)
     __shared__ float2 sQ[k2QLen];
-    __shared__ __align__(16) float2 sRot[32];
-    __shared__ float2 sList[64 + 8];   // flips of a pass: {J, byte offset into sQ}
+    __shared__ float2 sList[64 + DPE_C2_GB];   // flips of a pass: {J, byte offset into sQ}, then one batch of zeros
 
     // Block -> (window, tile, SV), XCD-aware as in the first form: the K blocks of a tile are congruent mod 8
     const int lane = threadIdx.x;
@@ -114,22 +113,19 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     // per 128 windows at H; in vector registers 0.567 at 160 instead of 136 VGPRs).  thA / thB: origin -> centre of a chip of
     // L1 / L1 + 1 samples.
     constexpr int CI = (L1 + 1) / 2;
-    if (lane < 28) {
+    f2 tw[CI + 1], thA, thB;
+    {
         const double a = lane < 26 ? (double)lane : (lane == 26 ? 0.5 * (double)(L1 - 1) - (double)CI : 0.5 * (double)L1 - (double)CI);
         double ph = a * ch.carrStep;
         ph -= floor(ph);
-        const f2 t = wipe_seed((float)ph);
-        sRot[lane] = make_float2(t.x, t.y);
+        const f2 t = wipe_seed((float)ph);   // lane j: T_j; lanes 26, 27: the two centre twiddles
+#pragma unroll
+        for (int j = 0; j <= CI; ++j) tw[j] = f2{readlane_f(t.x, j), readlane_f(t.y, j)};
+        thA = f2{readlane_f(t.x, 26), readlane_f(t.y, 26)};
+        thB = f2{readlane_f(t.x, 27), readlane_f(t.y, 27)};
     }
     float2 *momOut = mom + ((((size_t)w * K + k) * 2) * nBlk + blk) * kNMom;   // [side][nBlk][kNMom]
     const size_t momSide = (size_t)nBlk * kNMom;
-    __builtin_amdgcn_wave_barrier();
-    const f2 thA = f2{sRot[26].x, sRot[26].y}, thB = f2{sRot[27].x, sRot[27].y};
-    f2 tw[CI + 1];
-#pragma unroll
-    for (int j = 0; j <= CI; ++j) {
-        tw[j] = f2{readlane_f(sRot[j].x, 0), readlane_f(sRot[j].y, 0)};
-    }
 
     const int qLaneBytes = 8 * ((k2Pad - 32) + lane);   // byte offset in sQ of lag (lane - 32)'s entry for a boundary at the pass start
     const float phi = (float)(6.283185307179586476925286766559 * ch.carrStep);   // wipe-off phase step per sample (rad)
@@ -348,7 +344,7 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
             {
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
                 if ((bm >> lane) & 1ull) sList[rank] = make_float2(J, __builtin_bit_cast(float, 8 * (e - eA)));
-                if (lane < 8) sList[nb + lane] = make_float2(0.f, 0.f);
+                if (lane < DPE_C2_GB) sList[nb + lane] = make_float2(0.f, 0.f);
                 __builtin_amdgcn_wave_barrier();
             }
             f2 acc = f2{0.f, 0.f};
@@ -356,14 +352,18 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
             // with two batches of reads in flight, offsets of batch b + 2 and prefix values of b + 1 issued before the adds of
             // b: 0.578 against 0.565 ms per 128 windows at H, 0.571 with the compiler's own order.  The LDS array is 60 % busy;
             // what a wave waits for is its queue, not one round trip.)
-            constexpr int GB = DPE_C2_GB;   // list entries per batch of independent LDS reads
+            constexpr int GB = DPE_C2_GB;   // list entries per batch of independent LDS reads (8 / 12 / 16: 0.566 / 0.563 / 0.562 ms)
             for (int i0 = 0; i0 < nb; i0 += GB) {
                 float2 ent[GB], qv[GB];
 #pragma unroll
                 for (int j = 0; j < GB; ++j) ent[j] = sList[i0 + j];
+                // (the barriers keep the batch's reads together: interleaved with the FMAs, one read in flight at a time, the
+                // kernel measured 0.678 instead of 0.567 ms per 128 windows at H -- the compiler chose that order once)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < GB; ++j)
                     qv[j] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(sQ) + (qLaneBytes + __builtin_bit_cast(int, ent[j].y)));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < GB; ++j) {
                     const f2 ej = f2{ent[j].x, ent[j].y}, qj = f2{qv[j].x, qv[j].y};
