@@ -113,8 +113,9 @@ int dpe_bcs_update(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideS
 /* The same for ONE window with the channel parameters where the reference keeps them: in DEVICE arrays written by cuChanMgr
  * (dpeflow.cpp:169-176; BatchCorrScores captures the pointers once, batchcorrscores.cu:991-1004).  A one-block kernel derives
  * the per-channel constants on the device in fp64 (same expressions as the host form), so a host that keeps the reference's
- * cuChanMgr needs no device-to-host copy per window.  Uses the per-sample stage-1 kernels (the chip-boundary forms are
- * selected from the channel values, which the host does not see here). */
+ * cuChanMgr needs no device-to-host copy per window.  One exception: at sampling rates of >= 16 samples per chip the
+ * chip-boundary stage-1 kernels are selected from the channel values, and this call then reads back the <= 3 KB block its
+ * prep kernel derived (one stream wait per window) rather than fall back to the 4-5 x slower per-sample kernels. */
 typedef struct dpe_bcs_ports_dev {
     const double *codePhaseStart;      /* [K] chips   (input 2) */
     const double *carrierPhaseStart;   /* [K] cycles  (input 3) */

@@ -1345,7 +1345,8 @@ int dpe_bcs_destroy(dpe_bcs *h)
 }
 
 // chan_host == nullptr: the channel parameters of this (single-window) call are already in h->chan_d, written by
-// bcs_prep_kernel earlier on `stream` (dpe_bcs_update_dev) -- nothing the host decides below may then depend on their values.
+// bcs_prep_kernel earlier on `stream` (dpe_bcs_update_dev) -- nothing the host decides below may then depend on their values,
+// except the choice of a chip-boundary kernel at high sampling rates (which fetches them first, see there).
 static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windowStrideSamples, int32_t nWindows,
                            int32_t nChan, const dpe_chan_start *chan_host, dpe_stream_t stream_)
 {
@@ -1386,10 +1387,18 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         d.pad = 0;
         h->idxNext_h[i] = d.idxNext;
     }
-    // chip-boundary kernel: the closed-form DC term of a chip needs 2 pi |fi| / fc <= 0.25 (|fi| below ~40 kHz)
-    bool chip = h->chipOK && h->chipAllowed && !dev;   // (its eligibility is a property of the channel values: host form only)
+    // chip-boundary kernel: the closed-form DC term of a chip needs 2 pi |fi| / fc <= 0.25 (|fi| below ~40 kHz).  Its
+    // eligibility (and the second form's below) is a property of the channel VALUES.  The device-parameter form has them
+    // only on the device: at sampling rates where these kernels exist at all (>= 16 samples per chip) it reads back the
+    // block bcs_prep_kernel has just derived -- <= 3 KB and one stream wait per window, against a 4-5 x slower stage 1;
+    // at lower rates nothing is fetched and nothing the host decides depends on the values.
+    bool chip = h->chipOK && h->chipAllowed;
+    if (chip && dev) {
+        DPE_CHECK_HIP(hipMemcpyAsync(h->chan_h, h->chan_d, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyDeviceToHost, stream));
+        DPE_CHECK_HIP(hipStreamSynchronize(stream));
+    }
     for (int i = 0; chip && i < nWindows * nChan; ++i)
-        if (6.283185307179586 * std::fabs(chan_host[i].carrierFrequency) > 0.25 * chan_host[i].codeFrequency) chip = false;
+        if (6.283185307179586 * std::fabs(h->chan_h[i].fi) > 0.25 * h->chan_h[i].fc) chip = false;
     // second form of the chip kernel (dpe_bcs_chip2.h): every chip 16 .. 25 samples long, and the nav-bit boundary
     // (BCS_NavBitBoundary :247-253) on a chip boundary of the replica (:347-349) -- it is, unless fp64 rounding separates them
     bool chip2 = chip && h->chip2Allowed;

@@ -166,3 +166,45 @@ def test_random_case_through_the_second_form(i):
         print("chip2 sweep case %d: fs %.0f S %d K %d W %d L %d B %d" % (i, fs, S, K, W, L, B))
         raise
     print("case %d worst rel err %.3g" % (i, worst))
+
+
+def test_device_ports_at_a_high_sampling_rate_take_the_chip_kernel():
+    """dpe_bcs_update_dev at 25 Msps: the chip-boundary kernels are chosen by the channel values, which this form has on the
+    device only -- it reads back the block its prep kernel derived (one small copy per window) instead of falling back
+    to the per-sample kernels.  Same kernel and banks as the host form, both within the oracle's tolerance."""
+    import torch
+    from oracle import oracle as o
+    L, B = 31, 16
+    case = helpers.make_case(seed=23, fs=25e6, S=125000, K=4, G=64, amp=80.0)
+    K, S, fs = case["K"], case["S"], case["fs"]
+    iq, cs, _, _ = helpers.pack_gpu_inputs(case)
+    d = torch.from_numpy(iq).to("cuda:0")
+    s = case["wins"][0]["start"]
+
+    def dv(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dt)).to("cuda:0")
+    ports = dict(codePhaseStart=dv(s["rc"], np.float64), carrierPhaseStart=dv(s["ri"], np.float64), codeFrequency=dv(s["fc"], np.float64),
+                 carrierFrequency=dv(s["fi"], np.float64), cpElapsedStart=dv(s["cp"], np.int32), cpReference=dv(s["cp_ref"], np.int32),
+                 validPRNs=dv(s["prn"], np.uint8))
+    out = {}
+    for form in ("host", "dev"):
+        bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=1, max_channels=K)
+        bcs.Start()
+        if form == "host":
+            bcs.Update(d, cs)
+        else:
+            bcs.UpdateDev(d, K, ports)
+            assert bcs.dev_status() == 0
+        out[form] = (bcs.read_banks(), bcs.read_info(), bcs.stage1_kernel)
+        bcs.Stop()
+    assert out["host"][2] == out["dev"][2] == "bcs_bank_chip2_kernel"
+    (code0, carr0), info0, _ = out["host"]
+    (code1, carr1), info1, _ = out["dev"]
+    assert np.array_equal(info1[0], info0[0]) and np.array_equal(info1[1], info0[1]) and np.array_equal(info1[2], info0[2])
+    for k in range(K):
+        c, f, _ = o.bcs_sv(case["wins"][0]["iq"], fs, int(s["prn"][k]), s["rc"][k], s["ri"][k], s["fc"][k], s["fi"][k],
+                           int(s["cp"][k]), int(s["cp_ref"][k]), -L, L, -B, B, case["C"])
+        for got, ref in ((code1[0][k], c), (carr1[0][k], f)):
+            assert np.abs(got - ref).max() < TOL * np.abs(ref).max()
+        assert np.abs(code1[0][k] - code0[0][k]).max() < 2e-7 * np.abs(code0[0][k]).max()
+        assert np.abs(carr1[0][k] - carr0[0][k]).max() < 2e-7 * np.abs(carr0[0][k]).max()
