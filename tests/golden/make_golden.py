@@ -188,6 +188,39 @@ def make_o11(pg):
                         handoff_prns=ho["prn_list"], handoff_eph=ho["eph"], handoff_rxTime=ho["rxTime"])
 
 
+# ---- O3 / O12: vector_correlate_unfolded on seeded synthetic windows
+def run_o3(pg, tag, fs, T, seed, ch, amp, flip, prefix="o3"):
+    S = int(round(T * fs))
+    iq = dpe.synth.gen_iq(seed, fs, S, ch, amp=amp, flip=flip)
+    path = os.path.join(SCRATCH, "%s_%s.dat" % (prefix, tag))
+    iq.tofile(path)
+    rf = open_rawfile(pg, path, fs, T)
+    rf.update_rawsnippet()
+    Cf = int(rf.carr_fftpts)
+    code, carr, cpc, win, idxn = [], [], [], [], []
+    for k in range(len(ch["prn"])):
+        cor = pg.correlator.Correlator(int(ch["prn"][k]))
+        cc, cf, cp_compl = cor.vector_correlate_unfolded(
+            rf, ch["rc"][k], ch["ri"][k], ch["fc"][k], ch["fi"][k], float(ch["cp"][k]), float(ch["cp_ref"][k]))
+        code.append(np.asarray(cc)[S // 2 - 64: S // 2 + 65])
+        carr.append(np.asarray(cf)[Cf // 2 - 256: Cf // 2 + 257])
+        cpc.append(float(cp_compl))
+    np.savez_compressed(os.path.join(HERE, "%s_%s.npz" % (prefix, tag)), iq=iq, fs=fs, T=T, S=S, N=rf.N, C=Cf,
+                        first16=np.asarray(rf.rawsnippet)[:16], prn=ch["prn"], rc=ch["rc"], ri=ch["ri"],
+                        fc=ch["fc"], fi=ch["fi"], cp=ch["cp"], cp_ref=ch["cp_ref"],
+                        code=np.stack(code), carr=np.stack(carr), cp_compl=np.array(cpc), flip=np.asarray(flip))
+    rf.close_rawfile()
+
+
+def make_o12(pg):
+    """O12: the same reference function at config H's sampling rate (25 Msps, 4 ms window): chips of 24 / 25 samples, one
+    channel with a nav-bit sign change inside the window, one with the boundary inside but no change, one without a
+    boundary -- the inputs of the chip-boundary stage-1 kernels."""
+    ch = dpe.synth.random_channels(31, 3, prns=[7, 19, 30])
+    ch["cp_ref"] = ch["cp"] - np.array([19, 19, 5], dtype=np.int32)   # edges 1 ms - code phase into the window (twice), none
+    run_o3(pg, "highrate_4ms", 25e6, 0.004, 32, ch, 60.0, np.array([1, 0, 0], dtype=bool), prefix="o12")
+
+
 def time_dp(pg, iters=3):
     """SURVEY 8d, CPU baseline (2): the PyGNSS DP path timed in the dev container -- per 20 ms window,
     dp_time_update_channels_unfolded (vector_correlate_unfolded x K, the BatchCorrScores twin) and
@@ -254,6 +287,9 @@ def main():
     if "--only-o10" in sys.argv:
         make_o10(pg)
         return
+    if "--only-o12" in sys.argv:
+        make_o12(pg)
+        return
     ho = dpe.handoff.read_handoff(os.path.join(REF, "demofiles", "handoff_params_usrp6.csv"))
     prns = [int(p) for p in ho["prn_list"]]
     K = len(prns)
@@ -262,36 +298,14 @@ def main():
     chips = np.stack([pg.correlator.Correlator(p).chips.astype(np.int8) for p in range(1, 38)])
     np.savez_compressed(os.path.join(HERE, "o1_ca_chips.npz"), chips=chips)
 
-    # ---- O3: vector_correlate_unfolded on seeded synthetic windows
-    def run_o3(tag, fs, T, seed, ch, amp, flip):
-        S = int(round(T * fs))
-        iq = dpe.synth.gen_iq(seed, fs, S, ch, amp=amp, flip=flip)
-        path = os.path.join(SCRATCH, "o3_%s.dat" % tag)
-        iq.tofile(path)
-        rf = open_rawfile(pg, path, fs, T)
-        rf.update_rawsnippet()
-        Cf = int(rf.carr_fftpts)
-        code, carr, cpc, win, idxn = [], [], [], [], []
-        for k in range(len(ch["prn"])):
-            cor = pg.correlator.Correlator(int(ch["prn"][k]))
-            cc, cf, cp_compl = cor.vector_correlate_unfolded(
-                rf, ch["rc"][k], ch["ri"][k], ch["fc"][k], ch["fi"][k], float(ch["cp"][k]), float(ch["cp_ref"][k]))
-            code.append(np.asarray(cc)[S // 2 - 64: S // 2 + 65])
-            carr.append(np.asarray(cf)[Cf // 2 - 256: Cf // 2 + 257])
-            cpc.append(float(cp_compl))
-        np.savez_compressed(os.path.join(HERE, "o3_%s.npz" % tag), iq=iq, fs=fs, T=T, S=S, N=rf.N, C=Cf,
-                            first16=np.asarray(rf.rawsnippet)[:16], prn=ch["prn"], rc=ch["rc"], ri=ch["ri"],
-                            fc=ch["fc"], fi=ch["fi"], cp=ch["cp"], cp_ref=ch["cp_ref"],
-                            code=np.stack(code), carr=np.stack(carr), cp_compl=np.array(cpc), flip=np.asarray(flip))
-        rf.close_rawfile()
-
+    # ---- O3: vector_correlate_unfolded on seeded synthetic windows (run_o3)
     ch_ho = dict(prn=ho["prn_list"], rc=ho["rc"], ri=ho["ri"], fc=ho["fc"], fi=ho["fi"], cp=ho["cp"],
                  cp_ref=ho["cp_timestamp"])
     flips = np.array([1, 0, 1, 1, 0, 0, 1, 0], dtype=bool)
-    run_o3("handoff_20ms", 2.5e6, 0.02, 11, ch_ho, 200.0, flips)          # nav-bit edge inside window
+    run_o3(pg, "handoff_20ms", 2.5e6, 0.02, 11, ch_ho, 200.0, flips)          # nav-bit edge inside window
     ch_b = dpe.synth.random_channels(5, 4)
     ch_b["cp_ref"] = ch_b["cp"] - np.array([0, 1, 2, 7], dtype=np.int32)  # next edge >= 13 ms away
-    run_o3("short_5ms", 2.5e6, 0.005, 12, ch_b, 48.0, np.zeros(4, dtype=bool))  # no edge inside window
+    run_o3(pg, "short_5ms", 2.5e6, 0.005, 12, ch_b, 48.0, np.zeros(4, dtype=bool))  # no edge inside window
 
     # ---- O4: satellite clock correction + position/velocity at the handoff transmit times
     tx = ho["TOW"] + (ho["cp"] - ho["cp_timestamp"]) * 1e-3 + ho["rc"] / 1.023e6
@@ -402,6 +416,7 @@ def main():
     make_o9(pg)
     make_o10(pg)
     make_o11(pg)
+    make_o12(pg)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(HERE, f))))

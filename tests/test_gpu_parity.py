@@ -29,16 +29,22 @@ def _bcs_on_fixture(g, L, B):
     code, carr = bcs.read_banks()
     info = bcs.read_info()
     nfft = bcs.NumFFTPoints
+    _bcs_on_fixture.kernel = bcs.stage1_kernel
     bcs.Stop()
     return code[0], carr[0], info, nfft
 
 
-@pytest.mark.parametrize("name,L,B", [("o3_handoff_20ms", 8, 48), ("o3_handoff_20ms", 32, 140), ("o3_short_5ms", 4, 30)])
+@pytest.mark.parametrize("name,L,B", [("o3_handoff_20ms", 8, 48), ("o3_handoff_20ms", 32, 140), ("o3_short_5ms", 4, 30),
+                                      ("o12_highrate_4ms", 31, 16), ("o12_highrate_4ms", 64, 16), ("o12_highrate_4ms", 64, 40)])
 def test_bcs_vs_reference_fixture(golden, name, L, B):
-    """BatchCorrScores banks == pygnss vector_correlate_unfolded windows (fixture O3)."""
+    """BatchCorrScores banks == pygnss vector_correlate_unfolded windows (fixtures O3; O12 = the same reference function at
+    25 Msps: the +-31-lag case runs in bcs_bank_chip2_kernel, +-64 lags with its side chunks from the first chip form, and
+    with +-40 bins -- beyond the chip kernels' second-order bound -- in chunks of the boundary-difference kernel)."""
     g = golden(name)
     code, carr, info, nfft = _bcs_on_fixture(g, L, B)
     assert nfft == int(g["C"])
+    if name == "o12_highrate_4ms":
+        assert _bcs_on_fixture.kernel == ("bcs_bank_chip2_kernel" if B == 16 else "bcs_bank_wide_kernel")
     for k in range(len(g["prn"])):
         rc = g["code"][k][64 - L:64 + L + 1]
         rf = g["carr"][k][256 - B:256 + B + 1]

@@ -14,9 +14,9 @@ def test_o1_ca_chips(golden, oracle):
         assert np.array_equal(dpe.synth.ca_code(prn), g[prn - 1]), prn  # G2-delay form (product generator)
 
 
-@pytest.mark.parametrize("name", ["o3_handoff_20ms", "o3_short_5ms"])
+@pytest.mark.parametrize("name", ["o3_handoff_20ms", "o3_short_5ms", "o12_highrate_4ms"])
 def test_o3_bcs_fft_restatement(golden, oracle, name):
-    """numpy FFT restatement == pygnss vector_correlate_unfolded to fp64 rounding."""
+    """numpy FFT restatement == pygnss vector_correlate_unfolded to fp64 rounding (O12: the same at 25 Msps)."""
     g = golden(name)
     iq, fs, S, C = g["iq"], float(g["fs"]), int(g["S"]), int(g["C"])
     assert oracle.carr_fft_len(S) == C
@@ -42,16 +42,18 @@ def test_o3_bcs_fft_restatement(golden, oracle, name):
         assert abs(int(np.abs(carr).argmax()) - C // 2) <= 1
     if name == "o3_handoff_20ms":
         assert n_flip_chosen == 3      # PRN 6's edge is 7 samples before the window end
+    elif name == "o12_highrate_4ms":
+        assert n_flip_chosen == 1      # one of the two boundaries inside the window carries a sign change
     else:
         assert n_flip_chosen == 0
 
 
-@pytest.mark.parametrize("name", ["o3_handoff_20ms", "o3_short_5ms"])
+@pytest.mark.parametrize("name", ["o3_handoff_20ms", "o3_short_5ms", "o12_highrate_4ms"])
 def test_o3_bcs_c_oracle(golden, oracle, name):
     """C direct-sum oracle == fixtures (same maths as the FFT path, no 1/S, fftshift centre S/2)."""
     g = golden(name)
     iq, fs, C = g["iq"], float(g["fs"]), int(g["C"])
-    ks = range(len(g["prn"])) if name == "o3_short_5ms" else [0, 3]   # keep the CPU suite fast
+    ks = range(len(g["prn"])) if name == "o3_short_5ms" else ([0, 3] if name == "o3_handoff_20ms" else [0, 2])   # keep the CPU suite fast
     for k in ks:
         code, carr, info = oracle.bcs_sv(iq, fs, int(g["prn"][k]), g["rc"][k], g["ri"][k], g["fc"][k], g["fi"][k],
                                          int(g["cp"][k]), int(g["cp_ref"][k]), -64, 64, -40, 40, C)
