@@ -1,4 +1,4 @@
-"""Experiment: config R, 256 windows per step as ONE chain (bench.py's form) against TWO half-batches on two streams
+"""Experiment (usage: overlap_streams.py [R|H]): config R, 256 windows per step as ONE chain (bench.py's form) against TWO half-batches on two streams
 (each its own handle pair), so that stage 1 of one half runs beside the scan of the other."""
 import sys, time, os
 import numpy as np
@@ -6,11 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import navlab_dpe_sdr_amd as dpe
 
-cfg = dict(dpe.workload.CONFIG_R)
+name = sys.argv[1] if len(sys.argv) > 1 else "R"
+cfg = dict({"R": dpe.workload.CONFIG_R, "H": dpe.workload.CONFIG_H}[name])
 fs, S, K, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["L"], cfg["B"]
-W = 256
+W = 256 if name == "R" else 128
 dev = torch.device("cuda:0")
-iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=0, amp=cfg["amp"])
+distinct = W if name == "R" else 8          # (H: 8 distinct windows repeated, as in bench.py)
+iq, cs, ce, bw = dpe.workload.build_windows(distinct, fs, S, K, seed=0, amp=cfg["amp"])
+if distinct < W:
+    iq, cs, ce, bw = (np.concatenate([a] * (W // distinct)) for a in (iq, cs, ce, bw))
 pos_g, vel_g, pos, vel, off = dpe.workload.build_grids(cfg["G"], 0, 1)
 iq_d = torch.from_numpy(np.ascontiguousarray(iq)).to(dev)
 
@@ -47,7 +51,7 @@ s0 = torch.cuda.current_stream()
 def step1():
     bcs.Update(iq_d, cs, stream=s0)
     bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce, stream=s0)
-res["one chain of 256"] = timeit(step1)
+res["one chain of %d" % W] = timeit(step1)
 r_full = bcm.results()
 bcm.Stop(); bcs.Stop()
 
@@ -90,10 +94,10 @@ for depth in (2, 3):
         b, m = hs[i]
         b.Update(iq_d, cs, stream=streams[i])
         m.Update(b.CodeScores, b.CarrScores, bw, ce, stream=streams[i])
-    res["%d chains of 256, steps alternate" % depth] = timeit(stepalt)
+    res["%d chains of %d, steps alternate" % (depth, W)] = timeit(stepalt)
     got = hs[0][1].results()
     assert all(a["posIndex"] == b_["posIndex"] and a["velIndex"] == b_["velIndex"] for a, b_ in zip(got, r_full))
     for b, m in hs:
         m.Stop(); b.Stop()
 for k, v in res.items():
-    print("%-36s %.4f ms per 256 windows   %s" % (k, v[0], ["%.4f" % x for x in v[1]]))
+    print("%-36s %.4f ms per %d windows   %s" % (k, v[0], W, ["%.4f" % x for x in v[1]]))
