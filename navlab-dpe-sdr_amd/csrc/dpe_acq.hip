@@ -21,9 +21,19 @@
 namespace dpe {
 
 // X[b][n] = raw[n] * exp(-j 2 pi f_b n / fs)   (correlator.py:63)
-__global__ __launch_bounds__(256) void acq_wipe_kernel(const int16_t *__restrict__ iq, int S, int B, double binStart,
-                                                       double binStep, double invFs, float2 *__restrict__ X)
+// (both wipe-off kernels also clear max_percode for the fold kernel's atomic maxima: first kernel of a search)
+__device__ __forceinline__ void acq_clear(float *__restrict__ mp, long long n)
 {
+    const long long gt = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long gn = (long long)gridDim.x * gridDim.y * blockDim.x;
+    for (long long i = gt; i < n; i += gn) mp[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void acq_wipe_kernel(const int16_t *__restrict__ iq, int S, int B, double binStart,
+                                                       double binStep, double invFs, float2 *__restrict__ X,
+                                                       float *__restrict__ mp, long long mpLen)
+{
+    acq_clear(mp, mpLen);
     const int b = blockIdx.y;
     const double cyclesPerSample = (binStart + binStep * b) * invFs;
     const int *x = reinterpret_cast<const int *>(iq);
@@ -43,8 +53,10 @@ __global__ __launch_bounds__(256) void acq_wipe_kernel(const int16_t *__restrict
 // time-folded inputs (sampling the product spectrum at every N-th bin), so the coherent search runs
 // length-M transforms on folded data: N times less FFT work and memory than the literal formulation.
 __global__ __launch_bounds__(256) void acq_wipe_fold_kernel(const int16_t *__restrict__ iq, int M, int N, double binStart,
-                                                            double binStep, double invFs, float2 *__restrict__ X)
+                                                            double binStep, double invFs, float2 *__restrict__ X,
+                                                            float *__restrict__ mp, long long mpLen)
 {
+    acq_clear(mp, mpLen);
     const int b = blockIdx.y;
     const double cyclesPerSample = (binStart + binStep * b) * invFs;
     const int *x = reinterpret_cast<const int *>(iq);
@@ -87,80 +99,34 @@ __global__ __launch_bounds__(256) void acq_mul_kernel(const float2 *__restrict__
     }
 }
 
-// surface[p][b][j] = | sum_n Y[j + n M] |  (coherent)  or  sum_n |Y[j + n M]|   (correlator.py:77-84)
-__global__ __launch_bounds__(256) void acq_fold_kernel(const float2 *__restrict__ Y, int S, int M, int N, int coherent,
-                                                       float *__restrict__ surf)
+// surface[p][b][j] = | sum_n Y[j + n M] |  (coherent)  or  sum_n |Y[j + n M]|   (correlator.py:77-84), and
+// max_percode[p][j] = max_b surface[p][b][j]   (correlator.py:87) in the same pass: a block walks kAcqBinGroup bins of its
+// (PRN, delay range), keeps the running maximum per delay and merges it with one atomicMax on the value's bit pattern
+// (values are >= 0, so unsigned order is float order; a maximum does not depend on the order of the merges).  mp holds
+// zeros on entry (the wipe-off kernel clears it).  The separate column-maximum pass this replaces re-read the whole surface
+// with 320 blocks: 34 us of a 155 us search.
+constexpr int kAcqBinGroup = 25;
+__global__ __launch_bounds__(256) void acq_fold_kernel(const float2 *__restrict__ Y, int S, int M, int N, int coherent, int B,
+                                                       float *__restrict__ surf, unsigned int *__restrict__ mpBits)
 {
-    const size_t row = (size_t)blockIdx.z * gridDim.y + blockIdx.y;   // (p, b)
-    const float2 *y = Y + row * S;
+    const int p = blockIdx.z, b0 = blockIdx.y * kAcqBinGroup;
+    const int b1 = b0 + kAcqBinGroup < B ? b0 + kAcqBinGroup : B;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
-        float ar = 0.f, ai = 0.f, am = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const float2 v = y[j + n * M];
-            ar += v.x; ai += v.y;
-            am += sqrtf(v.x * v.x + v.y * v.y);
+        float mx = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            const size_t row = (size_t)p * B + b;
+            const float2 *y = Y + row * S;
+            float ar = 0.f, ai = 0.f, am = 0.f;
+            for (int n = 0; n < N; ++n) {
+                const float2 v = y[j + n * M];
+                ar += v.x; ai += v.y;
+                am += sqrtf(v.x * v.x + v.y * v.y);
+            }
+            const float sv = coherent ? sqrtf(ar * ar + ai * ai) : am;
+            surf[row * M + j] = sv;
+            mx = fmaxf(mx, sv);
         }
-        surf[row * M + j] = coherent ? sqrtf(ar * ar + ai * ai) : am;
-    }
-}
-
-// max_percode[p][j] = max_b surface[p][b][j]   (correlator.py:87)
-__global__ __launch_bounds__(256) void acq_colmax_kernel(const float *__restrict__ surf, int B, int M, float *__restrict__ mp)
-{
-    const int p = blockIdx.y;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
-        float m = 0.f;
-        for (int b = 0; b < B; ++b) m = fmaxf(m, surf[((size_t)p * B + b) * M + j]);
-        mp[(size_t)p * M + j] = m;
-    }
-}
-
-// per PRN: max_code_idx = first maximum of max_percode, max_dopp_idx = first maximum of that column (:88-89)
-__global__ __launch_bounds__(256) void acq_peak_kernel(const float *__restrict__ surf, const float *__restrict__ mp, int B, int M,
-                                                       int *__restrict__ codeIdx, int *__restrict__ doppIdx)
-{
-    const int p = blockIdx.x;
-    unsigned long long best = 0ull;
-    for (int j = threadIdx.x; j < M; j += 256) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(mp[(size_t)p * M + j]) << 32) |
-                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
-        best = key > best ? key : best;
-    }
-    __shared__ unsigned long long sB[4];
-    __shared__ int sCi;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off, 64);
-        best = o > best ? o : best;
-    }
-    if ((threadIdx.x & 63) == 0) sB[threadIdx.x >> 6] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long b = sB[0];
-        for (int q = 1; q < 4; ++q) b = sB[q] > b ? sB[q] : b;
-        sCi = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
-        codeIdx[p] = sCi;
-    }
-    __syncthreads();
-    const int ci = sCi;
-    best = 0ull;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(surf[((size_t)p * B + b) * M + ci]) << 32) |
-                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)b);
-        best = key > best ? key : best;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off, 64);
-        best = o > best ? o : best;
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sB[threadIdx.x >> 6] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long b = sB[0];
-        for (int q = 1; q < 4; ++q) b = sB[q] > b ? sB[q] : b;
-        doppIdx[p] = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+        atomicMax(&mpBits[(size_t)p * M + j], __float_as_uint(mx));
     }
 }
 
@@ -272,18 +238,56 @@ __device__ __forceinline__ unsigned int block_sum_u32(unsigned int v, unsigned i
     return sTmp[0] + sTmp[1] + sTmp[2] + sTmp[3];
 }
 
-__global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict__ mp, const int *__restrict__ codeIdx,
-                                                        const int *__restrict__ doppIdx, int M, int maskS, int iLo, double fLo,
-                                                        int iHi, double fHi, AcqStats *__restrict__ out)
+// Per PRN, one block: max_code_idx = first maximum of max_percode, max_dopp_idx = first maximum of that column of the
+// surface (correlator.py:88-89), then the peak statistics.  The row is staged in LDS when it fits (rowInLds: M floats of
+// dynamic shared memory) -- the two rank selections and their neighbours make about a dozen passes over it.
+__global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict__ surf, const float *__restrict__ mp, int B, int M,
+                                                        int rowInLds, int maskS, int iLo, double fLo, int iHi, double fHi,
+                                                        int *__restrict__ codeIdx, int *__restrict__ doppIdx,
+                                                        AcqStats *__restrict__ out)
 {
     const int p = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float sRow[];
     const float *m = mp + (size_t)p * M;
-    const int ci = codeIdx[p];
+    if (rowInLds) {
+        for (int j = tid; j < M; j += 256) sRow[j] = m[j];
+        __syncthreads();
+        m = sRow;
+    }
     __shared__ unsigned int hist[256];
     __shared__ unsigned int sTmp[4];
     __shared__ unsigned int sSel[2];
     __shared__ float sF[4];
     __shared__ double sD[4];
+    __shared__ unsigned long long sB[4];
+    auto block_argmax = [&](unsigned long long best) -> int {   // packed (value bits, ~index): larger value, then smaller index
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o > best ? o : best;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) sB[tid >> 6] = best;
+        __syncthreads();
+        unsigned long long b = sB[0];
+        for (int q = 1; q < 4; ++q) b = sB[q] > b ? sB[q] : b;
+        return (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+    };
+    unsigned long long best = 0ull;
+    for (int j = tid; j < M; j += 256) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(m[j]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+        best = key > best ? key : best;
+    }
+    const int ci = block_argmax(best);
+    best = 0ull;
+    for (int b = tid; b < B; b += 256) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(surf[((size_t)p * B + b) * M + ci]) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)b);
+        best = key > best ? key : best;
+    }
+    const int di = block_argmax(best);
+    if (tid == 0) { codeIdx[p] = ci; doppIdx[p] = di; }
+    __syncthreads();
     // row value with the +-maskS delays about the peak zeroed (indices wrap at both ends, see dpe_hip.h)
     auto val = [&](int j) -> float {
         int d = j - ci;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
     __syncthreads();
     if (tid == 0) {
         AcqStats r;
-        r.peak = m[ci]; r.maxRest = mx; r.ci = ci; r.di = doppIdx[p];
+        r.peak = m[ci]; r.maxRest = mx; r.ci = ci; r.di = di;
         r.sum = ((sD[0] + sD[1]) + sD[2]) + sD[3]; r.cnt = (long long)nCnt; r.lo = pLo; r.hi = pHi;
         out[p] = r;
     }
@@ -495,10 +499,10 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     const int S = h->SX, B = h->B, P = h->P, M = h->M;
     if (h->cfg.mode == 0)
         hipLaunchKernelGGL(acq_wipe_fold_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, samples_dev, M, h->N,
-                           h->cfg.binStartHz, h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d);
+                           h->cfg.binStartHz, h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M);
     else
         hipLaunchKernelGGL(acq_wipe_kernel, dim3((S + 1023) / 1024, B), dim3(256), 0, st, samples_dev, S, B, h->cfg.binStartHz,
-                           h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d);
+                           h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M);
     if (h->planFwd.exec(st, h->X_d)) return -1;
     for (int p0 = 0; p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
@@ -507,18 +511,19 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         // a short last chunk still runs the full-batch plan over stale rows; they are never read
         if (h->planInv.exec(st, h->Y_d)) return -1;
         // mode 0 arrives already folded: one term, |.|
-        hipLaunchKernelGGL(acq_fold_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->Y_d, S, M,
-                           h->cfg.mode == 0 ? 1 : h->N, h->cfg.mode == 0 ? 1 : 0, h->surf_d + (size_t)p0 * B * M);
+        hipLaunchKernelGGL(acq_fold_kernel, dim3((M + 255) / 256, (B + kAcqBinGroup - 1) / kAcqBinGroup, pc), dim3(256), 0, st, h->Y_d, S, M,
+                           h->cfg.mode == 0 ? 1 : h->N, h->cfg.mode == 0 ? 1 : 0, B, h->surf_d + (size_t)p0 * B * M,
+                           reinterpret_cast<unsigned int *>(h->mp_d) + (size_t)p0 * M);
     }
-    hipLaunchKernelGGL(acq_colmax_kernel, dim3((M + 255) / 256, P), dim3(256), 0, st, h->surf_d, B, M, h->mp_d);
-    hipLaunchKernelGGL(acq_peak_kernel, dim3(P), dim3(256), 0, st, h->surf_d, h->mp_d, B, M, h->peakIdx_d, h->peakIdx_d + P);
     {
         // percentile positions of _trim_mean(max_percode, 10): pos = (M - 1) q / 100, q = 5 and 95 (numpy.percentile)
         const double posLo = (double)(M - 1) * 5.0 / 100.0, posHi = (double)(M - 1) * 95.0 / 100.0;
         const int iLo = (int)std::floor(posLo), iHi = (int)std::floor(posHi);
         const int maskS = (int)std::ceil(h->cfg.samplingFrequency / kFCA);                      // :96-99
-        hipLaunchKernelGGL(acq_stats_kernel, dim3(P), dim3(256), 0, st, h->mp_d, h->peakIdx_d, h->peakIdx_d + P, M, maskS, iLo,
-                           posLo - (double)iLo, iHi, posHi - (double)iHi, h->stats_d);
+        const int rowInLds = (size_t)M * sizeof(float) <= 64 * 1024 ? 1 : 0;
+        hipLaunchKernelGGL(acq_stats_kernel, dim3(P), dim3(256), rowInLds ? (size_t)M * sizeof(float) : 0, st, h->surf_d, h->mp_d, B, M,
+                           rowInLds, maskS, iLo, posLo - (double)iLo, iHi, posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P,
+                           h->stats_d);
         DPE_CHECK_HIP(hipMemcpyAsync(h->stats_h, h->stats_d, sizeof(AcqStats) * P, hipMemcpyDeviceToHost, st));
     }
     DPE_CHECK_HIP(hipGetLastError());
