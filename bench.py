@@ -129,8 +129,9 @@ def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0):
 
 def acq_line(modes=("coherent", "textbook"), cpu_budget_s=5.0):
     """Cold-start acquisition (BASELINE.json configs[4]) as a measured line: 32 PRNs x 125 Doppler bins x all
-    2500 code delays of a 10 ms / 2.5 Msps window, the whole search (wipe-off + fold, batched rocFFT transforms, spectrum
-    product, inverse transforms, |.| surface, per-delay maximum, peak statistics) timed between HIP events on its stream.
+    2500 code delays of a 10 ms / 2.5 Msps window, the whole search (wipe-off + fold, forward rocFFT, spectrum product + inverse
+    transforms + |.| surface + per-delay maximum -- one fused kernel in the coherent mode --, peak statistics) timed between HIP
+    events on its stream.
     `value` = search cells (PRN x bin x delay) per second of the reference's coherent semantics (fixture O8); `modes` holds the
     textbook "1 ms coherent x 10 non-coherent" form too (BASELINE's wording; not a reference algorithm).  Roofline: the
     search is memory-bound by construction -- its batched transforms are 6e8 flop per window against 40 MB of surface -- so the
@@ -182,8 +183,10 @@ def acq_line(modes=("coherent", "textbook"), cpu_budget_s=5.0):
            "config": {"workload": "acq: cold-start acquisition, 32 PRNs x 125 Doppler bins (100 Hz) x 2500 code delays, 10 ms at 2.5 Msps "
                                   "(BASELINE.json configs[4])", "mode": modes[0], "prns": len(prns), "bins": int(bins.size), "delays": M},
            "x_realtime": 10.0 / ms0, "modes": per_mode, "found": found,
-           "roofline": {"bound": "hbm", "bound_physical": "launch latency + the 80 MB intermediate surface (Infinity-Cache resident)",
-                        "kernel": "dpe_acq_search (acq_wipe_fold + rocFFT fwd + acq_mul + rocFFT inv + acq_fold + colmax / peak / stats)",
+           "roofline": {"bound": "hbm", "bound_physical": "coherent: the fused transform kernel's VALU / LDS work and the one-block-per-PRN "
+                                                          "statistics chain; textbook: the 80 MB intermediate surface of the rocFFT chain",
+                        "kernel": "dpe_acq_search (coherent: acq_wipe_fold + rocFFT fwd + acq_corr2500 [product, 2500-point inverse "
+                                  "transform, |.|, column max] + acq_stats; other modes: acq_mul + rocFFT inv + acq_fold)",
                         "achieved": alg_bytes / (ms0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / (ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms0,

@@ -130,6 +130,177 @@ __global__ __launch_bounds__(256) void acq_fold_kernel(const float2 *__restrict_
     }
 }
 
+
+// ---- the coherent search's inner product at the reference's rate (2.5 Msps: 2 500 delays per code period), fused:
+//   surface[p][b][:] = | IFFT_2500( X[b][:] * Rc[p][:] ) |,   max_percode[p][:] = max_b surface[p][b][:]
+// in ONE kernel per PRN chunk -- spectrum multiply, a hand-written 2 500-point inverse transform in LDS, magnitude and the
+// running maximum over the block's bins.  The rocFFT form writes the 80 MB product, transforms it in place and reads it back
+// for the magnitudes (three kernels, 240 MB of traffic per 32-PRN search); here the product never leaves the registers and
+// the only large write is the surface itself.
+// Transform: 2500 = 10 x 10 x 5 x 5, decimation in frequency, 250 threads.  The 10-point butterflies are prime-factor
+// (2 x 5: no inner twiddles), W = exp(+j 2 pi n / 2500) comes from one table for all four passes, data ping-pongs between two
+// 20 KB LDS buffers (one barrier per pass).  Index scheme checked against numpy.fft.ifft before it was written in HIP
+// (5e-16 in fp64); on the GPU the search results equal the rocFFT path's (tests/test_gpu_acq.py, fixtures O8 / O9).
+typedef float af2 __attribute__((ext_vector_type(2)));
+// complex product in two packed instructions (the op_sel / neg forms of v_pk_fma_f32, as in dpe_bcs.hip)
+__device__ __forceinline__ af2 acq_cmul(af2 a, af2 b)
+{
+    af2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+__device__ __forceinline__ af2 acq_jrot(af2 b) { return af2{-b.y, b.x}; }   // j * b
+// inverse 5-point DFT (e^{+j 2 pi n k / 5}, unnormalised), in place
+__device__ __forceinline__ void acq_idft5(af2 &x0, af2 &x1, af2 &x2, af2 &x3, af2 &x4)
+{
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const af2 sa = x1 + x4, sb = x2 + x3, da = x1 - x4, db = x2 - x3;
+    const af2 y0 = x0 + sa + sb;
+    const af2 a1 = x0 + sa * c1 + sb * c2, a2 = x0 + sa * c2 + sb * c1;
+    const af2 b1 = acq_jrot(da * s1 + db * s2), b2 = acq_jrot(da * s2 - db * s1);
+    x0 = y0; x1 = a1 + b1; x4 = a1 - b1; x2 = a2 + b2; x3 = a2 - b2;
+}
+// inverse 10-point DFT as 2 x 5 prime-factor: inputs n = 5 n1 + 2 n2, outputs k = 5 k1 + 6 k2 (mod 10); in place, natural order
+__device__ __forceinline__ void acq_idft10(af2 (&v)[10])
+{
+    af2 e0 = v[0] + v[5], e1 = v[2] + v[7], e2 = v[4] + v[9], e3 = v[6] + v[1], e4 = v[8] + v[3];
+    af2 o0 = v[0] - v[5], o1 = v[2] - v[7], o2 = v[4] - v[9], o3 = v[6] - v[1], o4 = v[8] - v[3];
+    acq_idft5(e0, e1, e2, e3, e4);
+    acq_idft5(o0, o1, o2, o3, o4);
+    v[0] = e0; v[6] = e1; v[2] = e2; v[8] = e3; v[4] = e4;
+    v[5] = o0; v[1] = o1; v[7] = o2; v[3] = o3; v[9] = o4;
+}
+constexpr int kAcqFusedLen = 2500;
+constexpr int kAcqFusedBins = 6;     // bins per block: 21 x 32 blocks are resident at once (three per CU) on 256 CUs
+constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequences: = 25 (mod 32), so that the 25-lane groups of
+                                     // passes 1 / 2 fall on distinct 8-byte bank slots
+__global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc,
+                                                              const float2 *__restrict__ tw, int B, float *__restrict__ surf,
+                                                              unsigned int *__restrict__ mpBits)
+{
+    constexpr int N = kAcqFusedLen, SS = kAcqSubStride;
+    __shared__ float2 sA[10 * SS], sB[10 * SS];
+    __shared__ float2 sW250[256], sW25[32];   // W250^n = tw[10 n], W25^n = tw[100 n]: the twiddles of passes 2 and 3
+    const int t = threadIdx.x, p = blockIdx.y;
+    const bool act = t < 250;
+    const int tt = act ? t : 0;
+    if (act) sW250[t] = tw[10 * t];
+    if (t < 25) sW25[t] = tw[100 * t];
+    // the PRN's spectrum and the pass-1 twiddles W^(t k1) of this thread's ten elements stay in registers across the bins
+    af2 rc[10], w1[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const float2 r = Rc[(size_t)p * N + tt + 250 * q];
+        rc[q] = af2{r.x, r.y};
+        const float2 a = tw[tt * q];   // t k1 <= 249 * 9 < 2500
+        w1[q] = af2{a.x, a.y};
+    }
+    const int k1b = tt / 25, t1 = tt - 25 * k1b;        // pass 2: sub-sequence and position
+    float mx[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) mx[q] = 0.f;
+    const int b0 = blockIdx.x * kAcqFusedBins;
+    const int nb = (B - b0) < kAcqFusedBins ? (B - b0) : kAcqFusedBins;
+    float2 xn[10];   // the next bin's spectrum, fetched under this bin's transform
+#pragma unroll
+    for (int q = 0; q < 10; ++q) xn[q] = X[(size_t)b0 * N + tt + 250 * q];
+    __syncthreads();
+    for (int bi = 0; bi < nb; ++bi) {
+        const int b = b0 + bi;
+        if (act) {
+            // spectrum product (correlator.py:75) and pass 1: radix 10 over the stride-250 elements, twiddle W^(t k1)
+            af2 v[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) v[q] = acq_cmul(af2{xn[q].x, xn[q].y}, rc[q]);
+            if (bi + 1 < nb) {
+#pragma unroll
+                for (int q = 0; q < 10; ++q) xn[q] = X[(size_t)(b + 1) * N + t + 250 * q];
+            }
+            acq_idft10(v);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const af2 y = k ? acq_cmul(v[k], w1[k]) : v[k];
+                sA[k * SS + t] = make_float2(y.x, y.y);
+            }
+        }
+        __syncthreads();
+        if (act) {
+            // pass 2: radix 10 inside each 250-point sub-sequence (stride 25), twiddle W250^(t1 k2)
+            af2 v[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const float2 a = sA[k1b * SS + t1 + 25 * q];
+                v[q] = af2{a.x, a.y};
+            }
+            acq_idft10(v);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const float2 w = sW250[t1 * k];   // t1 k2 <= 24 * 9 < 250
+                const af2 y = k ? acq_cmul(v[k], af2{w.x, w.y}) : v[k];
+                sB[k1b * SS + k * 25 + t1] = make_float2(y.x, y.y);
+            }
+        }
+        __syncthreads();
+        if (act) {
+            // pass 3: radix 5 inside each 25-point sub-sequence (stride 5), twiddle W25^(t2 k3); two butterflies per thread
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int g = t + 250 * h, seq = g / 5, t2 = g - 5 * seq;
+                const int base = (seq / 10) * SS + (seq % 10) * 25;
+                af2 c[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const float2 a = sB[base + t2 + 5 * q];
+                    c[q] = af2{a.x, a.y};
+                }
+                acq_idft5(c[0], c[1], c[2], c[3], c[4]);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const float2 w = sW25[t2 * k];   // t2 k3 <= 16
+                    const af2 y = k ? acq_cmul(c[k], af2{w.x, w.y}) : c[k];
+                    sA[seq * 25 + k * 5 + t2] = make_float2(y.x, y.y);
+                }
+            }
+        }
+        __syncthreads();
+        float *sMag = reinterpret_cast<float *>(sB);   // (pass 2's output is consumed: its buffer takes the magnitudes in natural order)
+        if (act) {
+            // pass 4: the last radix 5; output index k = k1 + 10 (k2 + 10 (k3a + 5 k3b)), seq = 10 k1 + k2
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int g = t + 250 * h, seq = g / 5, k3a = g - 5 * seq;
+                af2 d[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const float2 a = sA[seq * 25 + k3a * 5 + q];
+                    d[q] = af2{a.x, a.y};
+                }
+                acq_idft5(d[0], d[1], d[2], d[3], d[4]);
+                const int k1 = seq / 10, k2 = seq - 10 * k1;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    sMag[k1 + 10 * (k2 + 10 * (k3a + 5 * k))] = __builtin_amdgcn_sqrtf(d[k].x * d[k].x + d[k].y * d[k].y);   // | . |  (correlator.py:80; v_sqrt_f32, 1 ulp)
+            }
+        }
+        __syncthreads();
+        if (act) {
+            float *o = surf + ((size_t)p * B + b) * N;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const float sv = sMag[t + 250 * q];
+                o[t + 250 * q] = sv;
+                mx[q] = fmaxf(mx[q], sv);
+            }
+        }
+        // (the next bin's pass 1 writes sA, last read before the barrier above; sB / sMag is rewritten only after pass 1's barrier)
+    }
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) atomicMax(&mpBits[(size_t)p * N + t + 250 * q], __float_as_uint(mx[q]));
+    }
+}
+
 }  // namespace dpe
 
 namespace dpe {
@@ -254,9 +425,9 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
         __syncthreads();
         m = sRow;
     }
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned int sTmp[4];
-    __shared__ unsigned int sSel[2];
+    __shared__ unsigned int hist[2 * 2048];
+    __shared__ unsigned int sTmp[8];
+    __shared__ unsigned int sSel[4];
     __shared__ float sF[4];
     __shared__ double sD[4];
     __shared__ unsigned long long sB[4];
@@ -279,15 +450,13 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
         best = key > best ? key : best;
     }
     const int ci = block_argmax(best);
-    best = 0ull;
+    // the peak's column of the surface: loads issued here, reduced at the end (they arrive under the selection passes)
+    unsigned long long bestD = 0ull;
     for (int b = tid; b < B; b += 256) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(surf[((size_t)p * B + b) * M + ci]) << 32) |
                                        (unsigned long long)(0xFFFFFFFFu - (unsigned)b);
-        best = key > best ? key : best;
+        bestD = key > bestD ? key : bestD;
     }
-    const int di = block_argmax(best);
-    if (tid == 0) { codeIdx[p] = ci; doppIdx[p] = di; }
-    __syncthreads();
     // row value with the +-maskS delays about the peak zeroed (indices wrap at both ends, see dpe_hip.h)
     auto val = [&](int j) -> float {
         int d = j - ci;
@@ -295,75 +464,99 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
         const int c = d < M - d ? d : M - d;
         return c <= maskS ? 0.f : m[j];
     };
-    // k-th smallest (0-based) of the masked row
-    auto select = [&](unsigned int k) -> float {
-        unsigned int prefix = 0u, mask = 0u;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            hist[tid] = 0u;
+    // the iLo-th and the iHi-th smallest (0-based) of the masked row, found TOGETHER: radix selection over the values' bit
+    // patterns (>= 0, so unsigned order is float order) in three passes of 11 / 11 / 10 bits with one histogram per rank --
+    // two ranks x four 8-bit passes one after the other were ~50 block barriers of a 26 us kernel
+    float selV[2], mxT = 0.f;
+    {
+        unsigned int prefix[2] = {0u, 0u}, kk[2] = {(unsigned int)iLo, (unsigned int)iHi}, mask = 0u;
+        const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = shifts[pass];
+            const unsigned int nbin = 1u << widths[pass];
+            for (unsigned int i = tid; i < 2u * nbin; i += 256) hist[i] = 0u;
             __syncthreads();
             for (int j = tid; j < M; j += 256) {
-                const unsigned int u = __float_as_uint(val(j));
-                if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+                const float vj = val(j);
+                mxT = fmaxf(mxT, vj);   // (the masked maximum rides along; three times the same value)
+                const unsigned int u = __float_as_uint(vj), dgt = (u >> shift) & (nbin - 1u);
+                if ((u & mask) == prefix[0]) atomicAdd(&hist[dgt], 1u);
+                if ((u & mask) == prefix[1]) atomicAdd(&hist[nbin + dgt], 1u);
             }
             __syncthreads();
-            // exclusive prefix over the 256 digit counts: the digit whose range holds rank k
-            const unsigned int c = hist[tid];
-            unsigned int inc = c;
+            const unsigned int per = nbin / 256u;   // 8 or 4 consecutive digits per thread
+            unsigned int tot[2] = {0u, 0u};
+            for (unsigned int q = 0; q < per; ++q) { tot[0] += hist[tid * per + q]; tot[1] += hist[nbin + tid * per + q]; }
+            unsigned int inc[2] = {tot[0], tot[1]};
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
-                const unsigned int o = __shfl_up(inc, off, 64);
-                if ((tid & 63) >= off) inc += o;
+                const unsigned int o0 = __shfl_up(inc[0], off, 64), o1 = __shfl_up(inc[1], off, 64);
+                if ((tid & 63) >= off) { inc[0] += o0; inc[1] += o1; }
             }
-            if ((tid & 63) == 63) sTmp[tid >> 6] = inc;
+            if ((tid & 63) == 63) { sTmp[tid >> 6] = inc[0]; sTmp[4 + (tid >> 6)] = inc[1]; }
             __syncthreads();
-            unsigned int base = 0u;
-            for (int q = 0; q < (tid >> 6); ++q) base += sTmp[q];
-            const unsigned int excl = base + inc - c;
-            if (c && k >= excl && k < excl + c) { sSel[0] = prefix | ((unsigned int)tid << shift); sSel[1] = k - excl; }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                unsigned int excl = inc[r] - tot[r];
+                for (int q = 0; q < (tid >> 6); ++q) excl += sTmp[4 * r + q];
+                if (tot[r] && kk[r] >= excl && kk[r] < excl + tot[r]) {   // the rank lies among this thread's digits
+                    for (unsigned int q = 0; q < per; ++q) {
+                        const unsigned int c = hist[r * nbin + tid * per + q];
+                        if (kk[r] < excl + c) { sSel[2 * r] = prefix[r] | ((tid * per + q) << shift); sSel[2 * r + 1] = kk[r] - excl; break; }
+                        excl += c;
+                    }
+                }
+            }
             __syncthreads();
-            prefix = sSel[0]; k = sSel[1];
-            mask |= 0xFFu << shift;
-            __syncthreads();
+            prefix[0] = sSel[0]; kk[0] = sSel[1]; prefix[1] = sSel[2]; kk[1] = sSel[3];
+            mask |= (nbin - 1u) << shift;
         }
-        return __uint_as_float(prefix);
-    };
-    // the order statistic after x = select(k): x itself if it occurs beyond rank k, else the smallest larger value
-    auto next_after = [&](float x, unsigned int k) -> float {
-        unsigned int le = 0u;
-        float mn = 3.0e38f;
+        selV[0] = __uint_as_float(prefix[0]);
+        selV[1] = __uint_as_float(prefix[1]);
+    }
+    // the order statistics after the two selected ones (x itself if it occurs beyond rank k, else the smallest larger value)
+    // and the masked maximum: one pass over the row, one round of reductions
+    float mx, nxt[2];
+    {
+        unsigned int le[2] = {0u, 0u};
+        float mn[2] = {3.0e38f, 3.0e38f};
         for (int j = tid; j < M; j += 256) {
             const float v = val(j);
-            le += v <= x ? 1u : 0u;
-            mn = (v > x && v < mn) ? v : mn;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                le[r] += v <= selV[r] ? 1u : 0u;
+                mn[r] = (v > selV[r] && v < mn[r]) ? v : mn[r];
+            }
         }
-        const unsigned int nLe = block_sum_u32(le, sTmp);
+        float mxw = mxT;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(mn, off, 64); mn = o < mn ? o : mn; }
+        for (int off = 32; off > 0; off >>= 1) {
+            le[0] += __shfl_xor(le[0], off, 64);
+            le[1] += __shfl_xor(le[1], off, 64);
+            const float o0 = __shfl_xor(mn[0], off, 64), o1 = __shfl_xor(mn[1], off, 64);
+            mn[0] = o0 < mn[0] ? o0 : mn[0];
+            mn[1] = o1 < mn[1] ? o1 : mn[1];
+            mxw = fmaxf(mxw, __shfl_xor(mxw, off, 64));
+        }
+        __shared__ float sR[4][3];
+        __shared__ unsigned int sL[4][2];
+        if ((tid & 63) == 0) {
+            sR[tid >> 6][0] = mn[0]; sR[tid >> 6][1] = mn[1]; sR[tid >> 6][2] = mxw;
+            sL[tid >> 6][0] = le[0]; sL[tid >> 6][1] = le[1];
+        }
         __syncthreads();
-        if ((tid & 63) == 0) sF[tid >> 6] = mn;
-        __syncthreads();
-        mn = fminf(fminf(sF[0], sF[1]), fminf(sF[2], sF[3]));
-        return nLe > k + 1u ? x : mn;
-    };
-    // masked maximum
-    float mx = 0.f;
-    for (int j = tid; j < M; j += 256) mx = fmaxf(mx, val(j));
+        mx = fmaxf(fmaxf(sR[0][2], sR[1][2]), fmaxf(sR[2][2], sR[3][2]));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((tid & 63) == 0) sF[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(sF[0], sF[1]), fmaxf(sF[2], sF[3]));
-    __syncthreads();
-    // percentiles: lo + (hi - lo) * f with a float difference, as the host expression (and scipy) evaluate it
-    double pLo, pHi;
-    {
-        const float a = select((unsigned int)iLo);
-        pLo = (double)a;
-        if (iLo + 1 < M) { const float b = next_after(a, (unsigned int)iLo); pLo = (double)a + (double)(b - a) * fLo; }
-        const float c = select((unsigned int)iHi);
-        pHi = (double)c;
-        if (iHi + 1 < M) { const float d = next_after(c, (unsigned int)iHi); pHi = (double)c + (double)(d - c) * fHi; }
+        for (int r = 0; r < 2; ++r) {
+            const unsigned int nLe = sL[0][r] + sL[1][r] + sL[2][r] + sL[3][r];
+            const float mnr = fminf(fminf(sR[0][r], sR[1][r]), fminf(sR[2][r], sR[3][r]));
+            nxt[r] = nLe > (unsigned int)(r ? iHi : iLo) + 1u ? selV[r] : mnr;
+        }
     }
+    // percentiles: lo + (hi - lo) * f with a float difference, as the host expression (and scipy) evaluate it
+    double pLo = (double)selV[0], pHi = (double)selV[1];
+    if (iLo + 1 < M) pLo = (double)selV[0] + (double)(nxt[0] - selV[0]) * fLo;
+    if (iHi + 1 < M) pHi = (double)selV[1] + (double)(nxt[1] - selV[1]) * fHi;
     double sum = 0.0;
     unsigned int cnt = 0u;
     for (int j = tid; j < M; j += 256) {
@@ -375,7 +568,9 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if ((tid & 63) == 0) sD[tid >> 6] = sum;
     __syncthreads();
+    const int di = block_argmax(bestD);
     if (tid == 0) {
+        codeIdx[p] = ci; doppIdx[p] = di;
         AcqStats r;
         r.peak = m[ci]; r.maxRest = mx; r.ci = ci; r.di = di;
         r.sum = ((sD[0] + sD[1]) + sD[2]) + sD[3]; r.cnt = (long long)nCnt; r.lo = pLo; r.hi = pHi;
@@ -393,6 +588,8 @@ struct dpe_acq {
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
     float *surf_d = nullptr, *mp_d = nullptr;
     int *peakIdx_d = nullptr;   // [2][P]: max_code_idx, max_dopp_idx
+    float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused coherent search (acq_corr2500_kernel), else null
+    bool fused = false;
     dpe::AcqStats *stats_d = nullptr, *stats_h = nullptr;   // per-PRN peak statistics; pinned host copy
     bool searched = false;
     // fine-frequency stage, allocated on first use
@@ -414,7 +611,7 @@ int dpe_acq_destroy(dpe_acq *h)
     h->planFwd.destroy();
     h->planInv.destroy();
     h->planFine.destroy();
-    void *bufs[] = {h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->stats_d};
+    void *bufs[] = {h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->stats_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->stats_h) (void)hipHostFree(h->stats_h);
     delete h;
@@ -481,8 +678,22 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         DPE_CHECK_HIP(hipDeviceSynchronize());
         return 0;
     };
-    const int rc = finish();
+    int rc = finish();
     pr.destroy();
+    // coherent search at 2 500 delays per code period: the fused kernel (DPE_ACQ_NO_FUSED=1 keeps the rocFFT chain, for A/B
+    // runs and as the cross-check of the parity tests)
+    if (!rc && cfg->mode == 0 && h->M == kAcqFusedLen && !getenv("DPE_ACQ_NO_FUSED")) {
+        std::vector<float2> tw(kAcqFusedLen);
+        for (int n = 0; n < kAcqFusedLen; ++n) {
+            const double a = 6.283185307179586476925286766559 * (double)n / (double)kAcqFusedLen;
+            tw[n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        h->tw_d = dev_alloc<float2>(kAcqFusedLen);
+        if (!h->tw_d || hipMemcpy(h->tw_d, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("[Acquisition] create: twiddle table");
+            rc = -1;
+        } else h->fused = true;
+    }
     if (rc) {
         dpe_acq_destroy(h);
         return -1;
@@ -504,7 +715,10 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         hipLaunchKernelGGL(acq_wipe_kernel, dim3((S + 1023) / 1024, B), dim3(256), 0, st, samples_dev, S, B, h->cfg.binStartHz,
                            h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M);
     if (h->planFwd.exec(st, h->X_d)) return -1;
-    for (int p0 = 0; p0 < P; p0 += h->chunk) {
+    if (h->fused)
+        hipLaunchKernelGGL(acq_corr2500_kernel, dim3((B + kAcqFusedBins - 1) / kAcqFusedBins, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
+                           B, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+    for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
         hipLaunchKernelGGL(acq_mul_kernel, dim3((S + 1023) / 1024, B, pc), dim3(256), 0, st, h->X_d,
                            h->Rc_d + (size_t)p0 * h->len, S, h->len, B, h->Y_d);

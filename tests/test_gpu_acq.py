@@ -80,6 +80,43 @@ def test_acq_32_prns_full_search():
     acq.close()
 
 
+def test_fused_coherent_search_equals_the_rocfft_chain():
+    """The coherent search at 2 500 delays per code period runs in one fused kernel (spectrum product, a hand-written
+    2 500-point inverse transform in LDS, magnitude, column maximum); DPE_ACQ_NO_FUSED=1 at create keeps the rocFFT chain
+    (multiply kernel, rocFFT, fold kernel).  Same surface to fp32 rounding, same maximum row, same peak cells and statistics
+    -- over 32 PRNs x 125 bins, with a bin count that leaves the last block of bins partly filled (125 = 20 x 6 + 5)."""
+    import os
+    import torch
+    fs, S = 2.5e6, 25000
+    ch = dpe.synth.random_channels(91, 5, prns=[4, 9, 16, 23, 29])
+    ch["cp_ref"] = ch["cp"].copy()
+    iq = torch.from_numpy(dpe.synth.gen_iq(92, fs, S, ch, amp=120.0, flip=np.zeros(5, dtype=bool))).to("cuda:0")
+    bins = np.arange(-62, 63) * 100.0
+    out = {}
+    for form in ("fused", "rocfft"):
+        old = os.environ.get("DPE_ACQ_NO_FUSED")
+        if form == "rocfft":
+            os.environ["DPE_ACQ_NO_FUSED"] = "1"
+        try:
+            acq = dpe.Acquisition(fs, S, list(range(1, 33)), bins, mode="coherent")   # the switch is read at create
+        finally:
+            if form == "rocfft":
+                if old is None:
+                    os.environ.pop("DPE_ACQ_NO_FUSED", None)
+                else:
+                    os.environ["DPE_ACQ_NO_FUSED"] = old
+        acq.search(iq)
+        out[form] = (acq.results(), acq.read_surface().copy())
+        acq.close()
+    (r0, s0), (r1, s1) = out["fused"], out["rocfft"]
+    assert s0.shape == s1.shape == (32, 125, 2500)
+    assert np.abs(s0 - s1).max() < 3e-6 * s1.max()
+    for a, b in zip(r0, r1):
+        assert a["max_code_idx"] == b["max_code_idx"] and a["max_dopp_idx"] == b["max_dopp_idx"] and a["found"] == b["found"]
+        assert abs(a["cppm"] / b["cppm"] - 1) < 1e-5 and abs(a["cppr"] / b["cppr"] - 1) < 1e-5
+    assert {4, 9, 16, 23, 29} <= {r["prn"] for r in r0 if r["found"]}   # (cppm > 2 also lets a cross-correlation peak through: both forms alike)
+
+
 @pytest.mark.gpu
 def test_o9_fine_frequency_and_two_window_driver(golden):
     """HIP search_signal (coarse + fine frequency) and the two-window driver against the reference's own
