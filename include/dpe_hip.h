@@ -31,7 +31,8 @@ extern "C" {
  * DPE_BCS_NO_CHIP=1 / DPE_BCS_NO_CHIP2=1 (no chip-boundary kernel / not its second form), DPE_BCS_NO_FUSE=1 (single
  * windows run the separate DC-sum kernel), DPE_BCS_FORCE_FFT=1 (full-length FFT form), DPE_BCS_TPB16=n / DPE_BCS_CHIP_TPB=n /
  * DPE_BCS_CHIP2_P=n (tiles or passes per block of the batch / chip kernels), DPE_BCM_NO_POLL=1 (dpe_bcm_results always
- * waits for the stream), DPE_COMM_TIMEOUT_S (rendezvous time-out).  Ablation switches that skip work (DPE_BCS_CHIP_DBG,
+ * waits for the stream), DPE_ACQ_NO_FUSED=1 (the coherent acquisition search keeps the rocFFT chain instead of the fused
+ * transform kernel), DPE_COMM_TIMEOUT_S (rendezvous time-out).  Ablation switches that skip work (DPE_BCS_CHIP_DBG,
  * DPE_BCS_FAT, DPE_BCM_SPLIT) exist only in builds with -DDPE_EXPERIMENTS. */
 #define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
 #define DPE_MAX_LAG_HALF_WIDTH 292  /* widest code-lag bank of the windowed stage-1 kernels: +-32 and four 65-lag chunks per side */

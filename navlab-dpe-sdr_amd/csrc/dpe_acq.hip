@@ -8,7 +8,9 @@
 //
 // Here: the bin loop becomes one batched FFT (rocFFT, called directly: dpe_fft.h -- an FFT is intrinsic to a
 // full code-delay search), the replica spectra (conj, 1/S folded in) are precomputed once per PRN at
-// create, and three small HIP kernels do wipe-off, spectrum multiply and fold + per-lag max over bins.
+// create, and HIP kernels do wipe-off, spectrum multiply and fold + per-lag max over bins.  The coherent search at
+// 2 500 delays per code period (the reference's 2.5 Msps) replaces multiply + inverse rocFFT + fold by ONE fused kernel
+// with its own 2 500-point transform (acq_corr2500_kernel, below).
 // mode 0 / 1 = the reference's coherent / non-coherent semantics (pinned by fixture O8);
 // mode 2 = the textbook "1 ms coherent x N non-coherent" of BASELINE.json (NOT in the reference: parity
 // unpinned, checked against the oracle's own restatement only).
