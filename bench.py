@@ -183,10 +183,9 @@ def acq_line(modes=("coherent", "textbook"), cpu_budget_s=5.0):
            "config": {"workload": "acq: cold-start acquisition, 32 PRNs x 125 Doppler bins (100 Hz) x 2500 code delays, 10 ms at 2.5 Msps "
                                   "(BASELINE.json configs[4])", "mode": modes[0], "prns": len(prns), "bins": int(bins.size), "delays": M},
            "x_realtime": 10.0 / ms0, "modes": per_mode, "found": found,
-           "roofline": {"bound": "hbm", "bound_physical": "coherent: the fused transform kernel's VALU / LDS work and the one-block-per-PRN "
-                                                          "statistics chain; textbook: the 80 MB intermediate surface of the rocFFT chain",
-                        "kernel": "dpe_acq_search (coherent: acq_wipe_fold + rocFFT fwd + acq_corr2500 [product, 2500-point inverse "
-                                  "transform, |.|, column max] + acq_stats; other modes: acq_mul + rocFFT inv + acq_fold)",
+           "roofline": {"bound": "hbm", "bound_physical": "the fused transform kernel's VALU / LDS work and the one-block-per-PRN statistics chain",
+                        "kernel": "dpe_acq_search (acq_wipe[_fold] + rocFFT fwd + acq_corr2500 [product, 2500-point inverse "
+                                  "transforms, |.| summed over the code periods in the textbook mode, column max] + acq_stats)",
                         "achieved": alg_bytes / (ms0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / (ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms0,

@@ -177,9 +177,12 @@ constexpr int kAcqFusedLen = 2500;
 constexpr int kAcqFusedBins = 6;     // bins per block: 21 x 32 blocks are resident at once (three per CU) on 256 CUs
 constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequences: = 25 (mod 32), so that the 25-lane groups of
                                      // passes 1 / 2 fall on distinct 8-byte bank slots
+// nSeg = 1: X[b][2500] holds the time-folded window (coherent mode).  nSeg = N: X[b][N][2500] holds the N code periods
+// of the window (textbook mode, "1 ms coherent x N non-coherent"): the magnitudes of the N transforms are summed in
+// registers -- a thread's ten outputs have the same indices in every segment -- before they go out.
 __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc,
-                                                              const float2 *__restrict__ tw, int B, float *__restrict__ surf,
-                                                              unsigned int *__restrict__ mpBits)
+                                                              const float2 *__restrict__ tw, int B, int nSeg,
+                                                              float *__restrict__ surf, unsigned int *__restrict__ mpBits)
 {
     constexpr int N = kAcqFusedLen, SS = kAcqSubStride;
     __shared__ float2 sA[10 * SS], sB[10 * SS];
@@ -199,25 +202,27 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
         w1[q] = af2{a.x, a.y};
     }
     const int k1b = tt / 25, t1 = tt - 25 * k1b;        // pass 2: sub-sequence and position
-    float mx[10];
+    float mx[10], macc[2][5];
 #pragma unroll
     for (int q = 0; q < 10; ++q) mx[q] = 0.f;
     const int b0 = blockIdx.x * kAcqFusedBins;
     const int nb = (B - b0) < kAcqFusedBins ? (B - b0) : kAcqFusedBins;
-    float2 xn[10];   // the next bin's spectrum, fetched under this bin's transform
+    const int nTr = nb * nSeg;   // transforms of this block: rows b0 nSeg .. of X, consecutive
+    const float2 *x0 = X + (size_t)b0 * nSeg * N;
+    float2 xn[10];   // the next transform's spectrum, fetched under this one
 #pragma unroll
-    for (int q = 0; q < 10; ++q) xn[q] = X[(size_t)b0 * N + tt + 250 * q];
+    for (int q = 0; q < 10; ++q) xn[q] = x0[tt + 250 * q];
     __syncthreads();
-    for (int bi = 0; bi < nb; ++bi) {
-        const int b = b0 + bi;
+    int seg = 0, b = b0;
+    for (int e = 0; e < nTr; ++e) {
         if (act) {
             // spectrum product (correlator.py:75) and pass 1: radix 10 over the stride-250 elements, twiddle W^(t k1)
             af2 v[10];
 #pragma unroll
             for (int q = 0; q < 10; ++q) v[q] = acq_cmul(af2{xn[q].x, xn[q].y}, rc[q]);
-            if (bi + 1 < nb) {
+            if (e + 1 < nTr) {
 #pragma unroll
-                for (int q = 0; q < 10; ++q) xn[q] = X[(size_t)(b + 1) * N + t + 250 * q];
+                for (int q = 0; q < 10; ++q) xn[q] = x0[(size_t)(e + 1) * N + t + 250 * q];
             }
             acq_idft10(v);
 #pragma unroll
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
             // pass 3: radix 5 inside each 25-point sub-sequence (stride 5), twiddle W25^(t2 k3); two butterflies per thread
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int g = t + 250 * h, seq = g / 5, t2 = g - 5 * seq;
-                const int base = (seq / 10) * SS + (seq % 10) * 25;
+                const int g = t + 250 * h, sq = g / 5, t2 = g - 5 * sq;
+                const int base = (sq / 10) * SS + (sq % 10) * 25;
                 af2 c[5];
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
@@ -261,41 +266,48 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
                 for (int k = 0; k < 5; ++k) {
                     const float2 w = sW25[t2 * k];   // t2 k3 <= 16
                     const af2 y = k ? acq_cmul(c[k], af2{w.x, w.y}) : c[k];
-                    sA[seq * 25 + k * 5 + t2] = make_float2(y.x, y.y);
+                    sA[sq * 25 + k * 5 + t2] = make_float2(y.x, y.y);
                 }
             }
         }
         __syncthreads();
         float *sMag = reinterpret_cast<float *>(sB);   // (pass 2's output is consumed: its buffer takes the magnitudes in natural order)
+        const bool last = seg == nSeg - 1;              // block-uniform
         if (act) {
-            // pass 4: the last radix 5; output index k = k1 + 10 (k2 + 10 (k3a + 5 k3b)), seq = 10 k1 + k2
+            // pass 4: the last radix 5; output index k = k1 + 10 (k2 + 10 (k3a + 5 k3b)), sq = 10 k1 + k2
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int g = t + 250 * h, seq = g / 5, k3a = g - 5 * seq;
+                const int g = t + 250 * h, sq = g / 5, k3a = g - 5 * sq;
                 af2 d[5];
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
-                    const float2 a = sA[seq * 25 + k3a * 5 + q];
+                    const float2 a = sA[sq * 25 + k3a * 5 + q];
                     d[q] = af2{a.x, a.y};
                 }
                 acq_idft5(d[0], d[1], d[2], d[3], d[4]);
-                const int k1 = seq / 10, k2 = seq - 10 * k1;
+                const int k1 = sq / 10, k2 = sq - 10 * k1;
 #pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    sMag[k1 + 10 * (k2 + 10 * (k3a + 5 * k))] = __builtin_amdgcn_sqrtf(d[k].x * d[k].x + d[k].y * d[k].y);   // | . |  (correlator.py:80; v_sqrt_f32, 1 ulp)
+                for (int k = 0; k < 5; ++k) {
+                    const float mg = __builtin_amdgcn_sqrtf(d[k].x * d[k].x + d[k].y * d[k].y);   // | . |  (correlator.py:80; v_sqrt_f32, 1 ulp)
+                    macc[h][k] = seg == 0 ? mg : macc[h][k] + mg;
+                    if (last) sMag[k1 + 10 * (k2 + 10 * (k3a + 5 * k))] = macc[h][k];
+                }
             }
         }
-        __syncthreads();
-        if (act) {
-            float *o = surf + ((size_t)p * B + b) * N;
+        __syncthreads();   // (also orders this pass's reads of sA before the next transform's pass-1 writes)
+        if (last) {
+            if (act) {
+                float *o = surf + ((size_t)p * B + b) * N;
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-                const float sv = sMag[t + 250 * q];
-                o[t + 250 * q] = sv;
-                mx[q] = fmaxf(mx[q], sv);
+                for (int q = 0; q < 10; ++q) {
+                    const float sv = sMag[t + 250 * q];
+                    o[t + 250 * q] = sv;
+                    mx[q] = fmaxf(mx[q], sv);
+                }
             }
-        }
-        // (the next bin's pass 1 writes sA, last read before the barrier above; sB / sMag is rewritten only after pass 1's barrier)
+            seg = 0; ++b;
+            // (sB / sMag is rewritten only after the next transform's pass-1 barrier)
+        } else ++seg;
     }
     if (act) {
 #pragma unroll
@@ -684,7 +696,7 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     pr.destroy();
     // coherent search at 2 500 delays per code period: the fused kernel (DPE_ACQ_NO_FUSED=1 keeps the rocFFT chain, for A/B
     // runs and as the cross-check of the parity tests)
-    if (!rc && cfg->mode == 0 && h->M == kAcqFusedLen && !getenv("DPE_ACQ_NO_FUSED")) {
+    if (!rc && (cfg->mode == 0 || cfg->mode == 2) && h->M == kAcqFusedLen && !getenv("DPE_ACQ_NO_FUSED")) {
         std::vector<float2> tw(kAcqFusedLen);
         for (int n = 0; n < kAcqFusedLen; ++n) {
             const double a = 6.283185307179586476925286766559 * (double)n / (double)kAcqFusedLen;
@@ -719,7 +731,7 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     if (h->planFwd.exec(st, h->X_d)) return -1;
     if (h->fused)
         hipLaunchKernelGGL(acq_corr2500_kernel, dim3((B + kAcqFusedBins - 1) / kAcqFusedBins, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
-                           B, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+                           B, h->cfg.mode == 0 ? 1 : h->N, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
         hipLaunchKernelGGL(acq_mul_kernel, dim3((S + 1023) / 1024, B, pc), dim3(256), 0, st, h->X_d,
