@@ -650,9 +650,12 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     h->SX = (cfg->mode == 0) ? h->M : h->S;
     h->chunk = cfg->prnChunk > 0 ? std::min(cfg->prnChunk, h->P) : std::min(8, h->P);
     const size_t S = h->SX, B = h->B, P = h->P;
+    // coherent / textbook search at 2 500 delays per code period: the fused kernel, which needs neither the product buffer nor
+    // the inverse plan (DPE_ACQ_NO_FUSED=1 keeps the rocFFT chain, for A/B runs and as the cross-check of the parity tests)
+    const bool wantFused = (cfg->mode == 0 || cfg->mode == 2) && h->M == kAcqFusedLen && !getenv("DPE_ACQ_NO_FUSED");
     h->X_d = dev_alloc<float2>(B * S);
     h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
-    h->Y_d = dev_alloc<float2>((size_t)h->chunk * B * S);
+    h->Y_d = dev_alloc<float2>(wantFused ? 1 : (size_t)h->chunk * B * S);
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
     h->peakIdx_d = dev_alloc<int>(2 * P);
@@ -664,7 +667,7 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         return -1;
     }
     const int batchFwd = (int)(B * (S / h->len)), batchInv = (int)(h->chunk * B * (S / h->len));
-    if (h->planFwd.create((size_t)h->len, (size_t)batchFwd, false) || h->planInv.create((size_t)h->len, (size_t)batchInv, true)) {
+    if (h->planFwd.create((size_t)h->len, (size_t)batchFwd, false) || (!wantFused && h->planInv.create((size_t)h->len, (size_t)batchInv, true))) {
         dpe_acq_destroy(h);   // (the message is rocFFT's, from dpe_fft.h)
         return -1;
     }
@@ -694,9 +697,7 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     };
     int rc = finish();
     pr.destroy();
-    // coherent search at 2 500 delays per code period: the fused kernel (DPE_ACQ_NO_FUSED=1 keeps the rocFFT chain, for A/B
-    // runs and as the cross-check of the parity tests)
-    if (!rc && (cfg->mode == 0 || cfg->mode == 2) && h->M == kAcqFusedLen && !getenv("DPE_ACQ_NO_FUSED")) {
+    if (!rc && wantFused) {
         std::vector<float2> tw(kAcqFusedLen);
         for (int n = 0; n < kAcqFusedLen; ++n) {
             const double a = 6.283185307179586476925286766559 * (double)n / (double)kAcqFusedLen;
