@@ -1137,6 +1137,7 @@ struct dpe_bcs {
     int chipTpbMax = 1;                // longest tile (passes) whose 6-moment block still meets the Taylor bound
     long long C;
     int8_t *chipTable_d = nullptr;
+    uint32_t *chipBits_d = nullptr;   // the same chips as sign bits, periodically extended (bcs_bank_chip2_kernel: scalar loads)
     double *tTable_d = nullptr;   // ns-rounded sample times (always allocated; used only when useTable)
     bool useTable = false;
     long long *sums_d = nullptr;
@@ -1226,6 +1227,11 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     std::vector<int8_t> table(37 * 1024, 0);
     for (int prn = 1; prn <= 37; ++prn) gen_ca_code_host(prn, table.data() + (prn - 1) * 1024);
     h->chipTable_d = dev_alloc<int8_t>(table.size());
+    std::vector<uint32_t> bitTable((size_t)37 * k2BitWords, 0u);
+    for (int prn = 1; prn <= 37; ++prn)
+        for (int b = 0; b < 32 * k2BitWords; ++b)
+            if (table[(size_t)(prn - 1) * 1024 + b % kLCA] > 0) bitTable[(size_t)(prn - 1) * k2BitWords + (b >> 5)] |= 1u << (b & 31);
+    h->chipBits_d = dev_alloc<uint32_t>(bitTable.size());
     {
         std::vector<double> tt(S);
         for (int n = 0; n < S; ++n) tt[n] = std::round(((double)n / fs) * 1.0e9) / 1.0e9;
@@ -1279,7 +1285,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
     h->info_d = dev_alloc<int>(W * K);
     h->status_d = dev_alloc<int>(1);
-    if (!h->status_d || !h->tTable_d || !h->chipTable_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
+    if (!h->status_d || !h->tTable_d || !h->chipTable_d || !h->chipBits_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
         !h->info_d || hipHostMalloc((void **)&h->chanBase_h, dpe_bcs::kStaging * W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrScores] create: device allocation failed");
         dpe_bcs_destroy(h);
@@ -1287,6 +1293,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     }
     const auto finish = [&]() -> int {   // a failure from here on must not leak the handle
         DPE_CHECK_HIP(hipMemcpy(h->chipTable_d, table.data(), table.size(), hipMemcpyHostToDevice));
+        DPE_CHECK_HIP(hipMemcpy(h->chipBits_d, bitTable.data(), bitTable.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         DPE_CHECK_HIP(hipMemset(h->codeBank_d, 0, W * K * (2 * cfg->lagHalfWidth + 1) * sizeof(float2)));
         DPE_CHECK_HIP(hipMemset(h->carrBank_d, 0, W * K * (2 * cfg->binHalfWidth + 1) * sizeof(float2)));
         for (hipEvent_t &e : h->stagingFree) DPE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1332,7 +1339,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
 int dpe_bcs_destroy(dpe_bcs *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->tTable_d, h->chipTable_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
+    void *bufs[] = {h->tTable_d, h->chipTable_d, h->chipBits_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
     h->planS3.destroy(); h->planS2.destroy(); h->planC.destroy();
@@ -1621,7 +1628,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         const dim3 cgrid(((c2nBlk * nWindows + 7) / 8) * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
 #define DPE_LAUNCH_CHIP2(NM, LV)                                                                                               \
     hipLaunchKernelGGL((bcs_bank_chip2_kernel<NM, LV>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
-                       nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->part_d, h->mom_d)
+                       nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->chipBits_d, h->part_d, h->mom_d)
         if (c2L1 == 24) { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, 24); else DPE_LAUNCH_CHIP2(6, 24); }
         else { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, 19); else DPE_LAUNCH_CHIP2(6, 19); }
 #undef DPE_LAUNCH_CHIP2

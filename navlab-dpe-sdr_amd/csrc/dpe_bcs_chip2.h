@@ -33,9 +33,6 @@ namespace dpe {
 #ifndef DPE_C2_WAVES
 #define DPE_C2_WAVES 3
 #endif
-#ifndef DPE_C2_GB
-#define DPE_C2_GB 8
-#endif
 constexpr int k2Own0 = 3;      // first owner lane
 #ifndef DPE_C2_OWN
 #define DPE_C2_OWN 58
@@ -46,6 +43,8 @@ constexpr int k2MaxL1 = 24;    // L1 = floor(fs / fc) <= 24: chips of at most 25
 constexpr int k2MinL1 = 16;    // the margins reach +-32 samples: two regular chips must cover them
 constexpr int k2Pad = 64;
 constexpr int k2QLen = k2Pad + k2Own * (k2MaxL1 + 1) + 1 + 64;
+constexpr int k2Round = 16;    // list entries per gather round: four lane groups x four entries (the list is zero-padded to a whole round)
+constexpr int k2BitWords = 40; // words per PRN of the chip-sign bit table (dpe_bcs_create): bit b = [chip (b mod 1023) is +1], b < 1280
 
 // a * t + c and a * conj(t) + c with t a block constant in scalar registers (the lane-frame twiddles): two packed FMAs each
 #define DPE_C2_TWC "s"
@@ -64,17 +63,26 @@ __device__ __forceinline__ f2 tw_conj_mul_add(f2 a, f2 t, f2 c)
     return r;
 }
 
+// +1.0f / -1.0f per lane from a 64-bit lane mask held in scalar registers: one v_cndmask, the mask IS the condition operand
+__device__ __forceinline__ float mask_pm1(unsigned long long m)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, -1.0, 1.0, %1" : "=v"(r) : "s"(m));
+    return r;
+}
+
 template <int kNMom, int L1>
 __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
                                                                int S, int K, int nW, int Lt, int nBlk, int nSumBlk,
                                                                const BcsChanDev *__restrict__ chan,
                                                                const long long *__restrict__ sums,
                                                                const int8_t *__restrict__ chipTable,
+                                                               const uint32_t *__restrict__ chipBits,
                                                                float2 *__restrict__ part, float2 *__restrict__ mom)
 {
     constexpr int NL = 65;   // partial layout shared with the other stage-1 kernels: entry j <-> lag j - 32 (j = 64 unused)
     __shared__ float2 sQ[k2QLen];
-    __shared__ float2 sList[64 + DPE_C2_GB];   // flips of a pass: {J, byte offset into sQ}, then one batch of zeros
+    __shared__ float2 sList[64 + k2Round];   // flips of a pass: {J, byte offset into sQ}, zero-padded to a whole round
 
     // Block -> (window, tile, SV), XCD-aware as in the first form: the K blocks of a tile are congruent mod 8
     const int lane = threadIdx.x;
@@ -84,6 +92,11 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     (void)pb;
     const BcsChanDev ch = params_ptr(chan, inl)[(size_t)w * K + k];
     const int8_t *chips = chipTable + (ch.prn - 1) * 1024;
+    // the same chips as sign bits: lane l keeps word l of the PRN's (periodically extended) bit table for the whole tile, and a
+    // pass fetches the three words it needs with v_readlane at a scalar index -- no memory operation inside the pass loop.
+    // (A first version read them with scalar loads: the s_waitcnt that follows an s_load is lgkmcnt(0), which also drains the
+    // wave's LDS queue -- 0.81 against 0.57 ms per 128 windows at H.)
+    const int bitsV = (int)(lane < k2BitWords ? chipBits[(ch.prn - 1) * k2BitWords + lane] : 0u);
     float mRe, mIm;
     window_mean(sums, w, nSumBlk, S, mRe, mIm);
     const f2 meanv = f2{mRe, mIm};
@@ -91,12 +104,17 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
 
     // chip index of replica index m (phases are >= 0: the truncating conversion is the floor, :347-349)
     auto chip_at = [&](int m) -> int { return (int)fma((double)m, ch.codeStep, ch.rc); };
-    // first replica index of chip c: min { m : chip_at(m) >= c }
+    // first replica index of chip c: min { m : chip_at(m) >= c }.  The estimate ceil((c - rc) fs / fc) is off the exact threshold
+    // by < 1e-9 samples (three roundings at magnitude <= 2^20), so the two-sided check against the reference's own expression is
+    // only needed when the estimate lies within 1e-6 of an integer -- a wave-uniform branch that is all but never taken
     auto first_index = [&](int c) -> int {
-        const double md = ceil(((double)c - ch.rc) * ch.invStep);
+        const double xq = ((double)c - ch.rc) * ch.invStep;
+        const double md = ceil(xq);
         int m = (int)md;
-        if ((int)fma(md - 1.0, ch.codeStep, ch.rc) >= c) m -= 1;
-        else if ((int)fma(md, ch.codeStep, ch.rc) < c) m += 1;
+        if (__ballot(fabs((md - xq) - 0.5) > 0.499999) != 0ull) {
+            if ((int)fma(md - 1.0, ch.codeStep, ch.rc) >= c) m -= 1;
+            else if ((int)fma(md, ch.codeStep, ch.rc) < c) m += 1;
+        }
         return m;
     };
     static_assert(L1 >= k2MinL1 && L1 <= k2MaxL1, "chips of L1 or L1 + 1 samples, L1 = floor(fs / fc) (the host checks every channel)");
@@ -127,7 +145,12 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     float2 *momOut = mom + ((((size_t)w * K + k) * 2) * nBlk + blk) * kNMom;   // [side][nBlk][kNMom]
     const size_t momSide = (size_t)nBlk * kNMom;
 
-    const int qLaneBytes = 8 * ((k2Pad - 32) + lane);   // byte offset in sQ of lag (lane - 32)'s entry for a boundary at the pass start
+    // gather geometry: lane (g, j) = (lane >> 4, lane & 15) sums the lags j - 32 + 16 t, t = 0 .. 3, over the list entries 4 s + g:
+    // the 16 lanes of a group read 128 consecutive bytes per LDS access (conflict-free; lags 4 j .. 4 j + 3 per lane -- 16-byte
+    // pieces at a 32-byte lane stride -- were 4-way bank conflicts and made the kernel 40 % slower)
+    const int lg = lane >> 4, lj = lane & 15;
+    const int qLaneBytes = 8 * ((k2Pad - 32) + lj);   // byte offset in sQ of the lane's first lag for a boundary at the pass start
+    const int listLaneBytes = 16 * lg;                // a group takes the list entries 8 q + 2 g and 8 q + 2 g + 1: consecutive flips
     const float phi = (float)(6.283185307179586476925286766559 * ch.carrStep);   // wipe-off phase step per sample (rad)
     // DC-mean sums over a chip of len samples about its centre: G0 = sum exp(-j phi d) (real), j G1 = sum d exp(-j phi d)
     auto mean_sums = [&](float fl, float &G0, float &G1) {
@@ -140,7 +163,32 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     mean_sums((float)(L1 + 1), G0b, G1b);
     const float xOrigin = 0.5f * (float)(Lt - 1);   // moment abscissa origin relative to the tile's nominal start blk Lt
 
-    f2 accS[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};   // lag sums of the two nav-bit sides, lane <-> lag
+    // Lag sums: ONE accumulator set, for the nav-bit side being accumulated (accSide) -- four lags per lane, one flip group per
+    // 16 lanes, the end terms shared out among the groups.  A change of side (twice per tile at most, in the tile that holds
+    // the nav-bit boundary and in those whose margins wrap around the window's ends) goes through spill(): the four flip groups
+    // are added up and lanes 0 .. 15 add them into the block partial in global memory.
+    f2 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f2{0.f, 0.f};
+    int accSide = 0, spilled = 0;
+    float2 *partOut = part + ((((size_t)w * K + k) * nBlk + blk) * 2) * NL;   // [side][NL]
+    auto spill = [&](int side) {
+        float2 *o = partOut + side * NL;
+        const bool again = (spilled >> side) & 1;
+        spilled |= 1 << side;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f2 v = acc[t];
+            v.x += __shfl_xor(v.x, 16, 64); v.y += __shfl_xor(v.y, 16, 64);
+            v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64);
+            if (lane < 16) {
+                if (again) { const float2 old = o[lj + 16 * t]; v += f2{old.x, old.y}; }   // (the same lane wrote it: program order)
+                o[lj + 16 * t] = make_float2(v.x, v.y);
+            }
+            acc[t] = f2{0.f, 0.f};
+        }
+        if (lane == 0) o[64] = make_float2(0.f, 0.f);
+    };
     f2 M[kNMom];                                  // per-lane moment sums of the current side
 #pragma unroll
     for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
@@ -158,15 +206,19 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
 #pragma unroll
         for (int p = 0; p < kNMom; ++p) M[p] = f2{0.f, 0.f};
     };
-    auto add_moments = [&](f2 E0, f2 E1, float xb) {   // a chip's zeroth / first moment about its own centre xb
+    // a chip's zeroth / first moment about its own centre xb:  M_p += xb^p E0 + p xb^(p-1) E1 = xb^(p-1) (xb E0 + p E1)
+    // (two packed FMAs per order on three scalar powers; the running-product form it replaces took four)
+    auto add_moments = [&](f2 E0, f2 E1, float xb) {
         M[0] += E0;
-        f2 xp = E0 * xb;
-        f2 xq = E1;
+        const f2 xE0 = E0 * xb;
+        if (kNMom > 1) M[1] += xE0 + E1;
+        float xp = xb;
 #pragma unroll
-        for (int p = 1; p < kNMom; ++p) {
-            M[p] += xp + xq * (float)p;
+        for (int p = 2; p < kNMom; ++p) {
+            const float pf = (float)p;
+            const f2 F = __builtin_elementwise_fma(E1, f2{pf, pf}, xE0);
+            M[p] = __builtin_elementwise_fma(F, f2{xp, xp}, M[p]);
             xp *= xb;
-            xq *= xb;
         }
     };
 
@@ -175,18 +227,35 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     // the fp64 check only for lanes within 2^-24 of a sample boundary -- was measured in round 3: 0.608 against 0.601 ms per 128
     // windows at H.  fp64 FMAs issue at the full vector rate on this part and the two 64-bit multiply-adds of the DDA do not.)
     int eN = 0, offN = 0, lenN = 0, eAN = 0, eBN = 0;
-    int8_t rN = 0;
+    unsigned long long rMaskN = 0ull;   // wave-uniform: bit l = [lane l's chip is +1]
+    unsigned long long sideMaskN = 0ull;   // wave-uniform: bit l = [lane l's chip lies behind the nav-bit boundary]
     bool ownN = false, edgeN = false;
     int raw[L1], rawX = 0;
-    auto setup = [&](int cBase) {
-        const int c = cBase - k2Own0 + lane;
-        int cw = c, off = 0;
-        if (c < c0) { cw = c + Nc; off = -S; }
-        else if (c > cEnd) { cw = c - Nc; off = S; }
-        const int e = (cw == c0) ? 0 : first_index(cw);   // the window's first chip begins before sample 0: clipped
+    auto setup = [&](int cBase, auto pureTag) {
+        const int cF = cBase - k2Own0;   // lane 0's chip
+        const int c = cF + lane;
+        int e, off = 0;
+        if (cF > c0 && cF + 63 <= cEnd) {
+            // every chip of the pass lies inside the window (all passes but its first and last): no circular continuation, and
+            // the 64 chip signs are bits [cF mod 1023, + 64) of the PRN's periodically extended sign table -- three scalar
+            // v_readlane and two scalar shifts instead of a modulo, an address and a byte load per lane
+            e = first_index(c);
+            const int st = cF % kLCA, wi = st >> 5, sh = st & 31;
+            const unsigned w0 = (unsigned)__builtin_amdgcn_readlane(bitsV, wi), w1 = (unsigned)__builtin_amdgcn_readlane(bitsV, wi + 1),
+                           w2 = (unsigned)__builtin_amdgcn_readlane(bitsV, wi + 2);
+            const unsigned long long lo = ((unsigned long long)w1 << 32) | (unsigned long long)w0;
+            rMaskN = (lo >> sh) | ((((unsigned long long)w2) << 32) << (32 - sh));
+        } else {
+            int cw = c;
+            if (c < c0) { cw = c + Nc; off = -S; }
+            else if (c > cEnd) { cw = c - Nc; off = S; }
+            e = (cw == c0) ? 0 : first_index(cw);   // the window's first chip begins before sample 0: clipped
+            rMaskN = __ballot(chips[cw % kLCA] > 0);
+        }
         eN = e + off;
         offN = off;
-        rN = chips[cw % kLCA];
+        if constexpr (!decltype(pureTag)::value)
+            sideMaskN = ch.hasFlip ? __ballot(e >= ch.idxNext) : 0ull;   // (e = the chip's replica index: the nav-bit side, :352-367)
         const int nOwn = (cHi - cBase < k2Own) ? cHi - cBase : k2Own;
         const int eNext = __builtin_amdgcn_update_dpp(0, eN, 0x130, 0xf, 0xf, true);   // wave_shl:1 -> lane + 1
         ownN = lane >= k2Own0 && lane < k2Own0 + nOwn;
@@ -212,14 +281,61 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
             asm volatile("" ::: "memory");
         }
     };
-    setup(cLo);
+    // the lag sums over nList list entries (a multiple of 16): per round of 16 entries a lane reads the four of its group -- two
+    // PAIRS of consecutive flips -- forms four addresses and fetches the prefix values of its four lags at each (two LDS
+    // instructions each): 4 + 16 packed FMAs VALU and 10 LDS instructions per 16 flips, against 32 and 24 with lanes <-> single lags
+    auto gather = [&](f2 (&a4)[4], int nList) {
+        for (int i0 = 0; i0 < nList; i0 += k2Round) {
+            float2 ent[4], qv[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                ent[s] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(sList) + (listLaneBytes + 8 * i0 + 64 * (s >> 1) + 8 * (s & 1)));
+            __builtin_amdgcn_sched_barrier(0);   // (the reads of a round stay together: one at a time the LDS latency is exposed per entry)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const char *q = reinterpret_cast<const char *>(sQ) + (qLaneBytes + __builtin_bit_cast(int, ent[s].y));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) qv[s][t] = *reinterpret_cast<const float2 *>(q + 128 * t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f2 ej = f2{ent[s].x, ent[s].y};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f2 qj = f2{qv[s][t].x, qv[s][t].y};
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a4[t]) : "v"(qj), "v"(ej));   // a4 += q * J (J = low half of the entry)
+                }
+            }
+        }
+    };
+    // The pass loop in two instantiations.  kPure: every chip the tile touches -- owners and margin lanes of all its passes -- lies
+    // on ONE side of the nav-bit boundary (all tiles but the one that holds the boundary and, with a boundary in the window, the
+    // first and the last, whose margins wrap around): no side masks, no flush / spill inside the loop.
+    auto passes = [&](auto pureTag) {
+    constexpr bool kPure = decltype(pureTag)::value;
+    setup(cLo, pureTag);
     fetch();
+    // (a pass's flips are summed from zero and join the running sums with one addition: with a DC offset the prefix values
+    // are ~1e6 and alternate in sign -- added one by one to a running sum of the peak's size they cost it digits)
+    // Precision: with a DC offset the prefix values are a ramp of +-1e6 and the flips alternate in sign, so what a pass adds up
+    // cancels to a few percent of its terms.  A group's entries are PAIRS of consecutive flips, an unpaired last flip is shared
+    // out in quarters, and so is the end term -- every group's pass sum then cancels by itself -- and the pass sum is formed
+    // from zero and joins the running sums with one addition.  ((+900, -700) LSB of DC on a 40 LSB signal: code bank within
+    // 1.5e-6 of the oracle; 2.0e-6 with the flips dealt out one by one, 1.8e-6 with round 3's single-lag lanes.)
+    auto gather_pass = [&](int nList, f2 endQuarter) {
+        f2 t4[4] = {endQuarter, endQuarter, endQuarter, endQuarter};
+        gather(t4, nList);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += t4[t];
+    };
 
     for (int p = 0; p < nPassT; ++p) {
         const int e = eN, off = offN, len = lenN, eA = eAN, eB = eBN;
         const bool own = ownN, edge = edgeN;
-        const float r = (float)rN;
-        const int sd = (ch.hasFlip && e - off >= ch.idxNext) ? 1 : 0;
+        const unsigned long long rMask = rMaskN, sideMask = sideMaskN;
+        const float r = mask_pm1(rMask);
+        const bool sd1 = !kPure && __builtin_amdgcn_inverse_ballot_w64(sideMask);
 
         // ---- 1. the chip's samples in the lane's rotating frame: u_i, and vv = sum of all u_i (first moment, by Abel summation)
         f2 u[L1], uX, run = f2{0.f, 0.f}, vv = f2{0.f, 0.f};
@@ -285,7 +401,7 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
         // ---- the next pass's chips and samples: issued here (u[] is dead, its registers take the samples), they arrive under
         // the moments and the gather of this pass
         if (p + 1 < nPassT) {
-            setup(cLo + (p + 1) * k2Own);
+            setup(cLo + (p + 1) * k2Own, pureTag);
             fetch();
         }
 
@@ -309,86 +425,112 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
                 mean_sums(lenf, G0, G1);
             }
             const f2 mw = cmul(meanv, wc);
-            const float rOwn = own ? r : 0.f;
-            const f2 E0 = (tot - mw * G0) * rOwn;
-            const f2 E1 = (D1 - f2{-mw.y, mw.x} * G1) * rOwn;
+            const f2 P0 = tot - mw * G0, P1 = D1 - f2{-mw.y, mw.x} * G1;
             const float xb = (float)(e - blk * Lt) - xOrigin + 0.5f * (lenf - 1.f);
-            const bool any0 = __ballot(own && sd == 0) != 0ull, any1 = __ballot(own && sd == 1) != 0ull;
-            if (any0) {
-                const float m0 = sd == 0 ? 1.f : 0.f;
-                add_moments(E0 * m0, E1 * m0, xb);
-            }
-            if (any1) {
-                if (curSide == 0) { flush(0); curSide = 1; }
-                const float m1 = sd == 1 ? 1.f : 0.f;
-                add_moments(E0 * m1, E1 * m1, xb);
+            if constexpr (kPure) {
+                const float rOwn = own ? r : 0.f;
+                add_moments(P0 * rOwn, P1 * rOwn, xb);
+            } else {
+                // sides among the owned chips (uniform masks): all passes but the one that holds the nav-bit boundary have one
+                const unsigned long long ownMask = __ballot(own);
+                const bool any0 = (~sideMask & ownMask) != 0ull, any1 = (sideMask & ownMask) != 0ull;
+                if (any1 && !any0 && curSide == 0) { flush(0); curSide = 1; }
+                const float rA = (own && (sd1 == !any0)) ? r : 0.f;   // the owners on the first side present
+                add_moments(P0 * rA, P1 * rA, xb);
+                if (any0 && any1) {
+                    flush(0);
+                    curSide = 1;
+                    const float rB = (own && sd1) ? r : 0.f;
+                    add_moments(P0 * rB, P1 * rB, xb);
+                }
             }
         }
 
-        // ---- 4. lag sums per nav-bit side: the flips among the boundaries the lag window reaches
+        // ---- 4. lag sums: the flips among the boundaries the lag window reaches
         const bool inReach = lane >= 1 && e > eA - 32 && e < eB + 32;
         const unsigned long long rm = __ballot(inReach);
         const int firstIn = __builtin_ctzll(rm), lastIn = 63 - __builtin_clzll(rm);
-        // sides present among the chips in reach (and the one before them, whose value enters the first difference): a pass
-        // away from the nav-bit boundary has one
+        // sides present among the chips in reach (and the one before them, whose value enters the first difference)
         const unsigned long long near = rm | (rm >> 1);
-        const unsigned long long s1m = __ballot(sd != 0) & near;
-        const int sideFirst = (s1m == near) ? 1 : 0, sideLast = (s1m != 0ull) ? 1 : 0;
-        for (int s = sideFirst; s <= sideLast; ++s) {
-            const float rs = (sd == s) ? r : 0.f;
-            const float rsPrev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x138, 0xf, 0xf, true));   // wave_shr:1 -> lane - 1
-            const float J = inReach ? rsPrev - rs : 0.f;
-            const unsigned long long bm = __ballot(J != 0.f);
-            const float rF = readlane_f(rs, firstIn - 1), rL = readlane_f(rs, lastIn);
-            const int nb = __builtin_popcountll(bm);
-            {
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-                if ((bm >> lane) & 1ull) sList[rank] = make_float2(J, __builtin_bit_cast(float, 8 * (e - eA)));
-                if (lane < DPE_C2_GB) sList[nb + lane] = make_float2(0.f, 0.f);
-                __builtin_amdgcn_wave_barrier();
+        const unsigned long long s1m = sideMask & near;
+        const int ofs8 = 8 * (e - eA);
+        if (kPure || s1m == 0ull || s1m == near) {
+            // one side (all passes but those about the nav-bit boundary or the window's ends): the flips are the chips in reach
+            // whose sign differs from the chip before -- a scalar mask; J = r_prev - r = -2 r there
+            if constexpr (!kPure) {
+                const int side = s1m != 0ull ? 1 : 0;
+                if (side != accSide) { spill(accSide); accSide = side; }
             }
-            f2 acc = f2{0.f, 0.f};
-            // (Measured in round 3 and dropped: an offsets-only list for passes with one side -- flips are +-2 and alternate --
-            // with two batches of reads in flight, offsets of batch b + 2 and prefix values of b + 1 issued before the adds of
-            // b: 0.578 against 0.565 ms per 128 windows at H, 0.571 with the compiler's own order.  The LDS array is 60 % busy;
-            // what a wave waits for is its queue, not one round trip.)
-            constexpr int GB = DPE_C2_GB;   // list entries per batch of independent LDS reads (8 / 12 / 16: 0.566 / 0.563 / 0.562 ms)
-            for (int i0 = 0; i0 < nb; i0 += GB) {
-                float2 ent[GB], qv[GB];
+            const unsigned long long bm = (rMask ^ (rMask << 1)) & rm;
+            const int nb = __builtin_popcountll(bm);
+            // list: the flips in pairs; with an odd count the last one stays out of it -- every group adds a quarter of its term
+            const bool odd = (nb & 1) != 0;
+            const int nbE = nb & ~1, lastFlip = 63 - __builtin_clzll(bm | 1ull);
+            const unsigned long long bmE = odd ? bm & ~(1ull << lastFlip) : bm;
+            const int nList = (nbE + k2Round - 1) & ~(k2Round - 1);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bmE >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bmE, 0));
+            if (lane < k2Round) sList[nbE + lane] = make_float2(0.f, 0.f);
+            if (__builtin_amdgcn_inverse_ballot_w64(bmE)) sList[rank] = make_float2(-2.f * r, __builtin_bit_cast(float, ofs8));
+            __builtin_amdgcn_wave_barrier();
+            // end terms: the centred prefix is -T/2 before the first and +T/2 behind the last boundary in reach
+            const float rEndsQ = 0.5f * (float)((int)((rMask >> (firstIn - 1)) & 1ull) + (int)((rMask >> lastIn) & 1ull) - 1);
+            f2 t0 = half * rEndsQ;
+            f2 t4[4] = {t0, t0, t0, t0};
+            if (odd) {
+                const float jq = ((rMask >> lastFlip) & 1ull) ? -0.5f : 0.5f;   // J / 4, J = -2 r
+                const char *q = reinterpret_cast<const char *>(sQ) + (qLaneBytes + __builtin_amdgcn_readlane(ofs8, lastFlip));
 #pragma unroll
-                for (int j = 0; j < GB; ++j) ent[j] = sList[i0 + j];
-                // (the barriers keep the batch's reads together: interleaved with the FMAs, one read in flight at a time, the
-                // kernel measured 0.678 instead of 0.567 ms per 128 windows at H -- the compiler chose that order once)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < GB; ++j)
-                    qv[j] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(sQ) + (qLaneBytes + __builtin_bit_cast(int, ent[j].y)));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < GB; ++j) {
-                    const f2 ej = f2{ent[j].x, ent[j].y}, qj = f2{qv[j].x, qv[j].y};
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(qj), "v"(ej));   // acc += q * J (J = low half of the entry)
+                for (int t = 0; t < 4; ++t) {
+                    const float2 v = *reinterpret_cast<const float2 *>(q + 128 * t);
+                    t4[t] = __builtin_elementwise_fma(f2{v.x, v.y}, f2{jq, jq}, t4[t]);
                 }
             }
-            __builtin_amdgcn_wave_barrier();   // the next side / pass rewrites the list
-            // end terms: the centred prefix is -T/2 before the first and +T/2 behind the last boundary in reach
-            const float rEnds = rF + rL;
-            acc = __builtin_elementwise_fma(half, f2{rEnds, rEnds}, acc);
-            accS[0] += s == 0 ? acc : f2{0.f, 0.f};
-            accS[1] += s == 1 ? acc : f2{0.f, 0.f};
+            gather(t4, nList);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += t4[t];
+            __builtin_amdgcn_wave_barrier();   // the next pass rewrites the list
+        } else {
+            for (int sI = 0; sI < 2; ++sI) {
+                if (sI != accSide) { spill(accSide); accSide = sI; }
+                const float rs = (sd1 == (sI == 1)) ? r : 0.f;   // the replica masked to this side (:352-367)
+                const float rsPrev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x138, 0xf, 0xf, true));   // wave_shr:1 -> lane - 1
+                const float J = inReach ? rsPrev - rs : 0.f;
+                const unsigned long long bm = __ballot(J != 0.f);
+                const float rF = readlane_f(rs, firstIn - 1), rL = readlane_f(rs, lastIn);
+                const int nb = __builtin_popcountll(bm);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+                if ((bm >> lane) & 1ull) sList[rank] = make_float2(J, __builtin_bit_cast(float, ofs8));
+                if (lane < k2Round) sList[nb + lane] = make_float2(0.f, 0.f);
+                __builtin_amdgcn_wave_barrier();
+                gather_pass((nb + k2Round - 1) & ~(k2Round - 1), half * (0.25f * (rF + rL)));
+                __builtin_amdgcn_wave_barrier();   // the next side / pass rewrites the list
+            }
         }
+        // (Measured in round 3 and dropped: an offsets-only list with two batches of reads in flight: 0.578 against 0.565 ms per
+        // 128 windows at H.  The LDS array is 60 % busy; what a wave waits for is its queue, not one round trip.)
         __builtin_amdgcn_wave_barrier();   // the next pass overwrites sQ
+    }
+    };   // passes
+    // side of a pure tile: chips below cB = the chip that starts at the nav-bit boundary lie before it (the host selects this
+    // kernel only when the boundary IS a chip boundary); the tile's lanes span the chips cLo - 3 .. cLo + k2Own (nPassT - 1) + 60
+    {
+        const int cFirst = cLo - k2Own0, cLast = cLo + k2Own * (nPassT - 1) + (63 - k2Own0);
+        const int cB = ch.hasFlip ? __builtin_amdgcn_readfirstlane(chip_at(ch.idxNext)) : 0;
+        const bool pure = !ch.hasFlip || (cFirst > c0 && cLast <= cEnd && (cB <= cFirst || cB > cLast));
+        if (pure) {
+            curSide = accSide = (ch.hasFlip && cB <= cFirst) ? 1 : 0;
+            passes(std::true_type{});
+        } else {
+            passes(std::false_type{});
+        }
     }
     flush(curSide);
     for (int side = 0; side < 2; ++side)   // a side without samples in this tile: zero block
         if (!((flushed >> side) & 1) && lane < kNMom) momOut[side * momSide + lane] = make_float2(0.f, 0.f);
-    // ---- block partial of the lag sums (one wave: nothing to reduce)
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        float2 *o = part + ((((size_t)w * K + k) * nBlk + blk) * 2 + side) * NL;
-        o[lane] = make_float2(accS[side].x, accS[side].y);
-        if (lane == 0) o[64] = make_float2(0.f, 0.f);
-    }
+    // ---- block partial of the lag sums: what is still in registers, then zeros for a side that never occurred
+    spill(accSide);
+    for (int side = 0; side < 2; ++side)
+        if (!((spilled >> side) & 1)) partOut[side * NL + lane] = make_float2(0.f, 0.f), partOut[side * NL + 64] = make_float2(0.f, 0.f);
 }
 
 }  // namespace dpe
