@@ -1413,9 +1413,9 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     int c2L1 = 0;
     for (int i = 0; chip2 && i < nWindows * nChan; ++i) {
         const BcsChanDev &d = h->chan_h[i];
-        const int l1 = (int)d.invStep;   // chips of l1 or l1 + 1 samples; instantiated for 24 (25 Msps) and 19 (20 Msps)
+        const int l1 = (int)d.invStep;   // chips of l1 or l1 + 1 samples; instantiated for every l1 in 16 .. 24 (16.4 .. 25.6 Msps)
         if (i == 0) c2L1 = l1;
-        if (l1 != c2L1 || (l1 != 24 && l1 != 19)) chip2 = false;
+        if (l1 != c2L1 || l1 < k2MinL1 || l1 > k2MaxL1) chip2 = false;
         if (d.hasFlip && (int)std::fma((double)d.idxNext, d.codeStep, d.rc) == (int)std::fma((double)(d.idxNext - 1), d.codeStep, d.rc)) chip2 = false;
         if (d.codeStep > stepMax) stepMax = d.codeStep;
     }
@@ -1629,8 +1629,12 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
 #define DPE_LAUNCH_CHIP2(NM, LV)                                                                                               \
     hipLaunchKernelGGL((bcs_bank_chip2_kernel<NM, LV>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
                        nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->chipBits_d, h->part_d, h->mom_d)
-        if (c2L1 == 24) { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, 24); else DPE_LAUNCH_CHIP2(6, 24); }
-        else { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, 19); else DPE_LAUNCH_CHIP2(6, 19); }
+#define DPE_LAUNCH_CHIP2_L(LV) case LV: if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, LV); else DPE_LAUNCH_CHIP2(6, LV); break
+        switch (c2L1) {
+            DPE_LAUNCH_CHIP2_L(16); DPE_LAUNCH_CHIP2_L(17); DPE_LAUNCH_CHIP2_L(18); DPE_LAUNCH_CHIP2_L(19); DPE_LAUNCH_CHIP2_L(20);
+            DPE_LAUNCH_CHIP2_L(21); DPE_LAUNCH_CHIP2_L(22); DPE_LAUNCH_CHIP2_L(23); DPE_LAUNCH_CHIP2_L(24);
+        }
+#undef DPE_LAUNCH_CHIP2_L
 #undef DPE_LAUNCH_CHIP2
     } else if (chip) {
         const dim3 cgrid(((nBlk * nWindows + 7) / 8) * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)

@@ -142,13 +142,18 @@ N_C2 = int(os.environ.get("DPE_FUZZ_CHIP2_CASES", "10"))
 
 @pytest.mark.parametrize("i", range(N_C2))
 def test_random_case_through_the_second_form(i):
-    """Seeded sweep aimed at bcs_bank_chip2_kernel: 20 / 25 Msps (19.5 / 24.4 samples per chip), window lengths that are
+    """Seeded sweep aimed at bcs_bank_chip2_kernel: 20 / 25 Msps (19.5 / 24.4 samples per chip) and, every other case, one of the
+    integer-nanosecond rates that give 16 ... 23 samples per chip (the kernel is instantiated for every chip length 16 ... 24;
+    front ends at 16.368 / 20.46 / 24.552 Msps have non-integer-ns periods, i.e. the reference's ns-rounded time table, and
+    stay on the per-sample kernels), window lengths that are
     multiples of nothing (so the clipped first and last chips, the circular wrap inside the margins and partial last
     passes of a tile all vary), 1 ... 12 SVs, 1 ... 3 windows, nav-bit boundary anywhere, lag windows 17 ... 31.  Banks of
     the second form, of the first form and of the per-sample kernels against the oracle; the second form must be the one
     that ran."""
     rng = np.random.Generator(np.random.PCG64(424243 + i))
     fs = float(rng.choice([20e6, 25e6]))
+    if i % 2 == 1:   # sampling periods of 61, 58, 56, 53, 48, 46, 44, 42, 41 ns: floor(fs / fc) = 16, 16, 17, 18, 20, 21, 22, 23, 23
+        fs = 1e9 / float(rng.choice([61, 58, 56, 53, 48, 46, 44, 42, 41]))
     S = 2 * int(rng.integers(3000, 90001))
     K = int(rng.choice([1, 2, 3, 5, 8, 12]))
     W = int(rng.choice([1, 1, 2, 3]))

@@ -938,18 +938,22 @@ def test_reference_maximum_grid_size():
         assert sc[best] >= want.max() * (1 - TOL)
 
 
-@pytest.mark.parametrize("name,W,probe", [("R", 256, (0, 100, 255)), ("H", 32, (0, 31))])
+@pytest.mark.parametrize("name,W,probe", [("R", 256, (0, 100, 255)), ("H", 128, (0, 5, 127))])
 def test_bench_configurations_against_the_oracle(oracle, name, W, probe):
     """The exact configurations bench.py times.  R: S = 50000, 8 SVs, two 390625-point rngrid3-format grids, 256 windows per
     call, banks L = 4 / B = 20 (the 16-samples-per-lane bank kernel, the fat finalize shape, the batch scan).  H (--config H):
-    25 Msps, S = 500000, 12 SVs, 1e5-point grids, 32 windows, L = 31 (boundary-difference bank kernel).  Banks and every 97th
+    25 Msps, S = 500000, 12 SVs, 1e5-point grids, 128 windows per call -- 8 distinct ones repeated with their channel state, as
+    bench.py builds them -- L = 31 (bcs_bank_chip2_kernel: its tile length follows from the batch size).  Banks and every 97th
     score of a few windows against the oracle, and for ALL windows the reported arg-max against the first maximum of the
     scores the scan wrote."""
     import torch
     o = oracle
     cfg = dpe.workload.CONFIG_R if name == "R" else dpe.workload.CONFIG_H
     fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
-    iq, cs, ce, bw = dpe.workload.build_windows(W, fs, S, K, seed=0, amp=cfg["amp"])
+    distinct = W if name != "H" else 8
+    iq, cs, ce, bw = dpe.workload.build_windows(distinct, fs, S, K, seed=0, amp=cfg["amp"])
+    if distinct < W:
+        iq, cs, ce, bw = (np.concatenate([a] * (W // distinct))[:W] for a in (iq, cs, ce, bw))
     _, _, pos, vel, _ = dpe.workload.build_grids(G)
     bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K)
     bcs.Start()
@@ -961,7 +965,9 @@ def test_bench_configurations_against_the_oracle(oracle, name, W, probe):
     res = bcm.results()
     code, carr = bcs.read_banks()
     ps, vs = bcm.read_scores()
+    kernel = bcs.stage1_kernel
     bcm.Stop(); bcs.Stop()
+    assert kernel == ("bcs_bank16_kernel" if name == "R" else "bcs_bank_chip2_kernel")
     C = dpe.engine.carr_fft_len(S)
     for w in range(W):
         assert res[w]["posOutOfWindow"] == 0 and res[w]["velOutOfWindow"] == 0
