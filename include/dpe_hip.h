@@ -36,7 +36,8 @@ extern "C" {
  * DPE_BCS_FAT, DPE_BCM_SPLIT) exist only in builds with -DDPE_EXPERIMENTS. */
 #define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
 #define DPE_MAX_LAG_HALF_WIDTH 292  /* widest code-lag bank of the windowed stage-1 kernels: +-32 and four 65-lag chunks per side */
-#define DPE_ABI_VERSION 2   /* 2: dpe_bcm_config.referencePair, pitched score rows, sizes in dpe_bcm_results_from_keys, *_update_dev */
+#define DPE_ABI_VERSION 3   /* 2: dpe_bcm_config.referencePair, pitched score rows, sizes in dpe_bcm_results_from_keys, *_update_dev;
+                             * 3: the dpe_chm_dev_ family -- device-resident cuChanMgr + measurement hand-over -- and the _update_prepared forms */
 
 typedef void *dpe_stream_t;        /* hipStream_t (reference: cudaStream_t* flow stream, module.h:23) */
 typedef struct dpe_bcs dpe_bcs;    /* opaque: one BatchCorrScores instance */
@@ -334,6 +335,60 @@ int dpe_chm_update(dpe_chanmgr *h, const double *xk1k1, const double *xkk1, cons
 int dpe_chm_outputs(dpe_chanmgr *h, dpe_chan_start *start, dpe_chan_end *end, dpe_bcm_window *win,
                     double *batchSatStates);
 
+/* ------------------------------------------------------------------ cuChanMgr on the device ------ */
+/* The reference's form of the module: state and output ports live in DEVICE memory and one small kernel per window advances
+ * them (cuchanmgr.cu:1100-1132 Start, :1237-1264 Update -- CHM_ComputeSatStates / PropagateChannels / TimeUpdateChannels /
+ * GridPrep :240-306,338-608,641-829,853-923).  Same arithmetic as dpe_chm_* (the two forms share their functions), with one
+ * restructuring: the Kepler evaluations (:85-210) run AHEAD of the window on a side stream -- satellite state and its time
+ * derivative at the nominal transmit time -- and the per-window kernel advances them over the <= 1e-6 s that the new fix moves
+ * the transmit time (remainder 3e-11 m; beyond 1e-5 s it evaluates directly and sets status bit 1).
+ *
+ * Attached to a single-window BatchCorrScores / BatchCorrManifold pair (dpe_chm_dev_attach) the same kernel also
+ *   - forms the measurement from the scan's arg-max keys on the device (BCM_MakePosMeas / MakeVelMeas, batchcorrmanifold.cu:
+ *     1977-2068) and passes it through to both state ports (EKF_PassMeas, cuekf.cu:147-159; EnableEKF = false, as shipped),
+ *   - writes the channel-parameter blocks of the two handles for the NEXT window (what dpe_bcs_update_dev / dpe_bcm_update_dev
+ *     derive with a prep kernel each), so that a closed loop is, per window,
+ *         dpe_bcs_update_prepared -> dpe_bcm_update_prepared -> dpe_chm_dev_step        (four kernels, nothing read back)
+ *   - and leaves the fix in a pinned ring that the host polls (dpe_chm_dev_fix) while later windows are already enqueued. */
+typedef struct dpe_chm_dev dpe_chm_dev;
+typedef struct dpe_fix_record {
+    uint64_t seq;               /* window index + 1, written last (0: never written) */
+    double zVal[8];             /* the window's measurement = xCurrk1k1 = xCurrkk1 of the pass-through filter */
+    double rxTime;              /* receiver time at the END of the window the fix belongs to */
+    int64_t posIndex, velIndex; /* global grid indices of the ML points */
+    int64_t posOutOfWindow, velOutOfWindow;
+    float posScore, velScore;
+    int32_t status;             /* sticky bits: 1 Kepler iteration failed, 2 a transmit time left the expansion's range (evaluated
+                                 * directly), 4 an arg-max key was 0 / outside the grid (state held for that window) */
+    int32_t reserved;
+} dpe_fix_record;
+int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans, const double *timeGrid_host, int32_t dimT,
+                       dpe_chm_dev **out);
+int dpe_chm_dev_destroy(dpe_chm_dev *h);
+/* Before Start: bcs / bcm (either may be NULL) get their parameter blocks from this channel manager; with bcm a ring of
+ * fixRingDepth fixes is set up and dpe_chm_dev_step becomes available. */
+int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRingDepth);
+/* The device port arrays, in the structs dpe_bcs_update_dev / dpe_bcm_update_dev take, plus rxTime and the two state ports
+ * (any pointer may be NULL): what dpeflow.cpp:169-191,212 connects. */
+int dpe_chm_dev_ports(dpe_chm_dev *h, dpe_bcs_ports_dev *bcs, dpe_bcm_ports_dev *bcm, const double **rxTime_dev,
+                      double **xk1k1_dev, double **xkk1_dev, const double **zVal_dev);
+int dpe_chm_dev_start(dpe_chm_dev *h, const double *x0_host /* InitX [8] */, dpe_stream_t stream);   /* ::Start :1100-1132 */
+/* ::Update :1237-1264 with the two state inputs as device arrays (inputs 10 and 12; a host that keeps the reference's cuEKF). */
+int dpe_chm_dev_update(dpe_chm_dev *h, const double *xk1k1_dev, const double *xkk1_dev, dpe_stream_t stream);
+/* Attached form: measurement from the keys of the attached BatchCorrManifold's LAST Update, pass-through, ::Update, parameter
+ * blocks of the next window, fix -> ring.  Asynchronous; never waits. */
+int dpe_chm_dev_step(dpe_chm_dev *h, dpe_stream_t stream);
+/* Fix of window `window` (0 = the first dpe_chm_dev_step).  timeoutMicros < 0: wait; otherwise returns 1 when the fix has not
+ * arrived within that time (0 = just look).  -1: never enqueued, or already overwritten (the host fell fixRingDepth behind). */
+int dpe_chm_dev_fix(dpe_chm_dev *h, int64_t window, dpe_fix_record *out, int32_t timeoutMicros);
+/* Diagnostics / tests: the state in the form of dpe_chm_outputs (synchronises `stream`). */
+int dpe_chm_dev_read(dpe_chm_dev *h, dpe_chan_start *start, dpe_chan_end *end, dpe_bcm_window *win, double *batchSatStates,
+                     int32_t *status, dpe_stream_t stream);
+/* One window whose channel-parameter block is already on the device, written by an attached device-resident channel manager (no prep kernel, no host
+ * work on the values).  As the *_update_dev forms otherwise. */
+int dpe_bcs_update_prepared(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, dpe_stream_t stream);
+int dpe_bcm_update_prepared(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nChan, dpe_stream_t stream);
+
 /* ------------------------------------------------------------------ cuEKF ---- */
 /* The EnableEKF=true path of dsp::cuEKF (cudarecv/modules/src/cuekf.cu): 8-state Kalman filter, host fp64.
  * The shipped flow disables it (dpeflow.cpp:90) and passes zVal through (EKF_PassMeas :147-159).
@@ -356,7 +411,8 @@ int dpe_ekf_state(dpe_ekf *h, double *xk1k1, double *xkk1, double *Pk1k1, double
 /* Cold-start coarse acquisition.  Only the reference's Python twin implements it:
  * Correlator.coarse_acquisition, pygnss/pythonreceiver/scalar/correlator.py:53-103 (CUDARecv only
  * forward-declares the classes, cudarecv/dsp/inc/dsp.h:207-209).  Full code-delay x Doppler search
- * with batched FFTs (rocFFT through hipFFT). */
+ * with batched FFTs (rocFFT, called directly: csrc/dpe_fft.h) and, for the coherent / textbook searches at 2 500 delays, a fused
+ * hand-written transform kernel. */
 typedef struct dpe_acq dpe_acq;
 typedef struct dpe_acq_config {
     int32_t samplesPerWindow;   /* S = round(T fs), e.g. 25000 for 10 ms at 2.5 Msps (rawfile.py:162) */
@@ -414,7 +470,8 @@ int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count);
 /* enable = 1: events around every kernel; enable = 2 * m: only around the slots of bit mask m (e.g. 4 = the bank kernel
  * alone -- bench.py times just the dominant kernel inside its timed region). */
 /* Name of the stage-1 kernel the last Update launched ("bcs_bank_kernel", "bcs_bank16_kernel", "bcs_bank_wide_kernel",
- * "bcs_bank_chip_kernel"): which of the forms of DESIGN.md 2.2 the shape selected. */
+ * "bcs_bank_chip_kernel", "bcs_bank_chip2_kernel", or the rocFFT full-lag path): which of the forms of DESIGN.md 2.2 the
+ * shape selected. */
 const char *dpe_bcs_stage1_kernel(dpe_bcs *h);
 int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count);
 

@@ -20,18 +20,9 @@
 #include <atomic>
 
 #include "dpe_common.h"
+#include "dpe_prep.h"
 
 namespace dpe {
-
-struct BcmSvDev {
-    float ue, un, uu;  // unit line of sight (receiver -> SV) in the ENU frame of the grid
-    float g;           // bank entries per metre of (delta_t + d_rho)   [vel: -(entries per m/s)]
-    float h;           // position manifold: 1 / (2 range)
-    float idx0;        // bank-relative fractional index at the grid centre
-    float pad0, pad1;
-    // velocity manifold (no second-order term): {h, pad0, pad1} = g {ue, un, uu}, so that the index is four chained FMAs
-    // idx0 + g dt - (g ue) dx - (g un) dy - (g uu) dz instead of dot product, difference, scale
-};
 
 // Single-window calls pass both manifolds' coefficients in the kernel-argument segment of the scan
 // kernels (params_ptr, dpe_common.h); pb must stay their FIRST argument.
@@ -397,72 +388,35 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
 // on the device (cuChanMgr / cuEKF outputs, dpeflow.cpp:178-191,212; captured once by the reference at
 // batchcorrmanifold.cu:2512-2540) -- what the host loop of dpe_bcm_update computes, in fp64.  The host form carries the centre
 // index in long double because rxTime - pr / C (rxTime ~ 4e5 s) rounds at 5.8e-11 s in fp64; here the same difference is kept
-// as an unevaluated sum (TwoSum), which is more than the 64-bit significand gives.  One block, thread <-> channel; thread 0
-// also leaves the window's frame (xCurrkk1, ENU2ECEFMat, DopplerSign) in pinned host memory for dpe_bcm_results.
+// as an unevaluated sum (TwoSum, bcm_prep_one in dpe_prep.h).  One block, thread <-> channel; thread 0 also leaves the window's
+// frame (xCurrkk1, ENU2ECEFMat, DopplerSign) in pinned host memory for dpe_bcm_results.  rxTimeDev != nullptr: the receive
+// time is read from the device (a channel manager that lives there), else it is the host scalar of the reference (:2536-2537).
 struct BcmPortsDev {
     const double *x, *R, *sat, *rcEnd, *fc, *fi;
     const int *cpRefTOW, *cpElaEnd, *cpRef, *dopplerSign;
     int dimT;
 };
-struct BcmDevWin {   // pinned mirror of the window inputs of a device-parameter Update
-    double xCurrkk1[8], enu2ecef[9];
-    int dopplerSign, bad;
-};
-#pragma clang fp contract(off)
-__global__ void bcm_prep_kernel(BcmPortsDev p, int K, double rxTime, double fs, double Cf, int S, int L, int B, long long C,
-                                BcmSvDev *__restrict__ svPos, BcmSvDev *__restrict__ svVel, BcmDevWin *__restrict__ hostWin)
+__global__ void bcm_prep_kernel(BcmPortsDev p, int K, double rxTime, const double *__restrict__ rxTimeDev, double fs, double Cf, int S, int L, int B,
+                                long long C, BcmSvDev *__restrict__ svPos, BcmSvDev *__restrict__ svVel, BcmDevWin *__restrict__ hostWin)
 {
     const int k = threadIdx.x;
     const double *c = p.x, *R = p.R;
-    const int ds = p.dopplerSign[0];
+    const int dsRaw = p.dopplerSign[0];
+    const int ds = (dsRaw == 1 || dsRaw == -1) ? dsRaw : 1;   // (a bad value is flagged; the scan must stay finite)
+    if (rxTimeDev) rxTime = *rxTimeDev;
     if (k == 0) {
         for (int i = 0; i < 8; ++i) hostWin->xCurrkk1[i] = c[i];
         for (int i = 0; i < 9; ++i) hostWin->enu2ecef[i] = R[i];
         hostWin->dopplerSign = ds;
-        hostWin->bad = (ds == 1 || ds == -1) ? 0 : 1;
+        hostWin->bad = (dsRaw == 1 || dsRaw == -1) ? 0 : 1;
     }
     if (k >= K) return;
     const double *s = p.sat + ((size_t)k * p.dimT + p.dimT / 2) * 8;                      // mid-time entry, :1775
-    const double dx = s[0] - c[0], dy = s[1] - c[1], dz = s[2] - c[2];                    // :1779-1781
-    const double range = sqrt(dx * dx + dy * dy + dz * dz);                               // :1782
-    const double ux = dx / range, uy = dy / range, uz = dz / range;
-    const double ue = R[0] * ux + R[3] * uy + R[6] * uz;                                  // R^T u
-    const double un = R[1] * ux + R[4] * uy + R[7] * uz;
-    const double uu = R[2] * ux + R[5] * uy + R[8] * uz;
-    // position manifold, centre index (:1783-1791)
-    const double pr = range - kC * s[3] + c[3];
-    const double t = pr / kC;
-    const double hi = rxTime - t, bb = hi - rxTime;
-    double lo = (rxTime - (hi - bb)) + (-t - bb);                                         // rxTime - t = hi + lo exactly
-    const double d1 = hi - (double)p.cpRefTOW[k];                                         // exact: both are multiples of ulp(rxTime)
-    const double n = (double)(p.cpElaEnd[k] - p.cpRef[k]);
-    const double pn = n * kTCA;
-    lo -= fma(n, kTCA, -pn);                                                              // the product's own rounding
-    const double cfd = (d1 - pn) + lo;
-    const double fck = p.fc[k];
-    const double rc0 = cfd * kFCA - p.rcEnd[k];
-    const double basePos = (fs / fck) * (-rc0) + (double)S / 2.0;
-    BcmSvDev a;
-    a.ue = (float)ue; a.un = (float)un; a.uu = (float)uu;
-    a.g = (float)(fs * kFCA / (fck * kC));
-    a.h = (float)(0.5 / range);
-    a.idx0 = (float)(basePos - (double)(S / 2 - L));
-    a.pad0 = a.pad1 = 0.f;
+    BcmSvDev a, v;
+    bcm_prep_one(c, R, s, p.rcEnd[k], p.fc[k], p.fi[k], p.cpRefTOW[k], p.cpElaEnd[k], p.cpRef[k], ds, rxTime, fs, Cf, S, L, B, C, a, v);
     svPos[k] = a;
-    // velocity manifold, centre index (:1917-1936)
-    const double ex = c[4] - kOEDot * c[1], ey = c[5] + kOEDot * c[0], ez = c[6];
-    const double lrr = ux * (ex - s[4]) + uy * (ey - s[5]) + uz * (ez - s[6]);
-    const double fbc = kFL1 * ((lrr - c[7]) / kC + s[7]) / ds;
-    const double baseVel = (Cf / fs) * (fbc - p.fi[k]) + Cf / 2.0;
-    const double gv = (Cf / fs) * kFL1 / (kC * ds);
-    BcmSvDev v;
-    v.ue = (float)ue; v.un = (float)un; v.uu = (float)uu;
-    v.g = (float)(-gv);
-    v.idx0 = (float)(baseVel - (double)(C / 2 - B));
-    v.h = (float)(-gv * ue); v.pad0 = (float)(-gv * un); v.pad1 = (float)(-gv * uu);
     svVel[k] = v;
 }
-#pragma clang fp contract(fast)
 
 // PosScores in the reference's port type: one dense fp64 row (ConfigOutput(3, "PosScores", DOUBLE_t, GRID, ...), :2300)
 __global__ void bcm_export_f64_kernel(const float *__restrict__ row, long long G, double *__restrict__ out)
@@ -538,6 +492,7 @@ struct dpe_bcm {
     dpe_bcm_config cfg;
     std::vector<double> posGrid_h, velGrid_h;  // local shard, fp64 (for zVal)
     float4 *posGrid_d = nullptr, *velGrid_d = nullptr;
+    double *posGrid64_d = nullptr, *velGrid64_d = nullptr;   // fp64 copies for a measurement formed on the device (dpe_bcm_hook_get)
     float *posScores_d = nullptr, *velScores_d = nullptr;
     long long posPitch = 0, velPitch = 0;   // floats between the score rows of consecutive windows (grid size rounded up to 32)
     dpe::BcmSvDev *sv_d = nullptr;  // [2][W][maxK]  (manifold-major)
@@ -941,7 +896,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
 int dpe_bcm_destroy(dpe_bcm *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d, h->done_d};
+    void *bufs[] = {h->posGrid64_d, h->velGrid64_d, h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d, h->done_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->svBase_h) (void)hipHostFree(h->svBase_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
@@ -1121,10 +1076,46 @@ int dpe_bcm_update_dev(dpe_bcm *h, const float *codeBank_dev, const float *carrB
     const BcmPortsDev p = {ports->xCurrkk1, ports->enu2ecef, ports->satStates, ports->codePhaseEnd, ports->codeFrequency, ports->carrierFrequency,
                            ports->cpRefTOW, ports->cpElapsedEnd, ports->cpRef, ports->dopplerSign, ports->dimT};
     const size_t W = h->cfg.maxWindows, maxK = h->cfg.maxChannels;
-    hipLaunchKernelGGL(bcm_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, rxTime, h->cfg.samplingFrequency,
+    hipLaunchKernelGGL(bcm_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, rxTime, (const double *)nullptr, h->cfg.samplingFrequency,
                        (double)h->cfg.numFFTPoints, h->cfg.samplesPerWindow, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, (long long)h->cfg.numFFTPoints,
                        h->sv_d, h->sv_d + W * maxK, h->devWin_hd);
     return bcm_update_impl(h, codeBank_dev, carrBank_dev, 1, nChan, nullptr, nullptr, stream);
+}
+
+int dpe_bcm_update_prepared(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_dev, int32_t nChan, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h, "[BatchCorrManifold] Update: null argument");
+    DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrManifold] Update: nChan %d out of range", nChan);
+    DPE_REQUIRE(!h->refPair, "[BatchCorrManifold] Update: referencePair re-evaluates points on the host and needs the host form of the inputs");
+    return bcm_update_impl(h, codeBank_dev, carrBank_dev, 1, nChan, nullptr, nullptr, stream);
+}
+
+int dpe_bcm_hook_get(dpe_bcm *h, dpe_bcm_hook *out)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && out, "[BatchCorrManifold] hook: null argument");
+    const size_t W = h->cfg.maxWindows, maxK = h->cfg.maxChannels;
+    if (!h->posGrid64_d) {
+        h->posGrid64_d = dev_alloc<double>(h->posGrid_h.size());
+        h->velGrid64_d = dev_alloc<double>(h->velGrid_h.size());
+        DPE_REQUIRE(h->posGrid64_d && h->velGrid64_d, "[BatchCorrManifold] hook: fp64 grid allocation failed");
+        DPE_CHECK_HIP(hipMemcpy(h->posGrid64_d, h->posGrid_h.data(), sizeof(double) * h->posGrid_h.size(), hipMemcpyHostToDevice));
+        DPE_CHECK_HIP(hipMemcpy(h->velGrid64_d, h->velGrid_h.data(), sizeof(double) * h->velGrid_h.size(), hipMemcpyHostToDevice));
+    }
+    out->svPos_d = h->sv_d;
+    out->svVel_d = h->sv_d + W * maxK;
+    out->devWin_hd = h->devWin_hd;
+    out->keys_d[0] = h->keys_d;
+    out->keys_d[1] = h->keys_d + 4 * W;
+    out->posGrid64_d = h->posGrid64_d;
+    out->velGrid64_d = h->velGrid64_d;
+    out->posG = h->cfg.posGridSize; out->velG = h->cfg.velGridSize;
+    out->posOffset = h->cfg.posGridIndexOffset; out->velOffset = h->cfg.velGridIndexOffset;
+    out->fs = h->cfg.samplingFrequency; out->Cf = (double)h->cfg.numFFTPoints;
+    out->S = h->cfg.samplesPerWindow; out->L = h->cfg.lagHalfWidth; out->B = h->cfg.binHalfWidth;
+    out->maxWindows = h->cfg.maxWindows; out->maxChannels = h->cfg.maxChannels;
+    out->C = h->cfg.numFFTPoints;
+    return 0;
 }
 
 int dpe_bcm_set_graph(dpe_bcm *h, int32_t enable)

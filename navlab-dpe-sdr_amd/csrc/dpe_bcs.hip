@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "dpe_common.h"
+#include "dpe_prep.h"
 
 namespace dpe {
 
@@ -48,21 +49,6 @@ __device__ __forceinline__ f2 wipe_seed(float f)
     asm volatile("s_nop 1" : "+v"(w));   // covers the trans -> VALU forwarding hazard for the asm consumers
     return w;
 }
-
-struct BcsChanDev {
-    double rc;        // code phase at sample 0 (chips)
-    double codeStep;  // chips per sample  = fc / fs
-    double ri;        // carrier phase at sample 0 (cycles)
-    double carrStep;  // cycles per sample = fi / fs
-    float rotRe, rotIm;  // exp(-j 2 pi carrStep)
-    int32_t idxNext;  // BCS_NavBitBoundary
-    int32_t hasFlip;  // 0 < idxNext < S
-    int32_t prn;
-    int32_t pad;
-    double fc, fi;    // raw code / carrier frequency (time-table mode)
-    double invStep;   // samples per chip = fs / fc (chip-boundary kernel)
-};
-static_assert(sizeof(BcsChanDev) % 16 == 0, "the parameter upload copies 16-byte words");
 
 // Time of sample n: n/fs, or (TABLE) the reference's ns-rounded table (BCS_GenTimeIdcs,
 // batchcorrscores.cu:185-196) when the sampling period is not an integer number of nanoseconds.
@@ -1054,44 +1040,24 @@ __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finali
 
 // Device-resident channel parameters (dpe_bcs_update_dev): what the host loop of dpe_bcs_update computes per channel, from
 // the reference's own port arrays on the device (cuChanMgr's outputs, dpeflow.cpp:169-176; captured once by the reference at
-// batchcorrscores.cu:991-1004).  One block; fp64 throughout, expression for expression the host form.  status: bit 0 = a PRN
-// outside 1..37 (clamped so that the kernels stay inside the chip table), bit 1 = a non-positive code frequency / negative phase.
+// batchcorrscores.cu:991-1004).  One block; fp64 throughout, expression for expression the host form (bcs_prep_one, dpe_prep.h).
+// status: bit 0 = a PRN outside 1..37 (clamped so that the kernels stay inside the chip table), bit 1 = a non-positive code
+// frequency / negative code phase (nominal values substituted: the kernels index the chip table with them).
 struct BcsPortsDev {
     const double *rc, *ri, *fc, *fi;
     const int *cpEla, *cpRef;
     const unsigned char *prn;
 };
-#pragma clang fp contract(off)
 __global__ void bcs_prep_kernel(BcsPortsDev p, int K, double fs, int S, BcsChanDev *__restrict__ out, int *__restrict__ status)
 {
     const int k = threadIdx.x;
     if (k == 0) *status = 0;
     __syncthreads();
     if (k >= K) return;
-    BcsChanDev d;
-    int bad = 0, prn = p.prn[k];
-    if (prn < 1 || prn > kPrnMax) { bad |= 1; prn = prn < 1 ? 1 : kPrnMax; }
-    const double fc = p.fc[k], rc = p.rc[k];
-    if (!(fc > 0.0) || !(rc >= 0.0)) bad |= 2;
-    d.rc = rc;
-    d.codeStep = fc / fs;
-    d.ri = p.ri[k];
-    d.carrStep = p.fi[k] / fs;
-    d.fc = fc;
-    d.fi = p.fi[k];
-    d.invStep = fs / fc;
-    const double ang = -6.283185307179586476925286766559 * d.carrStep;
-    d.rotRe = (float)cos(ang);
-    d.rotIm = (float)sin(ang);
-    const int since = (((p.cpEla[k] - p.cpRef[k]) % 20) + 20) % 20;                       // BCS_NavBitBoundary :247-253
-    d.idxNext = (int)(floor((kLCA * (20 - since) - rc) * (fs / fc)) + 1);
-    d.hasFlip = (d.idxNext > 0 && d.idxNext < S) ? 1 : 0;
-    d.prn = prn;
-    d.pad = 0;
-    out[k] = d;
+    int bad;
+    out[k] = bcs_prep_one(p.rc[k], p.ri[k], p.fc[k], p.fi[k], p.cpEla[k], p.cpRef[k], (int)p.prn[k], fs, S, bad);
     if (bad) atomicOr(status, bad);
 }
-#pragma clang fp contract(fast)
 
 // Dense export in the reference layout (complex128, fft-shifted rows), zero outside the banks.
 __global__ void bcs_export_kernel(const float2 *__restrict__ bank, int n, long long rowLen, long long centre, int K,
@@ -1719,6 +1685,24 @@ int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, co
     hipLaunchKernelGGL(bcs_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, h->cfg.samplingFrequency,
                        h->cfg.samplesPerWindow, h->chan_d, h->status_d);
     return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
+}
+
+int dpe_bcs_update_prepared(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, dpe_stream_t stream)
+{
+    DPE_REQUIRE(h && samples_dev, "[BatchCorrScores] Update: null argument");
+    DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrScores] Update: nChan %d out of range", nChan);
+    return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
+}
+
+int dpe_bcs_hook_get(dpe_bcs *h, dpe_bcs_hook *out)
+{
+    DPE_REQUIRE(h && out, "[BatchCorrScores] hook: null argument");
+    out->chan_d = h->chan_d;
+    out->status_d = h->status_d;
+    out->fs = h->cfg.samplingFrequency;
+    out->S = h->cfg.samplesPerWindow;
+    out->maxChannels = h->cfg.maxChannels;
+    return 0;
 }
 
 int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream)

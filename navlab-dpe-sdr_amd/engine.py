@@ -30,6 +30,8 @@ EXPORTS = [
     "dpe_set_device", "dpe_comm_create", "dpe_comm_wrap_nccl", "dpe_comm_destroy", "dpe_comm_rank", "dpe_comm_allreduce_max_u64",
     "dpe_comm_allgather", "dpe_bcm_exchange_keys", "dpe_bcs_allgather_banks",
     "dpe_bcs_update_dev", "dpe_bcs_dev_status", "dpe_bcm_update_dev", "dpe_bcm_export_scores_f64",
+    "dpe_chm_dev_create", "dpe_chm_dev_destroy", "dpe_chm_dev_attach", "dpe_chm_dev_ports", "dpe_chm_dev_start", "dpe_chm_dev_update",
+    "dpe_chm_dev_step", "dpe_chm_dev_fix", "dpe_chm_dev_read", "dpe_bcs_update_prepared", "dpe_bcm_update_prepared",
 ]
 
 
@@ -273,6 +275,12 @@ class BatchCorrScores:
         self._W, self._K = 1, int(n_chan)
         return 0
 
+    def UpdatePrepared(self, Samples, n_chan, stream=None):
+        """One window whose channel block an attached ChanMgrDev has already written on the device."""
+        _check(lib().dpe_bcs_update_prepared(self._h, _ptr(Samples), C.c_int32(n_chan), _stream(stream)))
+        self._W, self._K = 1, int(n_chan)
+        return 0
+
     def dev_status(self, stream=None):
         st = C.c_int32()
         _check(lib().dpe_bcs_dev_status(self._h, C.byref(st), _stream(stream)))
@@ -434,6 +442,12 @@ class BatchCorrManifold:
         self.Keys = keys.value
         return 0
 
+    def UpdatePrepared(self, CodeScores, CarrScores, n_chan, stream=None):
+        """One window whose coefficient blocks an attached ChanMgrDev has already written on the device."""
+        _check(lib().dpe_bcm_update_prepared(self._h, _ptr(CodeScores), _ptr(CarrScores), C.c_int32(n_chan), _stream(stream)))
+        self._W = 1
+        return 0
+
     def results(self, stream=None):
         res = (BcmResult * self._W)()
         _check(lib().dpe_bcm_results(self._h, res, _stream(stream)))
@@ -559,6 +573,95 @@ class ChanMgr:
 
     def __del__(self):
         try:            # at interpreter shutdown module globals may already be gone
+            self.Stop()
+        except Exception:
+            pass
+
+
+class FixRecord(C.Structure):     # dpe_fix_record
+    _fields_ = [("seq", C.c_uint64), ("zVal", C.c_double * 8), ("rxTime", C.c_double), ("posIndex", C.c_int64), ("velIndex", C.c_int64),
+                ("posOutOfWindow", C.c_int64), ("velOutOfWindow", C.c_int64), ("posScore", C.c_float), ("velScore", C.c_float),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ChanMgrDev:
+    """Module "cuChanMgr" as the reference has it: state and port arrays in DEVICE memory, one small kernel per window
+    (dpe_chm_dev_*; cuchanmgr.cu:1100-1132,1237-1264).  attach(bcs, bcm) makes it write their parameter blocks and form the
+    measurement from the scan's keys: the closed loop is then bcs.UpdatePrepared -> bcm.UpdatePrepared -> step()."""
+
+    def __init__(self, prn, rc, ri, fc, fi, cp, cp_ref, cp_ref_tow, eph, rx_time, T, time_grid=(0.0,), DopplerSign=1):
+        K = len(prn)
+        init = np.zeros(K, dtype=CHM_INIT_DTYPE)
+        init["prn"], init["cpElapsed"], init["cpReference"], init["cpRefTOW"] = prn, cp, cp_ref, cp_ref_tow
+        init["codePhase"], init["carrierPhase"], init["codeFrequency"], init["carrierFrequency"] = rc, ri, fc, fi
+        init["eph"] = eph
+        self.K = K
+        tg = np.ascontiguousarray(time_grid, dtype=np.float64)
+        self._dimT = tg.size
+        self._h = C.c_void_p(None)
+        cfg = ChmConfig(K, int(DopplerSign), float(T), float(rx_time))
+        _check(lib().dpe_chm_dev_create(C.byref(cfg), init.ctypes.data_as(C.c_void_p), tg.ctypes.data_as(C.c_void_p),
+                                        C.c_int32(tg.size), C.byref(self._h)))
+
+    @classmethod
+    def from_handoff(cls, ho, T, K=None, time_grid=(0.0,)):
+        sl = slice(0, K)
+        return cls(ho["prn_list"][sl], ho["rc"][sl], ho["ri"][sl], ho["fc"][sl], ho["fi"][sl], ho["cp"][sl],
+                   ho["cp_timestamp"][sl], ho["TOW"][sl], ho["eph"][sl], ho["rxTime"], T, time_grid)
+
+    def attach(self, bcs=None, bcm=None, ring_depth=64):
+        _check(lib().dpe_chm_dev_attach(self._h, bcs._h if bcs is not None else None, bcm._h if bcm is not None else None,
+                                        C.c_int32(ring_depth)))
+
+    def ports(self):
+        """-> (BcsPortsDev, BcmPortsDev, rxTime_dev, xk1k1_dev, xkk1_dev, zVal_dev): raw device pointers."""
+        b, m = BcsPortsDev(), BcmPortsDev()
+        rx, x1, xk, z = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().dpe_chm_dev_ports(self._h, C.byref(b), C.byref(m), C.byref(rx), C.byref(x1), C.byref(xk), C.byref(z)))
+        return b, m, rx.value, x1.value, xk.value, z.value
+
+    def Start(self, x0, stream=None):
+        a = np.ascontiguousarray(x0, dtype=np.float64)
+        _check(lib().dpe_chm_dev_start(self._h, a.ctypes.data_as(C.c_void_p), _stream(stream)))
+        return 0
+
+    def Update(self, x_k1k1_dev, x_kk1_dev, stream=None):
+        _check(lib().dpe_chm_dev_update(self._h, _ptr(x_k1k1_dev), _ptr(x_kk1_dev), _stream(stream)))
+        return 0
+
+    def step(self, stream=None):
+        _check(lib().dpe_chm_dev_step(self._h, _stream(stream)))
+        return 0
+
+    def fix(self, window, timeout_us=-1):
+        """-> dict of the window's fix, or None when it has not arrived within timeout_us (>= 0)."""
+        r = FixRecord()
+        rc = lib().dpe_chm_dev_fix(self._h, C.c_int64(window), C.byref(r), C.c_int32(timeout_us))
+        if rc == 1:
+            return None
+        _check(rc)
+        return dict(zVal=np.array(r.zVal[:]), rxTime=r.rxTime, posIndex=r.posIndex, velIndex=r.velIndex, posScore=r.posScore,
+                    velScore=r.velScore, posOutOfWindow=r.posOutOfWindow, velOutOfWindow=r.velOutOfWindow, status=r.status)
+
+    def outputs(self, with_batch=False, stream=None):
+        start = np.zeros(self.K, dtype=CHAN_START_DTYPE)
+        end = np.zeros(self.K, dtype=CHAN_END_DTYPE)
+        win = np.zeros(1, dtype=BCM_WINDOW_DTYPE)
+        batch = np.zeros((self.K, self._dimT, 8))
+        status = C.c_int32(0)
+        _check(lib().dpe_chm_dev_read(self._h, start.ctypes.data_as(C.c_void_p), end.ctypes.data_as(C.c_void_p),
+                                      win.ctypes.data_as(C.c_void_p), batch.ctypes.data_as(C.c_void_p), C.byref(status), _stream(stream)))
+        self.status = status.value
+        return (start, end, win, batch) if with_batch else (start, end, win)
+
+    def Stop(self):
+        if self._h:
+            lib().dpe_chm_dev_destroy(self._h)
+            self._h = C.c_void_p(None)
+        return 0
+
+    def __del__(self):
+        try:
             self.Stop()
         except Exception:
             pass

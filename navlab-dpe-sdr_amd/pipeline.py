@@ -54,3 +54,48 @@ def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
     bcm.Stop()
     bcs.Stop()
     return fixes, results
+
+
+def run_device_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), init_delta=(0, 0, 0, 0), K=None, lpower=1,
+                    ring_depth=64, stream=None):
+    """The same loop with nothing read back per window: the channel manager lives on the device (engine.ChanMgrDev), forms
+    the measurement from the scan's keys, passes it through and writes the next window's parameter blocks; the host enqueues
+        BatchCorrScores.UpdatePrepared -> BatchCorrManifold.UpdatePrepared -> ChanMgrDev.step
+    for every window and collects the fixes from the pinned ring afterwards (at most ring_depth - 1 windows ahead)."""
+    import torch
+    iq_windows = np.ascontiguousarray(iq_windows)
+    W, S2 = iq_windows.shape
+    S = S2 // 2
+    K = len(ho["prn_list"]) if K is None else K
+    nfft = engine.carr_fft_len(S)
+    L, B = bank_half_widths(pos_grid, vel_grid, fs, nfft)
+    bcs = engine.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_channels=K)
+    bcs.Start()
+    bcm = engine.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos_grid, vel_grid, LPower=lpower, lag_half_width=L,
+                                   bin_half_width=B, max_channels=K)
+    bcm.Start()
+    cm = engine.ChanMgrDev.from_handoff(ho, S / fs, K, time_grid)
+    cm.attach(bcs, bcm, ring_depth)
+    x = np.array(ho["X_ECEF"], dtype=np.float64).copy()
+    x[:4] += np.asarray(init_delta, dtype=np.float64)
+    iq_d = torch.from_numpy(iq_windows).to("cuda:0")
+    cm.Start(x, stream)
+    fixes, results, got = np.zeros((W, 8)), [], 0
+    for w in range(W):
+        while w - got >= ring_depth - 1:          # never more than the ring holds ahead of the fixes already collected
+            results.append(cm.fix(got))
+            got += 1
+        bcs.UpdatePrepared(iq_d[w], K, stream)
+        bcm.UpdatePrepared(bcs.CodeScores, bcs.CarrScores, K, stream)
+        cm.step(stream)
+    while got < W:
+        results.append(cm.fix(got))
+        got += 1
+    for w, r in enumerate(results):
+        fixes[w] = r["zVal"]
+    cm.outputs()
+    status = cm.status
+    cm.Stop()
+    bcm.Stop()
+    bcs.Stop()
+    return fixes, results, status

@@ -1,0 +1,142 @@
+"""Device-resident channel manager (dpe_chm_dev_*, csrc/dpe_chanmgr.hip) -- the reference's own form of cuChanMgr: state and
+port arrays in device memory, one small kernel per window (cudarecv/modules/src/cuchanmgr.cu:1100-1132,1237-1264) -- against
+the host form dpe_chm_* (itself pinned by the oracle and fixtures O4 / O5 / O7, tests/test_abi_cpu.py), and the closed loop that
+reads nothing back per window against the host-driven loop.
+
+Tolerances.  The two forms share their functions; what differs is the maths library (sin / cos / atan2 of the device against
+glibc's: last-bit differences) and the satellite states, which the device form advances from an expansion made ahead of the
+window (second-order remainder 3e-11 m).  Frequencies, phases, satellite states, ENU matrix: 1e-12 relative.  Code phases:
+the reference forms them as (rxTime - pr / C - ...) x 1.023e6 with rxTime ~ 4e5 s, i.e. on a 5.8e-11 s = 6e-5 chip raster
+(DESIGN.md 2.5); a last-bit difference in pr can move the result by one step of that raster, so they are held to 1e-4 chips
+(in the cases below they agree to 1e-9)."""
+import numpy as np
+import pytest
+
+import navlab_dpe_sdr_amd as dpe
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(dev, host, K):
+    sd, ed, wd, bd = dev
+    sh, eh, wh, bh = host
+    for f in ("cpElapsedStart", "cpReference", "prn"):
+        assert np.array_equal(sd[f], sh[f]), f
+    for f in ("cpRefTOW", "cpElapsedEnd", "cpRef"):
+        assert np.array_equal(ed[f], eh[f]), f
+    worst = {}
+    for name, a, b, tol, rel in (("rcStart", sd["codePhaseStart"], sh["codePhaseStart"], 1e-4, False),
+                                 ("rcEnd", ed["codePhaseEnd"], eh["codePhaseEnd"], 1e-4, False),
+                                 ("riStart", sd["carrierPhaseStart"], sh["carrierPhaseStart"], 1e-9, False),
+                                 ("fc", sd["codeFrequency"], sh["codeFrequency"], 1e-12, True),
+                                 ("fi", sd["carrierFrequency"], sh["carrierFrequency"], 1e-9, False),
+                                 ("R", wd["enu2ecef"], wh["enu2ecef"], 1e-14, False),
+                                 ("x", wd["xCurrkk1"], wh["xCurrkk1"], 0.0, False)):
+        err = np.abs(np.asarray(a) - np.asarray(b)).max()
+        if rel:
+            err /= np.abs(np.asarray(b)).max()
+        worst[name] = err
+        assert err <= tol, (name, err)
+    assert wd["rxTime"][0] == wh["rxTime"][0] and wd["dopplerSign"][0] == wh["dopplerSign"][0]
+    # batch satellite states: positions relative to the orbit radius, velocities to the speed, clock terms absolutely
+    pos = np.abs(bd[..., :3] - bh[..., :3]).max() / 2.6e7
+    vel = np.abs(bd[..., 4:7] - bh[..., 4:7]).max() / 3.0e3
+    clk = max(np.abs(bd[..., 3] - bh[..., 3]).max(), np.abs(bd[..., 7] - bh[..., 7]).max())
+    assert pos < 1e-12 and vel < 1e-12 and clk < 1e-17, (pos, vel, clk)
+    assert np.array_equal(ed["satState"], bd[:, bd.shape[1] // 2])
+    worst.update(satPos=pos, satVel=vel)
+    return worst
+
+
+@pytest.mark.parametrize("ahead", [True, False])
+def test_device_channel_manager_matches_the_host_form(monkeypatch, ahead):
+    """Start + 5 Updates with a moving fix (tens of metres and m/s per window, clock terms included), time grid of 9 entries:
+    every port of the device form against dpe_chm_outputs.  ahead = False (DPE_CHM_NO_AHEAD=1 at create) evaluates every
+    satellite state inside the per-window kernel, as the reference does; ahead = True is the shipped form."""
+    import torch
+    if not ahead:
+        monkeypatch.setenv("DPE_CHM_NO_AHEAD", "1")
+    K = 8
+    ho = dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV)
+    T = 0.02
+    tg = np.linspace(-12.0, 12.0, 9)
+    host = dpe.engine.ChanMgr.from_handoff(ho, T, K)
+    dev = dpe.engine.ChanMgrDev.from_handoff(ho, T, K, tg)
+    x = np.array(ho["X_ECEF"], dtype=np.float64).copy()
+    host.Start(x, x, tg)
+    dev.Start(x)
+    w = _compare(dev.outputs(with_batch=True), host.outputs(with_batch=True), K)
+    rng = np.random.Generator(np.random.PCG64(5))
+    for it in range(5):
+        x1 = x + np.concatenate([rng.uniform(-30, 30, 3), rng.uniform(-40, 40, 1), rng.uniform(-3, 3, 3), rng.uniform(-1, 1, 1)])
+        xk = x1 + np.concatenate([rng.uniform(-2, 2, 4), rng.uniform(-0.2, 0.2, 4)])
+        host.Update(x1, xk, tg)
+        a, b = torch.from_numpy(x1).to("cuda:0"), torch.from_numpy(xk).to("cuda:0")
+        dev.Update(a, b)
+        w = _compare(dev.outputs(with_batch=True), host.outputs(with_batch=True), K)
+        assert dev.status == 0, dev.status     # no Kepler failure, no transmit time outside the expansion's range
+        x = x1
+    print("worst differences after 5 Updates:", {k: float("%.3g" % v) for k, v in w.items()})
+    dev.Stop(); host.Stop()
+
+
+def test_device_closed_loop_matches_the_host_driven_loop():
+    """40 windows of a receiver moving at (5, -3, 2) m/s, 9^4-point grids, 8 SVs: the loop that reads nothing back
+    (UpdatePrepared x 2 + ChanMgrDev.step per window, fixes from the pinned ring, the host up to 7 windows ahead) gives the
+    grid points of the host-driven loop window by window, and fixes equal to 1e-8 m (the ENU matrix comes from the device's
+    atan2 / sincos instead of glibc's: last-bit differences)."""
+    fs, S, K, W = 2.5e6, 50000, 8, 40
+    v = np.array([5.0, -3.0, 2.0])
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=71, amp=200.0, velocity=v)
+    ho = dpe.workload.extend_handoff(dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV), K)
+    pos = dpe.synth.uniform_grid(9, 1.0)
+    vel = dpe.synth.uniform_grid(9, 2.0)
+    tg = np.unique(pos[:, 3])
+    fixes_h, res_h = dpe.pipeline.run_closed_loop(iq, ho, fs, pos, vel, time_grid=tg, K=K)
+    fixes_d, res_d, status = dpe.pipeline.run_device_loop(iq, ho, fs, pos, vel, time_grid=tg, K=K, ring_depth=8)
+    assert status == 0
+    for w in range(W):
+        assert res_d[w]["posIndex"] == res_h[w]["posIndex"] and res_d[w]["velIndex"] == res_h[w]["velIndex"], w
+        assert res_d[w]["posOutOfWindow"] == res_h[w]["posOutOfWindow"] and res_d[w]["velOutOfWindow"] == res_h[w]["velOutOfWindow"]
+        assert abs(res_d[w]["posScore"] - res_h[w]["posScore"]) <= 2e-6 * res_h[w]["posScore"]
+    assert np.abs(fixes_d - fixes_h).max() < 1e-8
+    verr = np.linalg.norm(fixes_d[:, 4:7] - v, axis=1)
+    assert verr[0] > 5.0 and verr[15:].max() < 2.0       # the loop converges as the host-driven one does
+
+
+def test_device_ports_feed_the_dev_update_forms():
+    """A host that keeps the reference's module structure: ChanMgrDev's port arrays handed to dpe_bcs_update_dev /
+    dpe_bcm_update_dev (prep kernels) instead of the prepared forms -- same result for a window."""
+    import torch
+    fs, S, K = 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(1, fs, S, K, seed=3, amp=200.0)
+    ho = dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV)
+    g = dpe.synth.uniform_grid(9, 1.0)
+    tg = np.unique(g[:, 3])
+    L, B = dpe.pipeline.bank_half_widths(g, g, fs, dpe.engine.carr_fft_len(S))
+    x = np.array(ho["X_ECEF"], dtype=np.float64)
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+    out = []
+    for form in ("prepared", "ports"):
+        bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_channels=K)
+        bcs.Start()
+        bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, g, g, lag_half_width=L, bin_half_width=B, max_channels=K)
+        bcm.Start()
+        cm = dpe.engine.ChanMgrDev.from_handoff(ho, S / fs, K, tg)
+        if form == "prepared":
+            cm.attach(bcs, bcm, 4)
+            cm.Start(x)
+            bcs.UpdatePrepared(iq_d[0], K)
+            bcm.UpdatePrepared(bcs.CodeScores, bcs.CarrScores, K)
+        else:
+            cm.Start(x)
+            pb, pm, rx, _, _, _ = cm.ports()
+            s, e, win = cm.outputs()
+            bcs.UpdateDev(iq_d[0], K, {n: getattr(pb, n) for n, _ in pb._fields_})
+            bcm.UpdateDev(bcs.CodeScores, bcs.CarrScores, K, {n: getattr(pm, n) for n, _ in pm._fields_ if n not in ("dimT", "reserved")},
+                          tg.size, float(win["rxTime"][0]))
+        out.append(bcm.results()[0])
+        cm.Stop(); bcm.Stop(); bcs.Stop()
+    a, b = out
+    assert a["posIndex"] == b["posIndex"] and a["velIndex"] == b["velIndex"] and a["posScore"] == b["posScore"] and a["velScore"] == b["velScore"]
+    assert np.array_equal(a["zVal"], b["zVal"])
