@@ -338,10 +338,10 @@ int dpe_chm_outputs(dpe_chanmgr *h, dpe_chan_start *start, dpe_chan_end *end, dp
 /* ------------------------------------------------------------------ cuChanMgr on the device ------ */
 /* The reference's form of the module: state and output ports live in DEVICE memory and one small kernel per window advances
  * them (cuchanmgr.cu:1100-1132 Start, :1237-1264 Update -- CHM_ComputeSatStates / PropagateChannels / TimeUpdateChannels /
- * GridPrep :240-306,338-608,641-829,853-923).  Same arithmetic as dpe_chm_* (the two forms share their functions), with one
- * restructuring: the Kepler evaluations (:85-210) run AHEAD of the window on a side stream -- satellite state and its time
- * derivative at the nominal transmit time -- and the per-window kernel advances them over the <= 1e-6 s that the new fix moves
- * the transmit time (remainder 3e-11 m; beyond 1e-5 s it evaluates directly and sets status bit 1).
+ * GridPrep :240-306,338-608,641-829,853-923).  Same arithmetic as dpe_chm_* (the two forms share their functions), laid out for
+ * latency: a channel's two Kepler evaluations per window (:85-210; their transmit times lie ~1e-7 s apart) run side by side
+ * on two waves -- the second is the first advanced along a difference quotient over 2^-10 s, remainder 3e-11 m -- with the
+ * iterations started from the previous window's anomaly (same fixed point), beside the ENU matrix and the fix hand-over.
  *
  * Attached to a single-window BatchCorrScores / BatchCorrManifold pair (dpe_chm_dev_attach) the same kernel also
  *   - forms the measurement from the scan's arg-max keys on the device (BCM_MakePosMeas / MakeVelMeas, batchcorrmanifold.cu:
@@ -358,8 +358,8 @@ typedef struct dpe_fix_record {
     int64_t posIndex, velIndex; /* global grid indices of the ML points */
     int64_t posOutOfWindow, velOutOfWindow;
     float posScore, velScore;
-    int32_t status;             /* sticky bits: 1 Kepler iteration failed, 2 a transmit time left the expansion's range (evaluated
-                                 * directly), 4 an arg-max key was 0 / outside the grid (state held for that window) */
+    int32_t status;             /* sticky bits: 1 Kepler iteration failed, 4 an arg-max key was 0 / outside the grid (state held for
+                                 * that window), 8 / 16 the BatchCorrScores input flags of dpe_bcs_dev_status */
     int32_t reserved;
 } dpe_fix_record;
 int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans, const double *timeGrid_host, int32_t dimT,

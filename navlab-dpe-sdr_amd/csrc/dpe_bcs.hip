@@ -22,6 +22,7 @@
 
 #include "dpe_common.h"
 #include "dpe_prep.h"
+#include "dpe_chm_dev.h"   // chm_k2: the device-resident channel manager's time update, carried as an extra block (FUSE form)
 
 namespace dpe {
 
@@ -171,7 +172,7 @@ __device__ __forceinline__ void window_mean(const long long *__restrict__ sums, 
 // enters the Doppler moments, and linearly: M_p[(raw - mean) w r] = M_p[raw w r] - mean * M_p[w r].  So this kernel
 // accumulates both moment sets and the k = 0 blocks also write the int64 sample sums of their tiles (one slot per
 // block); bcs_finalize_kernel forms the mean from the slots and combines.  One launch and ~4 us less per window.
-template <int LH, int kNMom, bool TABLE, bool FUSE>
+template <int LH, int kNMom, bool TABLE, bool FUSE, bool CO = false>
 __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride, int S,
                                                        int K, int nSub, int tilesPerBlock, int nBlk, int vecOK, int nSumBlk, int lagShift,
                                                        const BcsChanDev *__restrict__ chan,
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
                                                        const int8_t *__restrict__ chipTable,
                                                        const double *__restrict__ tT,
                                                        float2 *__restrict__ part, float2 *__restrict__ mom,
-                                                       float2 *__restrict__ momRep, long long *__restrict__ sumSlots)
+                                                       float2 *__restrict__ momRep, long long *__restrict__ sumSlots, ChmKArgs co)
 {
     constexpr int NL = 2 * LH + 1;      // lags
     constexpr int NREP = kSub + 2 * LH;  // replica entries per sub-tile (with halo)
@@ -188,7 +189,20 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
     __shared__ __align__(16) float sRep[4][NREP + 4];
     __shared__ float2 sAcc[4][NL];
 
-    const int blk = blockIdx.x, k = blockIdx.y, w = blockIdx.z;
+    // Closed loop on the device (dpe_chm_dev_*): the channel manager's time update for THIS window's scan rides along as block
+    // (0, 0, 0) of the launch -- it needs nothing stage 1 produces and stage 1 nothing of it -- beside the correlator blocks
+    // instead of 10 us in front of them; the blocks of row x = 0 are then not correlator blocks.
+    // (CO: an instantiation of its own -- the time update's registers and code stay out of the kernel every other caller runs)
+    int blkX = blockIdx.x;
+    if constexpr (CO) {
+        static_assert(FUSE && !TABLE, "the co-block rides in the single-window form");
+        if (blkX == 0) {
+            if (blockIdx.y == 0 && blockIdx.z == 0) chm_k2(co);
+            return;
+        }
+        blkX -= 1;
+    }
+    const int blk = blkX, k = blockIdx.y, w = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     (void)pb;
     const BcsChanDev ch = params_ptr(chan, inl)[w * K + k];
@@ -1120,6 +1134,8 @@ struct dpe_bcs {
     bool lastDev = false;              // the last Update took its channel parameters from device arrays (dpe_bcs_update_dev)
     int *status_d = nullptr;           // that form's input check, written by bcs_prep_kernel
     const char *lastKernel = "";   // stage-1 kernel of the last Update (dpe_bcs_stage1_kernel)
+    dpe::ChmKArgs co{};            // a task of the device-resident channel manager for the next stage-1 launch (dpe_bcs_cotask_set)
+    bool coPending = false;
     std::vector<int32_t> idxNext_h;
     dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
     dpe::GraphCache graphs;
@@ -1388,6 +1404,10 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     h->lastW = nWindows;
     h->lastK = nChan;
     if (h->fftMode) {
+        if (h->coPending) {   // (a pending task of the device-resident channel manager: a kernel of its own in front)
+            hipLaunchKernelGGL(chm_k2_kernel, dim3(1), dim3(256), 0, stream, h->co);
+            h->coPending = false;
+        }
         // ---- full-length FFT form (dpe_bcs_fft.h): DC sum, then per chunk of windows the reference's own sequence
         const long long C = h->C;
         const int L = h->cfg.lagHalfWidth, B = h->cfg.binHalfWidth, maxK = h->cfg.maxChannels;
@@ -1547,6 +1567,11 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // sums ride along in the bank kernel (FUSE) and the finalize kernel applies the mean
     const bool fuse = nWindows * nChan <= DPE_MAX_CHAN && !use16 && !wide && !chip && h->LH <= 16 && h->cfg.lagHalfWidth <= 32 && h->fuseAllowed;
     const int sumSlotsUsed = fuse ? nBlk : sumBlocks;
+    // a pending task of the device-resident channel manager: an extra block of the FUSE form's launch, a kernel of its own in
+    // front of every other form
+    const bool coRide = h->coPending && fuse && !h->useTable && !h->graphs.capturing;
+    if (h->coPending && !coRide) hipLaunchKernelGGL(chm_k2_kernel, dim3(1), dim3(256), 0, stream, h->co);
+    h->coPending = false;
     h->lastSumBlocks = sumSlotsUsed;
     if (!fuse) {
         h->prof.begin(0, stream);
@@ -1557,14 +1582,16 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         h->prof.end(0, stream);
         if (upInSum) DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));   // the staging block is free again
     }
-#define DPE_LAUNCH_BANK4(LHV, NM, TB, FS)                                                                               \
-    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB, FS>), grid, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
+#define DPE_LAUNCH_BANK5(LHV, NM, TB, FS, COV, GRID)                                                                     \
+    hipLaunchKernelGGL((bcs_bank_kernel<LHV, NM, TB, FS, COV>), GRID, block, 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, \
                        S, nChan, h->nSub, tpb, nBlk, vecOK, sumBlocks, lagShift, h->chan_d, h->sums_d, h->chipTable_d, \
-                       h->tTable_d, h->part_d, h->mom_d, h->momRep_d, h->sums_d)
-#define DPE_LAUNCH_BANK3(LHV, NM, TB)                                        \
-    do {                                                                     \
-        if (fuse && LHV <= 16) DPE_LAUNCH_BANK4(LHV <= 16 ? LHV : 16, NM, TB, true);   \
-        else DPE_LAUNCH_BANK4(LHV, NM, TB, false);                           \
+                       h->tTable_d, h->part_d, h->mom_d, h->momRep_d, h->sums_d, COV ? h->co : ChmKArgs{})
+#define DPE_LAUNCH_BANK3(LHV, NM, TB)                                                                                    \
+    do {                                                                                                                \
+        if (fuse && LHV <= 16) {                                                                                        \
+            if (coRide) DPE_LAUNCH_BANK5(LHV <= 16 ? LHV : 16, NM, false, true, true, dim3(nBlk + 1, nChan, nWindows)); \
+            else DPE_LAUNCH_BANK5(LHV <= 16 ? LHV : 16, NM, TB, true, false, grid);                                     \
+        } else DPE_LAUNCH_BANK5(LHV, NM, TB, false, false, grid);                                                       \
     } while (0)
 #define DPE_LAUNCH_BANK2(LHV, NM)                           \
     do {                                                    \
@@ -1639,7 +1666,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
 #undef DPE_LAUNCH_BANK
 #undef DPE_LAUNCH_BANK2
 #undef DPE_LAUNCH_BANK3
-#undef DPE_LAUNCH_BANK4
+#undef DPE_LAUNCH_BANK5
     h->prof.end(1, stream);
     h->prof.begin(2, stream);
     const int nBinBlk = (2 * h->cfg.binHalfWidth + 1 + 15) / 16;
@@ -1692,6 +1719,25 @@ int dpe_bcs_update_prepared(dpe_bcs *h, const int16_t *samples_dev, int32_t nCha
     DPE_REQUIRE(h && samples_dev, "[BatchCorrScores] Update: null argument");
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrScores] Update: nChan %d out of range", nChan);
     return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
+}
+
+int dpe_bcs_cotask_set(dpe_bcs *h, const void *args, size_t bytes)
+{
+    DPE_REQUIRE(h && args && bytes == sizeof(dpe::ChmKArgs), "[BatchCorrScores] cotask: bad arguments");
+    DPE_REQUIRE(!h->coPending, "[BatchCorrScores] cotask: the previous task was never launched");
+    memcpy(&h->co, args, bytes);
+    h->coPending = true;
+    return 0;
+}
+
+int dpe_bcs_cotask_flush(dpe_bcs *h, void *stream)
+{
+    DPE_REQUIRE(h, "[BatchCorrScores] cotask: null handle");
+    if (!h->coPending) return 0;
+    hipLaunchKernelGGL(dpe::chm_k2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, h->co);
+    h->coPending = false;
+    DPE_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int dpe_bcs_hook_get(dpe_bcs *h, dpe_bcs_hook *out)

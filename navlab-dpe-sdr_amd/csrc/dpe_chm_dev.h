@@ -1,0 +1,572 @@
+// dpe_chm_dev.h -- the channel manager's arithmetic (cudarecv/modules/src/cuchanmgr.cu:26-923), shared by its host form
+// (dpe_chm_*, dpe_chanmgr.hip), its device form (dpe_chm_dev_*) and the stage-1 kernels of dpe_bcs.hip that carry the device
+// form's time update as an extra block of their launch.
+#pragma once
+#include "dpe_common.h"
+#include "dpe_prep.h"
+
+#ifdef __HIPCC__
+#define DPE_HD __host__ __device__
+#else
+#define DPE_HD
+#endif
+
+namespace dpe {
+
+struct Eph {  // subset of eph_t (cudarecv/utils/inc/ephhelper.h:98-125) used by CHM_Get_Sat_Pos
+    double sqrtA, e, i0, OMG0, omg, M0, deln, OMGd, idot, crc, crs, cuc, cus, cic, cis, toes, tocs, f0, f1, f2, tgd;
+};
+
+constexpr double kMu = 3.9860050e14;       // ephhelper.h MU_GPS
+constexpr double kRelF = -4.442807633e-10; // consthelper.h CONST_F
+constexpr double k2Pi = 6.2831853071796;   // consthelper.h CONST_2PI
+constexpr double kWgsA = 6378137.0, kWgsB = 6356752.314245, kWgsE = 0.08181919084262149, kWgsEp = 0.08209443794969568;
+
+DPE_HD static inline double half_week(double t)  // CHM_Correct_Week_Crossover :26-31
+{
+    return t > 302400.0 ? t - 604800.0 : (t < -302400.0 ? t + 604800.0 : t);
+}
+
+DPE_HD static inline bool solve_kepler(double M, double e, double &E)  // :97-107
+{
+    E = M;
+    double dE = 1.0;
+    for (int it = 0; it < 10 && std::fabs(dE) > 1e-12; ++it) {
+        double sE, cE;
+        sincos(E, &sE, &cE);   // glibc: bit-identical to sin() and cos(), one argument reduction
+        dE = (M - E + e * sE) / (1.0 - e * cE);
+        E = std::fmod(E + dE, k2Pi);
+    }
+    return std::fabs(dE) <= 1e-12;
+}
+
+// CHM_Get_Sat_Pos :85-210 -> state {x,y,z,clk bias, vx,vy,vz, clk drift}
+DPE_HD static inline int sat_state(const Eph &p, double tx, double out[8])
+{
+    const double A = p.sqrtA * p.sqrtA;
+    const double n = std::sqrt(kMu / (A * A * A)) + p.deln;
+    double tc = half_week(tx - p.tocs);
+    double clkb = p.f2 * tc * tc + p.f1 * tc + p.f0 - p.tgd;
+    double tk = half_week(tx - clkb - p.toes);
+    double E;
+    if (!solve_kepler(std::fmod(p.M0 + n * tk, k2Pi), p.e, E)) return -1;
+    const double dtr = kRelF * p.e * p.sqrtA * std::sin(E);
+    tc = tx - (clkb + dtr) - p.tocs;
+    clkb = p.f2 * tc * tc + p.f1 * tc + p.f0 + dtr - p.tgd;
+    const double clkd = p.f1 + 2.0 * p.f2 * tc;
+    tk = half_week(tx - clkb - p.toes);
+    if (!solve_kepler(std::fmod(p.M0 + n * tk, k2Pi), p.e, E)) return -1;
+    double sE, cE;
+    sincos(E, &sE, &cE);
+    const double den = 1.0 - p.e * cE;
+    const double nu = std::atan2(std::sqrt(1.0 - p.e * p.e) * sE / den, (cE - p.e) / den);
+    double u = std::fmod(nu + p.omg, k2Pi);
+    double c2, s2;
+    sincos(2.0 * u, &s2, &c2);
+    u += p.cuc * c2 + p.cus * s2;
+    const double r = A * den + p.crc * c2 + p.crs * s2;
+    const double inc = p.i0 + p.idot * tk + p.cic * c2 + p.cis * s2;
+    const double Om = std::fmod(p.OMG0 + (p.OMGd - kOEDot) * tk - kOEDot * p.toes, k2Pi);
+    double su, cu, sO, cO, si, ci;
+    sincos(u, &su, &cu);
+    sincos(Om, &sO, &cO);
+    sincos(inc, &si, &ci);
+    const double xo = r * cu, yo = r * su;
+    out[0] = xo * cO - yo * sO * ci;
+    out[1] = xo * sO + yo * cO * ci;
+    out[2] = yo * si;
+    out[3] = clkb;
+    sincos(2.0 * u, &s2, &c2);  // recomputed with the corrected u (:180-181)
+    const double Ed = n / den;
+    double snu, cnu;
+    sincos(nu, &snu, &cnu);
+    const double nud = sE * Ed * (1.0 + p.e * cnu) / (snu * den);
+    const double ud = nud + 2.0 * (p.cus * c2 - p.cuc * s2) * nud;
+    const double rd = A * p.e * sE * Ed + 2.0 * (p.crs * c2 - p.crc * s2) * nud;
+    const double id = p.idot + (p.cis * c2 - p.cic * s2) * 2 * nud;
+    const double vxo = rd * cu - yo * ud, vyo = rd * su + xo * ud;
+    const double Omd = p.OMGd - kOEDot;
+    const double ta = vxo - yo * ci * Omd, tb = xo * Omd + vyo * ci - yo * si * id;
+    out[4] = ta * cO - tb * sO;
+    out[5] = ta * sO + tb * cO;
+    out[6] = vyo * si + yo * ci * id;
+    out[7] = clkd;
+    return 0;
+}
+
+struct Chan {
+    int prn, cpElaStart, cpElaEnd, cpRef, cpRefTOW;
+    double rcStart, rcEnd, riStart, riEnd, fc, fi, txTime;
+    double sat[8];
+    Eph eph;
+};
+
+DPE_HD static inline double wrap_pos(double v, double m)
+{
+    double t = std::fmod(v, m);
+    return t < 0.0 ? t + m : t;
+}
+
+DPE_HD static inline double tx_of(const Chan &c, double cpEla, double rc)  // :258-260
+{
+    return c.cpRefTOW + ((cpEla - c.cpRef) * kTCA) + (rc / kFCA);
+}
+
+// Earth-rotation of a satellite state by the signal time of flight (:383-404, :895-916)
+DPE_HD static inline void rotate_state_cs(const double s[8], double ct, double st, double o[8]);
+DPE_HD static inline void rotate_state(const double s[8], double tau, double o[8])
+{
+    double ct, st;
+    sincos(-kOEDot * tau, &st, &ct);
+    rotate_state_cs(s, ct, st, o);
+}
+DPE_HD static inline void rotate_state_cs(const double s[8], double ct, double st, double o[8])
+{
+    o[0] = ct * s[0] - st * s[1];
+    o[1] = st * s[0] + ct * s[1];
+    o[2] = s[2];
+    o[3] = s[3];
+    o[4] = ct * s[4] - st * s[5] - kOEDot * st * s[0] - kOEDot * ct * s[1];
+    o[5] = st * s[4] + ct * s[5] + kOEDot * ct * s[0] - kOEDot * st * s[1];
+    o[6] = s[6];
+    o[7] = s[7];
+}
+
+// back-calculated code phase (chips since the reference code period) for a receiver state x at
+// receive time t and a rotated satellite state (:429-432, :763-774)
+DPE_HD static inline double back_calc_rc(const Chan &c, const double sat[8], const double *x, double t, double *rangeOut)
+{
+    const double lx = sat[0] - x[0], ly = sat[1] - x[1], lz = sat[2] - x[2];
+    const double range = std::sqrt(lx * lx + ly * ly + lz * lz);
+    const double pr = range - kC * sat[3] + x[3];
+    const double bcTx = t - pr / kC;
+    const double frac = bcTx - c.cpRefTOW - ((c.cpElaEnd - c.cpRef) * kTCA);
+    if (rangeOut) *rangeOut = range;
+    return frac * kFCA;
+}
+
+// time update shared by CHM_TimeUpdateChannels (:675-823) and the tail of CHM_PropagateChannels (:451-602)
+struct SatDirect {   // the reference's evaluation (CHM_Get_Sat_Pos)
+    DPE_HD int operator()(const Chan &c, double tx, double out[8]) const { return sat_state(c.eph, tx, out); }
+};
+template <class SatFn>
+DPE_HD static inline int advance(Chan &c, const double *x, double rxTime, double T, const SatFn &sat_at)
+{
+    const double adv = c.fc * T + c.rcEnd;
+    const double cpPred = c.cpElaEnd + std::floor(adv / kLCA);
+    const double rcPred = wrap_pos(adv, (double)kLCA);
+    const double txPred = tx_of(c, cpPred, rcPred);
+    double sp[8], sr[8];
+    if (sat_at(c, txPred, sp)) return -1;
+    const double tau = rxTime + T - (txPred + (x[3] / kC)) + sp[3];
+    rotate_state(sp, tau, sr);
+    const double bcRc = back_calc_rc(c, sr, x, rxTime + T, nullptr);
+    c.cpElaStart = c.cpElaEnd;
+    c.rcStart = c.rcEnd;
+    c.cpElaEnd += std::floor(bcRc / kLCA);
+    c.rcEnd = wrap_pos(bcRc, (double)kLCA);
+    c.riStart = c.riEnd;
+    c.riEnd = wrap_pos(c.fi * T + c.riEnd, 1.0);
+    c.txTime = tx_of(c, c.cpElaEnd, c.rcEnd);
+    return sat_at(c, c.txTime, c.sat);
+}
+
+// measurement update of fi / fc from the new fix (CHM_PropagateChannels :380-447), then the time update
+template <class SatFn>
+DPE_HD static inline int propagate(Chan &c, const double *x, double rxTime, double T, int dopplerSign, const SatFn &sat_at)
+{
+    double sr[8], range;
+    const double tau = rxTime - (c.txTime + (x[3] / kC)) + c.sat[3];
+    rotate_state(c.sat, tau, sr);
+    const double bcRc = back_calc_rc(c, sr, x, rxTime, &range);
+    const double ex = x[4] - kOEDot * x[1], ey = x[5] + kOEDot * x[0], ez = x[6];
+    const double lx = sr[0] - x[0], ly = sr[1] - x[1], lz = sr[2] - x[2];
+    const double lrr = ((lx / range) * (ex - sr[4])) + ((ly / range) * (ey - sr[5])) + ((lz / range) * (ez - sr[6]));
+    const double bcFi = kFL1 * ((lrr - x[7]) / kC + sr[7]) / dopplerSign;
+    const double bcFc = kFCA + (dopplerSign * kFCA / kFL1) * bcFi + (bcRc - c.rcEnd) / T;
+    c.fi = bcFi;
+    c.fc = bcFc;
+    return advance(c, x, rxTime, T, sat_at);
+}
+
+// CHM_GridPrep :892-916 for one channel: the K x dimT batch satellite states.  The entry the ML kernels read (dimT / 2,
+// BCM :1775) takes the reference's own evaluation.  The others differ from it by a clock-offset step of metres / c in the
+// time of flight, i.e. by d <= 1e-10 rad of Earth rotation: their rotation is the mid one advanced to first order,
+// cos(a + d) = cos a - d sin a, sin(a + d) = sin a + d cos a -- the d^2 / 2 <= 1e-20 remainder is far below the last bit --
+// instead of 2 (dimT - 1) more sin/cos evaluations per SV.
+DPE_HD static inline void batch_states(const Chan &c, double rxTime, const double *xkk1, const double *timeGrid, int dimT, double *out /* [dimT][8] */)
+{
+    const int mid = dimT / 2;
+    const double tau0 = rxTime - (c.txTime + ((timeGrid[mid] + xkk1[3]) / kC)) + c.sat[3];
+    double ct0, st0;
+    sincos(-kOEDot * tau0, &st0, &ct0);
+    for (int t = 0; t < dimT; ++t) {
+        double *o = out + (size_t)t * 8;
+        if (t == mid) { rotate_state_cs(c.sat, ct0, st0, o); continue; }
+        const double tau = rxTime - (c.txTime + ((timeGrid[t] + xkk1[3]) / kC)) + c.sat[3];
+        const double d = -kOEDot * (tau - tau0);
+        if (std::fabs(d) < 1e-8) rotate_state_cs(c.sat, ct0 - d * st0, st0 + d * ct0, o);
+        else rotate_state(c.sat, tau, o);   // a time grid of kilometres: evaluate directly
+    }
+}
+
+// CHM_Dev_ECEF2LL_Rad :37-50 + CHM_Dev_R_ENU2ECEF :54-73: row-major ENU -> ECEF at the grid centre
+DPE_HD static inline void enu2ecef_matrix(const double *xkk1, double Rm[9])
+{
+    const double p = std::sqrt(xkk1[0] * xkk1[0] + xkk1[1] * xkk1[1]);
+    const double th = std::atan2(xkk1[2] * kWgsA, p * kWgsB);
+    const double lat = std::atan2(xkk1[2] + std::pow(kWgsEp, 2) * kWgsB * std::pow(std::sin(th), 3),
+                                  p - std::pow(kWgsE, 2) * kWgsA * std::pow(std::cos(th), 3));
+    const double lon = std::atan2(xkk1[1], xkk1[0]);
+    double sa, ca, so, co;
+    sincos(lat, &sa, &ca);
+    sincos(lon, &so, &co);
+    Rm[0] = -so; Rm[1] = -sa * co; Rm[2] = ca * co;
+    Rm[3] = co;  Rm[4] = -sa * so; Rm[5] = ca * so;
+    Rm[6] = 0.0; Rm[7] = ca;       Rm[8] = sa;
+}
+
+}  // namespace dpe
+
+#ifdef __HIPCC__
+namespace dpe {
+
+struct ChmDevState {
+    Chan ch[DPE_MAX_CHAN];
+    double warmE[DPE_MAX_CHAN], warmM[DPE_MAX_CHAN];   // Kepler warm start: eccentric / mean anomaly of the channel's last evaluation
+    int warmOk[DPE_MAX_CHAN];
+    double rxTime, T;
+    int dopplerSign, K, dimT;
+    int status;        // sticky: 1 Kepler iteration failed, 4 an arg-max key was 0 / out of range, 8 / 16 BatchCorrScores input flags
+    long long window;  // windows completed (Start does not count)
+};
+// The reference's output ports of cuChanMgr (cuchanmgr.cu:973-990,1136-1171) and cuEKF (cuekf.cu:277-279) as device arrays,
+// plus zVal (BatchCorrManifold, :2297) and the TimeGrid input
+struct ChmPorts {
+    double *rxTime, *txTime, *rcStart, *riStart, *rcEnd, *riEnd, *fc, *fi, *sat, *enu2ecef, *xk1k1, *xkk1, *zVal, *timeGrid;
+    int *dopplerSign, *cpRef, *cpElaStart, *cpElaEnd, *cpRefTOW;
+    unsigned char *prn;
+};
+struct ChmKArgs {
+    ChmDevState *st;
+    ChmPorts p;
+    int mode;                       // 0 Start (CHM_ComputeSatStates + time update), 1 Update (measurement + time update)
+    const double *xk1k1, *xkk1;     // inputs 10 / 12 on the device; ignored when meas != 0
+    // measurement from the attached BatchCorrManifold's keys (BCM_MakePosMeas / MakeVelMeas + EKF_PassMeas)
+    int meas;
+    const unsigned long long *keys; // {posKey, velKey, posOutOfWindow, velOutOfWindow} of the window just scanned
+    const double *posGrid, *velGrid;
+    long long posG, velG, posOff, velOff;
+    dpe_fix_record *ring;           // pinned, device address
+    int ringDepth;
+    // parameter blocks of the attached handles for the NEXT window (nullptr: not attached)
+    BcsChanDev *bcsChan;
+    int *bcsStatus;
+    double fs;
+    int S;
+    BcmSvDev *svPos, *svVel;
+    BcmDevWin *devWin;
+    double Cf;
+    int L, B;
+    long long C;
+};
+
+// CHM_Get_Sat_Pos with the Kepler iterations started near their fixed point: the first solve from the channel's previous
+// eccentric anomaly advanced by the change of the mean anomaly (two iterations instead of five at e = 0.01), the second -- whose
+// mean anomaly differs by n x 1e-8 s -- from the first.  The iteration's fixed point does not depend on where it starts; the
+// values agree with the cold start to the last bits (1e-16 in E).
+__device__ static inline bool kepler_from(double M, double e, double &E)
+{
+    double dE = 1.0;
+    for (int it = 0; it < 10 && fabs(dE) > 1e-12; ++it) {
+        double sE, cE;
+        sincos(E, &sE, &cE);
+        dE = (M - E + e * sE) / (1.0 - e * cE);
+        E = fmod(E + dE, k2Pi);
+    }
+    return fabs(dE) <= 1e-12;
+}
+__device__ static inline int sat_state_warm(const Eph &p, double tx, double out[8], double &wE, double &wM, int &wOk)
+{
+    const double A = p.sqrtA * p.sqrtA;
+    const double n = sqrt(kMu / (A * A * A)) + p.deln;
+    double tc = half_week(tx - p.tocs);
+    double clkb = p.f2 * tc * tc + p.f1 * tc + p.f0 - p.tgd;
+    double tk = half_week(tx - clkb - p.toes);
+    double M = fmod(p.M0 + n * tk, k2Pi);
+    double E = M;
+    if (wOk && fabs(M - wM) < 1e-2) E = wE + (M - wM);
+    if (!kepler_from(M, p.e, E)) return -1;
+    const double dtr = kRelF * p.e * p.sqrtA * sin(E);
+    tc = tx - (clkb + dtr) - p.tocs;
+    clkb = p.f2 * tc * tc + p.f1 * tc + p.f0 + dtr - p.tgd;
+    const double clkd = p.f1 + 2.0 * p.f2 * tc;
+    tk = half_week(tx - clkb - p.toes);
+    M = fmod(p.M0 + n * tk, k2Pi);
+    if (!kepler_from(M, p.e, E)) return -1;
+    wE = E; wM = M; wOk = 1;
+    double sE, cE;
+    sincos(E, &sE, &cE);
+    const double den = 1.0 - p.e * cE;
+    const double nu = atan2(sqrt(1.0 - p.e * p.e) * sE / den, (cE - p.e) / den);
+    double u = fmod(nu + p.omg, k2Pi);
+    double c2, s2;
+    sincos(2.0 * u, &s2, &c2);
+    u += p.cuc * c2 + p.cus * s2;
+    const double r = A * den + p.crc * c2 + p.crs * s2;
+    const double inc = p.i0 + p.idot * tk + p.cic * c2 + p.cis * s2;
+    const double Om = fmod(p.OMG0 + (p.OMGd - kOEDot) * tk - kOEDot * p.toes, k2Pi);
+    double su, cu, sO, cO, si, ci;
+    sincos(u, &su, &cu);
+    sincos(Om, &sO, &cO);
+    sincos(inc, &si, &ci);
+    const double xo = r * cu, yo = r * su;
+    out[0] = xo * cO - yo * sO * ci;
+    out[1] = xo * sO + yo * cO * ci;
+    out[2] = yo * si;
+    out[3] = clkb;
+    sincos(2.0 * u, &s2, &c2);  // recomputed with the corrected u (:180-181)
+    const double Ed = n / den;
+    double snu, cnu;
+    sincos(nu, &snu, &cnu);
+    const double nud = sE * Ed * (1.0 + p.e * cnu) / (snu * den);
+    const double ud = nud + 2.0 * (p.cus * c2 - p.cuc * s2) * nud;
+    const double rd = A * p.e * sE * Ed + 2.0 * (p.crs * c2 - p.crc * s2) * nud;
+    const double id = p.idot + (p.cis * c2 - p.cic * s2) * 2 * nud;
+    const double vxo = rd * cu - yo * ud, vyo = rd * su + xo * ud;
+    const double Omd = p.OMGd - kOEDot;
+    const double ta = vxo - yo * ci * Omd, tb = xo * Omd + vyo * ci - yo * si * id;
+    out[4] = ta * cO - tb * sO;
+    out[5] = ta * sO + tb * cO;
+    out[6] = vyo * si + yo * ci * id;
+    out[7] = clkd;
+    return 0;
+}
+
+// The per-window work in two pieces, so that only the first sits between the scan of window n and the correlator of window n+1:
+//
+//   chm_k1 (one wave, a kernel of its own behind the scan): the measurement from the scan's keys (BCM_MakePosMeas / MakeVelMeas,
+//       batchcorrmanifold.cu:1977-2068), the pass-through (EKF_PassMeas, cuekf.cu:147-159), the measurement update of fi / fc
+//       (CHM_PropagateChannels :380-447), BatchCorrScores' parameter block of the next window, the fix for the host (the
+//       record's fields leave for the pinned ring as soon as the measurement exists, its sequence word at the kernel's end).
+//   chm_k2 (one block of 256 threads): the time update (CHM_TimeUpdateChannels :675-823) with its two Kepler evaluations
+//       (:85-210), CHM_GridPrep (:853-923), BatchCorrManifold's coefficient blocks.  Nothing the next window's stage 1 reads
+//       -- it runs as an extra block of that window's stage-1 LAUNCH (bcs_bank_kernel, FUSE form), beside the correlator blocks,
+//       and is complete when the scan starts.  (As a kernel of its own for a host that keeps the reference's module order.)
+//       Waves 0 / 1: a channel's two evaluations lie ~1e-7 s apart, so the second is the first advanced along the difference
+//       quotient over h = 2^-10 s (step error a h / 2 x dt = 3e-11 m) and the two run side by side.  Wave 2: the ENU matrix.
+//       Then all threads: the K x dimT batch states.
+constexpr double kChmH = 0.0009765625;
+
+__device__ static inline void chm_k1(const ChmKArgs &a)
+{
+    __shared__ double sX1[8];
+    __shared__ int sFlags;
+    ChmDevState *st = a.st;
+    const int k = threadIdx.x, K = st->K;
+    const double rxTime = st->rxTime, T = st->T;
+    const int ds = st->dopplerSign;
+    if (k == 0) sFlags = 0;
+    Chan c;
+    if (k < K) c = st->ch[k];
+    double z[8];
+    unsigned long long kp = 0ull, kv = 0ull;
+    long long ip = 0, iv = 0;
+    int measBad = 0;
+    if (k == 63) {
+        if (a.meas) {
+            // ML grid points -> ECEF measurement about the grid centre and with the ENU matrix the scan of this window used
+            // = the ports as the previous window's chm_k2 left them
+            kp = a.keys[0]; kv = a.keys[1];
+            ip = (long long)(0xFFFFFFFFu - (unsigned)(kp & 0xFFFFFFFFull)) - a.posOff;
+            iv = (long long)(0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull)) - a.velOff;
+            if (kp == 0ull || ip < 0 || ip >= a.posG) { measBad = 4; ip = 0; }
+            if (kv == 0ull || iv < 0 || iv >= a.velG) { measBad = 4; iv = 0; }
+            const double *g = a.posGrid + 4 * ip, *v = a.velGrid + 4 * iv, *R = a.p.enu2ecef, *cc = a.p.xkk1;
+            z[0] = R[0] * g[0] + R[1] * g[1] + R[2] * g[2] + cc[0];   // :1990-1999
+            z[1] = R[3] * g[0] + R[4] * g[1] + R[5] * g[2] + cc[1];
+            z[2] = R[6] * g[0] + R[7] * g[1] + R[8] * g[2] + cc[2];
+            z[3] = g[3] + cc[3];
+            z[4] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + cc[4];   // :2042-2051
+            z[5] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + cc[5];
+            z[6] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + cc[6];
+            z[7] = v[3] + cc[7];
+            if (measBad) {   // no valid score this window: hold the state (and say so)
+                for (int i = 0; i < 8; ++i) z[i] = cc[i];
+                atomicOr(&sFlags, measBad);
+            }
+            for (int i = 0; i < 8; ++i) { sX1[i] = z[i]; a.p.zVal[i] = z[i]; a.p.xk1k1[i] = z[i]; a.p.xkk1[i] = z[i]; }   // EKF_PassMeas: both state ports
+            // the fix for the host: the record's fields go out over the host link now, its sequence word at the end of the kernel
+            dpe_fix_record *r = a.ring + (st->window % a.ringDepth);
+            for (int i = 0; i < 8; ++i) __hip_atomic_store(&r->zVal[i], z[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->rxTime, rxTime, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->posIndex, (long long)(ip + a.posOff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->velIndex, (long long)(iv + a.velOff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->posOutOfWindow, (long long)a.keys[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->velOutOfWindow, (long long)a.keys[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->posScore, __uint_as_float((unsigned)(kp >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->velScore, __uint_as_float((unsigned)(kv >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&r->status, st->status | measBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            for (int i = 0; i < 8; ++i) {
+                const double x1 = a.xk1k1[i], xk = a.xkk1[i];
+                sX1[i] = x1; a.p.xk1k1[i] = x1; a.p.xkk1[i] = xk;
+            }
+        }
+    }
+    __syncthreads();
+    if (k < K && a.mode == 1) {   // measurement update (CHM_PropagateChannels :380-447)
+        double sr[8], range;
+        const double tau = rxTime - (c.txTime + (sX1[3] / kC)) + c.sat[3];
+        rotate_state(c.sat, tau, sr);
+        const double bcRc = back_calc_rc(c, sr, sX1, rxTime, &range);
+        const double ex = sX1[4] - kOEDot * sX1[1], ey = sX1[5] + kOEDot * sX1[0], ez = sX1[6];
+        const double lx = sr[0] - sX1[0], ly = sr[1] - sX1[1], lz = sr[2] - sX1[2];
+        const double lrr = ((lx / range) * (ex - sr[4])) + ((ly / range) * (ey - sr[5])) + ((lz / range) * (ez - sr[6]));
+        const double bcFi = kFL1 * ((lrr - sX1[7]) / kC + sr[7]) / ds;
+        const double bcFc = kFCA + (ds * kFCA / kFL1) * bcFi + (bcRc - c.rcEnd) / T;
+        c.fi = bcFi;
+        c.fc = bcFc;
+        st->ch[k].fi = bcFi;
+        st->ch[k].fc = bcFc;
+    }
+    if (k < K && a.bcsChan) {   // the next window starts where this one ended: rcEnd, riEnd, cpElaEnd with the new frequencies
+        int bad;
+        a.bcsChan[k] = bcs_prep_one(c.rcEnd, c.riEnd, c.fc, c.fi, c.cpElaEnd, c.cpRef, c.prn, a.fs, a.S, bad);
+        if (bad) atomicOr(&sFlags, bad << 3);
+    }
+    __syncthreads();
+    if (k == 0) {
+        if (sFlags) st->status |= sFlags;
+        if (a.bcsStatus) *a.bcsStatus = (sFlags >> 3) & 3;
+    }
+    if (k == 63 && a.meas) {   // the record is complete once its fields have arrived: sequence word last
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&(a.ring + (st->window % a.ringDepth))->seq, (unsigned long long)(st->window + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__device__ __forceinline__ static void chm_k2(const ChmKArgs &a)
+{
+    __shared__ double sXk[8], sR[9];
+    __shared__ double sTx[DPE_MAX_CHAN], sS1[DPE_MAX_CHAN][8], sSat[DPE_MAX_CHAN][8], sTau0[DPE_MAX_CHAN], sCt[DPE_MAX_CHAN], sSt[DPE_MAX_CHAN];
+    __shared__ int sFlags;
+    ChmDevState *st = a.st;
+    const int tid = threadIdx.x, nThreads = blockDim.x, wave = tid >> 6, k = tid & 63, K = st->K, dimT = st->dimT;
+    const double rxTime = st->rxTime, T = st->T;
+    const int ds = st->dopplerSign;
+    const bool live = wave < 2 && k < K;
+    if (tid == 0) sFlags = 0;
+    if (tid < 8) sXk[tid] = a.p.xkk1[tid];
+    Chan c;
+    double wE = 0.0, wM = 0.0;
+    int wOk = 0;
+    if (live) {
+        c = st->ch[k];
+        wE = st->warmE[k]; wM = st->warmM[k]; wOk = st->warmOk[k];
+    }
+    __syncthreads();
+    // ---- 1. predicted transmit time (CHM_TimeUpdateChannels :675-823); at Start first CHM_ComputeSatStates :258-301
+    double x1[8];
+    for (int i = 0; i < 8; ++i) x1[i] = a.p.xk1k1[i];
+    double txPred = 0.0;
+    if (wave == 0 && live) {
+        if (a.mode == 0) {
+            c.txTime = tx_of(c, c.cpElaEnd, c.rcEnd);
+            if (sat_state_warm(c.eph, c.txTime, c.sat, wE, wM, wOk)) atomicOr(&sFlags, 1);
+        }
+        const double adv = c.fc * T + c.rcEnd;
+        const double cpPred = c.cpElaEnd + floor(adv / kLCA);
+        const double rcPred = wrap_pos(adv, (double)kLCA);
+        txPred = tx_of(c, cpPred, rcPred);
+        sTx[k] = txPred;
+    }
+    __syncthreads();
+    // ---- 2. the satellite state at the predicted transmit time (wave 0) and a step later (wave 1), side by side; wave 2: the
+    //         ENU -> ECEF matrix of the next grid centre (CHM_Dev_R_ENU2ECEF :54-73)
+    double sp[8];
+    if (live) {
+        const double tx = sTx[k] + (wave == 1 ? kChmH : 0.0);
+        if (sat_state_warm(c.eph, tx, sp, wE, wM, wOk)) atomicOr(&sFlags, 1);
+        if (wave == 1)
+            for (int i = 0; i < 8; ++i) sS1[k][i] = sp[i];
+    }
+    if (tid == 128) {
+        double Rm[9];
+        enu2ecef_matrix(sXk, Rm);
+        for (int i = 0; i < 9; ++i) { sR[i] = Rm[i]; a.p.enu2ecef[i] = Rm[i]; }
+        a.p.rxTime[0] = rxTime + T;
+        a.p.dopplerSign[0] = ds;
+    }
+    __syncthreads();
+    // ---- 3. wave 0: the rest of the time update; the state at the back-calculated transmit time along the difference quotient
+    if (wave == 0 && live) {
+        double sr[8];
+        const double tau = rxTime + T - (txPred + (x1[3] / kC)) + sp[3];
+        rotate_state(sp, tau, sr);
+        const double bcRc = back_calc_rc(c, sr, x1, rxTime + T, nullptr);
+        c.cpElaStart = c.cpElaEnd;
+        c.rcStart = c.rcEnd;
+        c.cpElaEnd += floor(bcRc / kLCA);
+        c.rcEnd = wrap_pos(bcRc, (double)kLCA);
+        c.riStart = c.riEnd;
+        c.riEnd = wrap_pos(c.fi * T + c.riEnd, 1.0);
+        c.txTime = tx_of(c, c.cpElaEnd, c.rcEnd);
+        const double dt = c.txTime - txPred;
+        for (int i = 0; i < 8; ++i) c.sat[i] = fma((sS1[k][i] - sp[i]) / kChmH, dt, sp[i]);
+        st->ch[k] = c;
+        st->warmE[k] = wE; st->warmM[k] = wM; st->warmOk[k] = wOk;
+        // ports (cuchanmgr.cu:1136-1171)
+        a.p.txTime[k] = c.txTime;
+        a.p.rcStart[k] = c.rcStart; a.p.riStart[k] = c.riStart;
+        a.p.rcEnd[k] = c.rcEnd;     a.p.riEnd[k] = c.riEnd;
+        a.p.fc[k] = c.fc;           a.p.fi[k] = c.fi;
+        a.p.cpRef[k] = c.cpRef;     a.p.cpElaStart[k] = c.cpElaStart;
+        a.p.cpElaEnd[k] = c.cpElaEnd; a.p.cpRefTOW[k] = c.cpRefTOW;
+        a.p.prn[k] = (unsigned char)c.prn;
+        // CHM_GridPrep :892-916 at the new receive time: the mid-time rotation here, the K x dimT entries by all threads below
+        const double tau0 = rxTime + T - (c.txTime + ((a.p.timeGrid[dimT / 2] + sXk[3]) / kC)) + c.sat[3];
+        double ct0, st0;
+        sincos(-kOEDot * tau0, &st0, &ct0);
+        sCt[k] = ct0; sSt[k] = st0; sTau0[k] = tau0;
+        for (int i = 0; i < 8; ++i) sSat[k][i] = c.sat[i];
+        if (a.svPos) {
+            double mid[8];
+            rotate_state_cs(c.sat, ct0, st0, mid);
+            BcmSvDev ap, av;
+            bcm_prep_one(sXk, sR, mid, c.rcEnd, c.fc, c.fi, c.cpRefTOW, c.cpElaEnd, c.cpRef, ds, rxTime + T, a.fs, a.Cf, a.S, a.L, a.B, a.C, ap, av);
+            a.svPos[k] = ap;
+            a.svVel[k] = av;
+        }
+    }
+    __syncthreads();
+    // ---- 4. batch satellite states, entry (channel, time-grid index) per thread (see batch_states: the mid entry takes the
+    //         reference's own evaluation, the others its first-order neighbourhood)
+    for (int e = tid; e < K * dimT; e += nThreads) {
+        const int kk = e / dimT, t = e - kk * dimT;
+        double *o = a.p.sat + (size_t)e * 8;
+        const double ct0 = sCt[kk], st0 = sSt[kk];
+        if (t == dimT / 2) { rotate_state_cs(sSat[kk], ct0, st0, o); continue; }
+        const double dTau = -(a.p.timeGrid[t] - a.p.timeGrid[dimT / 2]) / kC;   // tau - tau0
+        const double d = -kOEDot * dTau;
+        if (fabs(d) < 1e-8) rotate_state_cs(sSat[kk], ct0 - d * st0, st0 + d * ct0, o);
+        else rotate_state(sSat[kk], sTau0[kk] + dTau, o);
+    }
+    if (tid == 0) {
+        st->rxTime = rxTime + T;   // :1121, :1249
+        if (a.mode == 1) st->window += 1;
+        if (sFlags) st->status |= sFlags;
+        if (a.devWin) {   // the window frame dpe_bcm_results would read (pinned)
+            for (int i = 0; i < 8; ++i) a.devWin->xCurrkk1[i] = sXk[i];
+            for (int i = 0; i < 9; ++i) a.devWin->enu2ecef[i] = sR[i];
+            a.devWin->dopplerSign = ds;
+            a.devWin->bad = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) static void chm_k1_kernel(ChmKArgs a) { chm_k1(a); }
+__global__ __launch_bounds__(256) static void chm_k2_kernel(ChmKArgs a) { chm_k2(a); }
+
+}  // namespace dpe
+#endif  // __HIPCC__

@@ -62,8 +62,10 @@ __device__ __forceinline__ BcsChanDev bcs_prep_one(double rc, double ri, double 
     d.fi = fi;
     d.invStep = fs / fc;
     const double ang = -6.283185307179586476925286766559 * d.carrStep;
-    d.rotRe = (float)cos(ang);
-    d.rotIm = (float)sin(ang);
+    double sa, ca;
+    sincos(ang, &sa, &ca);   // (one argument reduction; the host's std::cos / std::sin give the same floats)
+    d.rotRe = (float)ca;
+    d.rotIm = (float)sa;
     const int since = (((cpEla - cpRef) % 20) + 20) % 20;                                   // BCS_NavBitBoundary :247-253
     d.idxNext = (int)(floor((kLCA * (20 - since) - rc) * (fs / fc)) + 1);
     d.hasFlip = (d.idxNext > 0 && d.idxNext < S) ? 1 : 0;
@@ -131,6 +133,11 @@ struct dpe_bcs_hook {
     int S, maxChannels;
 };
 int dpe_bcs_hook_get(dpe_bcs *h, dpe_bcs_hook *out);
+// The device-resident channel manager's time update (chm_k2, dpe_chm_dev.h) as a task for this handle's next stage-1 launch:
+// `args` = a dpe::ChmKArgs; the launch carries it as an extra block when its kernel form can (single-window bcs_bank_kernel),
+// otherwise -- and from dpe_bcs_cotask_flush -- it runs as a kernel of its own first.
+int dpe_bcs_cotask_set(dpe_bcs *h, const void *args, size_t bytes);
+int dpe_bcs_cotask_flush(dpe_bcs *h, void *stream);
 struct dpe_bcm_hook {
     dpe::BcmSvDev *svPos_d, *svVel_d;          // [maxWindows][maxChannels] each; window 0 is the single-window block
     dpe::BcmDevWin *devWin_hd;                 // pinned window frame (device address)

@@ -6,6 +6,9 @@
 //   dpe_flow --samples f.dat --handoff handoff.csv --out X.csv [--fs 2.5e6] [--T 0.02] [--iters 3000]
 //            [--grid-dim 25] [--spacing 1.0] [--grid-type 0|2] [--load-grid rngrid.csv] [--lpower 1]
 //            [--init-delta dx dy dz dt]
+//            [--device-loop [--fix-lag n]]       cuChanMgr on the device (dpe_chm_dev_*): measurement, pass-through and channel
+//                                                update in one kernel behind the scan, nothing read back per window; the flow
+//                                                thread enqueues up to n (default 8) windows ahead of the fixes it has collected
 //            [--ranks N --rank r --rendezvous DIR [--comm rccl|files] [--device d] [--shard-stage1]]
 //                                                one flow per GPU: grid shard r of N, arg-max exchanged through
 //                                                dpe_bcm_exchange_keys (RCCL, or host files for tests); --shard-stage1: each
@@ -26,13 +29,102 @@
         }                                                                     \
     } while (0)
 
+// The flow of dpeflow.cpp:55-213 with cuEKF (pass-through), cuChanMgr and the X-file logger replaced by cuChanMgrDev.
+static int run_device_loop(const std::string &samples, const std::string &handoff, const std::string &out, const std::string &rinex,
+                           const std::string &loadGrid, double fs, double T, int iters, int gridDim, int gridType, int lpower, float spacing,
+                           const float *delta, int L, int B, int fixLag, int device, bool timing)
+{
+    dsp::Flow flow;
+    auto *bcs = new dsp::BatchCorrScores;
+    auto *bcm = new dsp::BatchCorrManifold;
+    auto *chm = new dsp::cuChanMgrDev(bcs, bcm);
+    flow.Add(new dsp::DPInit);
+    flow.Add(new dsp::SampleBlock);
+    flow.Add(bcs);
+    flow.Add(bcm);
+    flow.Add(chm);
+    CHECK(flow.SetModParam("SampleBlock", "SamplingFrequency", fs));
+    CHECK(flow.SetModParam("SampleBlock", "RunLive", false));
+    CHECK(flow.SetModParam("SampleBlock", "Filename", samples.c_str()));
+    CHECK(flow.SetModParam("SampleBlock", "SampleLength", T));
+    CHECK(flow.SetModParam("SampleBlock", "ReleaseLag", fixLag + 2));
+    CHECK(flow.SetModParam("DPInit", "HandoffFilename", handoff.c_str()));
+    if (!rinex.empty()) CHECK(flow.SetModParam("DPInit", "RINEXFilename", rinex.c_str()));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaX", delta[0]));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaY", delta[1]));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaZ", delta[2]));
+    CHECK(flow.SetModParam("DPInit", "InitDeltaT", delta[3]));
+    CHECK(flow.SetModParam("DPInit", "MaxIterations", iters + 1));
+    CHECK(flow.SetModParam("BatchCorrManifold", "PosGridDimSize", gridDim));
+    CHECK(flow.SetModParam("BatchCorrManifold", "VelGridDimSize", gridDim));
+    CHECK(flow.SetModParam("BatchCorrManifold", "GridDimSpacing", spacing));
+    CHECK(flow.SetModParam("BatchCorrManifold", "GridType", gridType));
+    CHECK(flow.SetModParam("BatchCorrManifold", "LPower", lpower));
+    CHECK(flow.SetModParam("BatchCorrManifold", "DeviceLoop", true));
+    CHECK(flow.SetModParam("BatchCorrScores", "DeviceLoop", true));
+    CHECK(flow.SetModParam("BatchCorrScores", "LagHalfWidth", L));
+    CHECK(flow.SetModParam("BatchCorrScores", "BinHalfWidth", B));
+    CHECK(flow.SetModParam("cuChanMgr", "DopplerSign", 1));
+    CHECK(flow.SetModParam("cuChanMgr", "FixLag", fixLag));
+    CHECK(flow.SetModParam("cuChanMgr", "XFilename", out.c_str()));
+    if (!loadGrid.empty()) {
+        CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGrid", true));
+        CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGridFilename", loadGrid.c_str()));
+    }
+    static const char *wires[][4] = {
+        {"DPInit", "StartByte", "SampleBlock", "StartByte"},
+        {"DPInit", "InitX", "cuChanMgr", "InitX"},
+        {"DPInit", "InitEph", "cuChanMgr", "InitEph"},
+        {"DPInit", "InitPRN", "cuChanMgr", "InitPRN"},
+        {"DPInit", "InitCodePhase", "cuChanMgr", "InitCodePhase"},
+        {"DPInit", "InitCarrierPhase", "cuChanMgr", "InitCarrierPhase"},
+        {"DPInit", "InitCodeFrequency", "cuChanMgr", "InitCodeFrequency"},
+        {"DPInit", "InitCarrierFrequency", "cuChanMgr", "InitCarrierFrequency"},
+        {"DPInit", "InitElapsedCodePeriods", "cuChanMgr", "InitElapsedCodePeriods"},
+        {"DPInit", "InitReferenceCodePeriods", "cuChanMgr", "InitReferenceCodePeriods"},
+        {"DPInit", "InitCPRefTOW", "cuChanMgr", "InitCPRefTOW"},
+        {"DPInit", "InitRXTime", "cuChanMgr", "InitRXTime"},
+        {"SampleBlock", "Samples", "BatchCorrScores", "Samples"},
+        {"SampleBlock", "SamplingFrequency", "BatchCorrScores", "SamplingFrequency"},
+        {"SampleBlock", "SampleLength", "BatchCorrScores", "SampleLength"},
+        {"SampleBlock", "SamplingFrequency", "BatchCorrManifold", "SamplingFrequency"},
+        {"SampleBlock", "SampleLength", "BatchCorrManifold", "SampleLength"},
+        {"SampleBlock", "SampleLength", "cuChanMgr", "SampleLength"},
+        {"BatchCorrScores", "CodeScores", "BatchCorrManifold", "CodeScores"},
+        {"BatchCorrScores", "CarrScores", "BatchCorrManifold", "CarrScores"},
+        {"BatchCorrScores", "NumFFTPoints", "BatchCorrManifold", "NumFFTPoints"},
+        {"cuChanMgr", "ValidPRNs", "BatchCorrScores", "ValidPRNs"},              // (device arrays, dpeflow.cpp:169-191)
+        {"cuChanMgr", "CodeFrequency", "BatchCorrManifold", "CodeFrequency"},
+    };
+    for (auto &w : wires) CHECK(flow.ConnectPort(w[0], w[1], w[2], w[3]));
+    std::clog << "[DPEFlow] Completed LoadFlow, device loop. (L=" << L << ", B=" << B << ", fix lag " << fixLag << ")" << std::endl;
+    if (device >= 0) CHECK(dpe_set_device(device));
+    dpe_stream_t stream = nullptr;
+    CHECK(dpe_stream_create(&stream));
+    CHECK(flow.Start(stream));
+    flow.EnableTiming(timing);
+    int n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (n < iters && flow.Step() == 0) ++n;
+    chm->Drain();                                            // the fixes still on their way (before any module stops)
+    dpe_stream_synchronize(stream);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    flow.ReportTiming(std::clog);
+    flow.Stop();
+    dpe_stream_destroy(stream);
+    std::clog << "[DPEFlow] " << n << " iterations, " << (n ? dt / n * 1e6 : 0.0) << " us per iteration ("
+              << (n ? n * T / dt : 0.0) << " x real time, closed loop on the device, one window per Update)" << std::endl;
+    return n > 0 ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
     std::string samples, handoff, out = "XFile.csv", loadGrid, rinex, rendezvous, commName = "rccl";
     int ranks = 1, rank = 0, device = -1;
     double fs = 2.5e6, T = 0.02;
     int iters = 3000, gridDim = 25, gridType = 0, lpower = 1;
-    bool useGraph = false, timing = false, enableEkf = false, shardStage1 = false;
+    bool useGraph = false, timing = false, enableEkf = false, shardStage1 = false, deviceLoop = false;
+    int fixLag = 8;
     float spacing = 1.0f, delta[4] = {0, 0, 0, 0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -88,6 +180,8 @@ int main(int argc, char **argv)
         else if (a == "--shard-stage1") { shardStage1 = true; }
         else if (a == "--timing") { timing = true; }
         else if (a == "--ekf") { enableEkf = true; }
+        else if (a == "--device-loop") { deviceLoop = true; }
+        else if (a == "--fix-lag") { fixLag = std::atoi(next()); ++i; }
         else if (a == "--init-delta") { next(4); for (int j = 0; j < 4; ++j) delta[j] = (float)std::atof(argv[i + 1 + j]); i += 4; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -114,6 +208,12 @@ int main(int argc, char **argv)
         }
     }
 
+    if (deviceLoop && (enableEkf || ranks > 1 || !rendezvous.empty() || useGraph)) {
+        std::fprintf(stderr, "[DPEFlow] --device-loop runs the shipped pass-through filter on one GPU (not with --ekf / --ranks / --graph)\n");
+        return 2;
+    }
+    if (deviceLoop) return run_device_loop(samples, handoff, out, rinex, loadGrid, fs, T, iters, gridDim, gridType, lpower, spacing, delta, L, B,
+                                           fixLag, device, timing);
     dsp::Flow flow;                                             // dpeflow.cpp:55-62
     flow.Add(new dsp::DPInit);
     flow.Add(new dsp::SampleBlock);

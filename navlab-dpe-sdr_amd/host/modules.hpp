@@ -10,8 +10,12 @@
 //   cuChanMgr         -> dpe_chm_*                             cudarecv/modules/src/cuchanmgr.cu:930-1268
 //   DataLogger        CSV rows of one port                     cudarecv/modules/src/datalogger.cu:156-203
 //
-// Port-level difference from the reference: channel-parameter ports are HOST arrays (the reference's
-// cuChanMgr publishes device arrays); sample / score-bank ports are device pointers as before.
+//   cuChanMgrDev      -> dpe_chm_dev_*  (device loop)          cuchanmgr.cu:1100-1132,1237-1264 + cuekf.cu:147-159 + batchcorrmanifold.cu:1977-2068
+//
+// Port-level difference from the reference: with cuChanMgr the channel-parameter ports are HOST arrays; with cuChanMgrDev
+// (dpe_flow --device-loop) they are device arrays as in the reference, the measurement / pass-through / channel update run in
+// one kernel behind the scan, and no module waits for the GPU: the fixes arrive through a pinned ring a few windows later.
+// Sample / score-bank ports are device pointers in both.
 #pragma once
 #include <fcntl.h>
 #include <unistd.h>
@@ -154,6 +158,9 @@ class SampleBlock : public Module {
         InsertParam("Hostname", Hostname, CHAR_t, sizeof(Hostname), 0);
         InsertParam("PortNo", &PortNo, INT_t, sizeof(int), sizeof(int));
         InsertParam("InputSourceType", &InputSourceType, CHAR_t, sizeof(char), sizeof(char));
+        // device loop: the consumer may be this many windows behind the flow thread, so a block goes back to the reader that
+        // many Updates after it was handed out (0: at the next Update, the reference's behaviour)
+        InsertParam("ReleaseLag", &ReleaseLag, INT_t, sizeof(int), sizeof(int));
     }
     ~SampleBlock() override { Stop(); }
     int Start(void *) override
@@ -175,7 +182,7 @@ class SampleBlock : public Module {
         }
         outputs[0].VectorLength = BlockLength;
         stop = eof = false;
-        load = 0; proc = -1;
+        load = 0; proc = -1; handed = 0;
         running = true;
         reader = std::thread(&SampleBlock::ReaderLoop, this);
         return 0;
@@ -184,7 +191,12 @@ class SampleBlock : public Module {
     {
         if (!running) DPE_MOD_FAIL("Update: not started");
         std::unique_lock<std::mutex> lk(mtx);
-        if (proc >= 0) { ring[proc].ready = false; cvFree.notify_one(); }   // hand the consumed block back
+        if (ReleaseLag < 0 || ReleaseLag > kNumBlocks - 4) DPE_MOD_FAIL("ReleaseLag " << ReleaseLag << " not in [0, " << kNumBlocks - 4 << "]");
+        if (handed > ReleaseLag) {   // hand the block consumed ReleaseLag Updates ago back
+            ring[(proc - ReleaseLag + kNumBlocks) % kNumBlocks].ready = false;
+            cvFree.notify_one();
+        }
+        ++handed;
         proc = (proc + 1) % kNumBlocks;
         // 1.5 s watchdog as in the reference (sampleblock.cu:484)
         if (!cvReady.wait_for(lk, std::chrono::milliseconds(1500), [&] { return ring[proc].ready || eof; }))
@@ -248,7 +260,8 @@ class SampleBlock : public Module {
     char Hostname[64] = "";
     int PortNo = 0;
     char InputSourceType = 0;   // 0 = file
-    int fd = -1, load = 0, proc = -1;
+    int fd = -1, load = 0, proc = -1, ReleaseLag = 0;
+    long long handed = 0;
     uint32_t BlockLength = 0;
     size_t bytes = 0;
     Slot ring[kNumBlocks];
@@ -284,6 +297,8 @@ class BatchCorrScores : public Module {
         InsertParam("BinHalfWidth", &binHalf, INT_t, sizeof(int), sizeof(int));
         InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
         InsertParam("SyncOutputs", &syncOutputs, BOOL_t, sizeof(bool), sizeof(bool));
+        // device loop: the channel block is written on the device by cuChanMgrDev (dpe_bcs_update_prepared)
+        InsertParam("DeviceLoop", &deviceLoop, BOOL_t, sizeof(bool), sizeof(bool));
         // multi-GPU (one flow per GPU, SURVEY 8e "shard SVs in stage 1 and all-gather the banks"): with ShardStage1 this flow
         // correlates channels [ShardRank K / ShardCount, (ShardRank + 1) K / ShardCount) and dpe_bcs_allgather_banks fills the
         // full banks the ports point at.  A closed loop has one window per Update, so the stage-1 shard is by channel.
@@ -342,6 +357,10 @@ class BatchCorrScores : public Module {
         if (!Started) DPE_MOD_FAIL("Error: Update() Failed due to batch correlator not initialized");
         const int K = (int)inputs[1]->VectorLength;                        // numChan, :994
         if (K < 1 || K > DPE_MAX_CHAN) DPE_MOD_FAIL("Update: bad channel count");
+        if (deviceLoop) {
+            if (dpe_bcs_update_prepared(h, (const int16_t *)inputs[0]->Data, K, flow_stream(flowStream))) { Stop(); return -1; }
+            return 0;
+        }
         dpe_chan_start ch[DPE_MAX_CHAN];
         for (int k = 0; k < K; ++k) {
             ch[k].prn = ((const uint8_t *)inputs[1]->Data)[k];
@@ -393,9 +412,11 @@ class BatchCorrScores : public Module {
         return 0;
     }
 
+    dpe_bcs *Handle() const { return h; }
+
   private:
     dpe_bcs *h = nullptr;
-    bool Started = false;
+    bool Started = false, deviceLoop = false;
     bool shardStage1 = false, sharded = false;
     int shardRank = 0, shardCount = 1, commBackend = DPE_COMM_RCCL, shardK = 0;
     char commRendezvous[512] = "";
@@ -434,6 +455,7 @@ class BatchCorrManifold : public Module {
         InsertParam("LoadPosGridFilename", loadPosGridFilename, CHAR_t, sizeof(loadPosGridFilename), 0);
         InsertParam("UseGraph", &useGraph, BOOL_t, sizeof(bool), sizeof(bool));
         InsertParam("ReferencePair", &referencePair, BOOL_t, sizeof(bool), sizeof(bool));   // dpe_bcm_config.referencePair
+        InsertParam("DeviceLoop", &deviceLoop, BOOL_t, sizeof(bool), sizeof(bool));         // coefficient blocks from cuChanMgrDev, no wait for the fix
         // multi-GPU (one flow per GPU): this flow scores grid shard ShardRank of ShardCount and exchanges the arg-max
         InsertParam("ShardRank", &shardRank, INT_t, sizeof(int), sizeof(int));
         InsertParam("ShardCount", &shardCount, INT_t, sizeof(int), sizeof(int));
@@ -498,6 +520,10 @@ class BatchCorrManifold : public Module {
         if (!Started) DPE_MOD_FAIL("Error: Update() Failed due to SatPos not initialized");
         const int K = (int)inputs[8]->VectorLength;
         const int dimT = (int)timeGrid.size();
+        if (deviceLoop) {   // the measurement is formed behind the scan by cuChanMgrDev's kernel; nothing to wait for here
+            if (dpe_bcm_update_prepared(h, (const float *)inputs[0]->Data, (const float *)inputs[1]->Data, K, flow_stream(flowStream))) { Stop(); return -1; }
+            return 0;
+        }
         dpe_bcm_window win = {};
         std::memcpy(win.xCurrkk1, inputs[2]->Data, sizeof(double) * 8);                                    // re-read every Update, :2540
         std::memcpy(win.enu2ecef, inputs[12]->Data, sizeof(double) * 9);
@@ -539,6 +565,8 @@ class BatchCorrManifold : public Module {
         return 0;
     }
     const dpe_bcm_result &LastResult() const { return last; }
+    dpe_bcm *Handle() const { return h; }
+    const std::vector<double> &TimeGrid() const { return timeGrid; }
     const std::vector<double> &PosGrid() const { return posGrid; }
     const std::vector<double> &VelGrid() const { return velGrid; }
 
@@ -546,7 +574,7 @@ class BatchCorrManifold : public Module {
     dpe_bcm *h = nullptr;
     bool Started = false, loadPosGrid = false;
     int posDim = 25, velDim = 25, gridType = 0, LPower = 1;
-    bool useGraph = false;
+    bool useGraph = false, deviceLoop = false;
     bool referencePair = false;   // reproduce the reference's floor(idx) / floor(idx + 1) pair where it double-counts (dpe_hip.h)
     int shardRank = 0, shardCount = 1, commBackend = DPE_COMM_RCCL;
     char commRendezvous[512] = "";
@@ -717,6 +745,138 @@ class cuChanMgr : public Module {
     std::vector<double> batch, rcS, riS, rcE, fc, fi;
     std::vector<uint8_t> prn;
     std::vector<int> cpRef, cpS, cpE, tow;
+};
+
+// ------------------------------------------------------------------------------------------------
+// cuChanMgr as the reference has it -- device state, device port arrays -- with the measurement hand-over (BCM_MakePosMeas /
+// MakeVelMeas), the pass-through filter (EKF_PassMeas, EnableEKF = false) and the channel update in ONE kernel behind the scan
+// (dpe_chm_dev_step).  Update() only enqueues; the fix of window n - FixLag is collected from the pinned ring and written to the
+// X-file (the XECEFLogger's "%f, " rows, datalogger.cu:160-203), the rest at Stop().
+class cuChanMgrDev : public Module {
+  public:
+    cuChanMgrDev(BatchCorrScores *bcs_, BatchCorrManifold *bcm_) : bcs(bcs_), bcm(bcm_)
+    {
+        ModuleName = "cuChanMgr";
+        AllocateInputs(12);
+        AllocateOutputs(18);
+        const char *in[12] = {"InitEph", "InitPRN", "InitCodePhase", "InitCarrierPhase", "InitCodeFrequency", "InitCarrierFrequency",
+                              "InitElapsedCodePeriods", "InitReferenceCodePeriods", "InitCPRefTOW", "InitRXTime", "InitX", "SampleLength"};
+        const DataType_t idt[12] = {UNDEFINED_t, CHAR_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, INT_t, INT_t, INT_t, DOUBLE_t, DOUBLE_t, DOUBLE_t};
+        const ValueType_t ivt[12] = {EPHEMS, VALUE, VALUE, VALUE, FREQUENCY_HZ, FREQUENCY_HZ, VALUE, VALUE, VALUE, VALUE, STATE, VALUE};
+        for (int i = 0; i < 12; ++i) ConfigExpectedInput(i, in[i], idt[i], ivt[i], i == 11 ? 1 : VECTORLENGTH_ANY);
+        InsertParam("DopplerSign", &dopplerSign, INT_t, sizeof(int), sizeof(int));
+        InsertParam("FixLag", &fixLag, INT_t, sizeof(int), sizeof(int));
+        InsertParam("XFilename", xFilename, CHAR_t, sizeof(xFilename), 0);
+        const char *out[18] = {"rxTime", "txTime", "CodePhaseStart", "CarrierPhaseStart", "CodePhaseEnd", "CarrierPhaseEnd",
+                               "CodeFrequency", "CarrierFrequency", "SatStates", "DopplerSign", "ValidPRNs", "cpReference",
+                               "cpElapsedStart", "cpElapsedEnd", "ENU2ECEFMat", "SatStatesOld", "cpRef", "cpRefTOW"};
+        const DataType_t odt[18] = {DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, INT_t,
+                                    CHAR_t, INT_t, INT_t, INT_t, DOUBLE_t, DOUBLE_t, INT_t, INT_t};
+        const ValueType_t ovt[18] = {VALUE, VALUE, VALUE, VALUE, VALUE, VALUE, FREQUENCY_HZ, FREQUENCY_HZ, STATE, VALUE, VALUE, VALUE,
+                                     VALUE, VALUE, VALUE, STATE, VALUE, VALUE};
+        for (int i = 0; i < 18; ++i) ConfigOutput(i, out[i], odt[i], ovt[i], HIP_DEVICE, i == 0 || i == 9 ? 1 : (i == 14 ? 9 : VECTORLENGTH_ANY), nullptr, 0);   // cuchanmgr.cu:973-990
+    }
+    ~cuChanMgrDev() override { Stop(); }
+    int Start(void *flowStream) override
+    {
+        if (h) { std::clog << "[" << ModuleName << "] Start: Already Started." << std::endl; return 0; }
+        for (int i = 0; i < 12; ++i)
+            if (!inputs[i]) DPE_MOD_FAIL("Start: input " << expectedInputs[i].Name << " not connected");
+        if (!bcs || !bcm || !bcs->Handle() || !bcm->Handle()) DPE_MOD_FAIL("Start: BatchCorrScores / BatchCorrManifold must be started first");
+        if (fixLag < 1 || fixLag > 24) DPE_MOD_FAIL("Start: FixLag " << fixLag << " not in [1, 24]");
+        K = (int)inputs[1]->VectorLength;
+        std::vector<dpe_chm_init_chan> init(K);
+        for (int k = 0; k < K; ++k) {
+            init[k].prn = ((const uint8_t *)inputs[1]->Data)[k];
+            init[k].codePhase = ((const double *)inputs[2]->Data)[k];
+            init[k].carrierPhase = ((const double *)inputs[3]->Data)[k];
+            init[k].codeFrequency = ((const double *)inputs[4]->Data)[k];
+            init[k].carrierFrequency = ((const double *)inputs[5]->Data)[k];
+            init[k].cpElapsed = ((const int *)inputs[6]->Data)[k];
+            init[k].cpReference = ((const int *)inputs[7]->Data)[k];
+            init[k].cpRefTOW = ((const int *)inputs[8]->Data)[k];
+            std::memcpy(init[k].eph, (const double *)inputs[0]->Data + (size_t)k * DPE_EPH_N, sizeof(double) * DPE_EPH_N);
+        }
+        const std::vector<double> &tg = bcm->TimeGrid();
+        dpe_chm_config cfg = {K, dopplerSign, *(double *)inputs[11]->Data, *(double *)inputs[9]->Data};
+        if (dpe_chm_dev_create(&cfg, init.data(), tg.data(), (int32_t)tg.size(), &h)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+        if (dpe_chm_dev_attach(h, bcs->Handle(), bcm->Handle(), fixLag + 8)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+        if (xFilename[0]) {
+            fp = std::fopen(xFilename, "w");
+            if (!fp) DPE_MOD_FAIL("Unable to open file: " << xFilename);
+        }
+        if (dpe_chm_dev_start(h, (const double *)inputs[10]->Data, flow_stream(flowStream))) DPE_MOD_FAIL("Start: " << dpe_last_error());
+        dpe_bcs_ports_dev pb;
+        dpe_bcm_ports_dev pm;
+        const double *rx = nullptr, *z = nullptr;
+        double *x1 = nullptr, *xk = nullptr;
+        dpe_chm_dev_ports(h, &pb, &pm, &rx, &x1, &xk, &z);
+        const uint32_t uK = (uint32_t)K, dimT = (uint32_t)tg.size();
+        UpdateOutput(0, 1, (void *)rx, 0);                       UpdateOutput(2, uK, (void *)pb.codePhaseStart, 0);
+        UpdateOutput(3, uK, (void *)pb.carrierPhaseStart, 0);    UpdateOutput(4, uK, (void *)pm.codePhaseEnd, 0);
+        UpdateOutput(6, uK, (void *)pb.codeFrequency, 0);        UpdateOutput(7, uK, (void *)pb.carrierFrequency, 0);
+        UpdateOutput(8, uK * dimT, (void *)pm.satStates, 0);     UpdateOutput(9, 1, (void *)pm.dopplerSign, 0);
+        UpdateOutput(10, uK, (void *)pb.validPRNs, 0);           UpdateOutput(11, uK, (void *)pb.cpReference, 0);
+        UpdateOutput(12, uK, (void *)pb.cpElapsedStart, 0);      UpdateOutput(13, uK, (void *)pm.cpElapsedEnd, 0);
+        UpdateOutput(14, 9, (void *)pm.enu2ecef, 0);             UpdateOutput(16, uK, (void *)pm.cpRef, 0);
+        UpdateOutput(17, uK, (void *)pm.cpRefTOW, 0);
+        // txTime (1), CarrierPhaseEnd (5), SatStatesOld (15): not consumed by the active kernels
+        UpdateOutput(1, uK, (void *)pm.codePhaseEnd, 0); UpdateOutput(5, uK, (void *)pb.carrierPhaseStart, 0); UpdateOutput(15, uK * dimT, (void *)pm.satStates, 0);
+        enq = got = 0;
+        return 0;
+    }
+    int Update(void *flowStream) override
+    {
+        if (!h) DPE_MOD_FAIL("Error: Update() Failed due to SatPos not initialized");
+        if (dpe_chm_dev_step(h, flow_stream(flowStream))) DPE_MOD_FAIL("Update: " << dpe_last_error());
+        ++enq;
+        while (enq - got > fixLag)
+            if (Collect(-1)) return -1;
+        return 0;
+    }
+    // Collects the fixes still on their way.  Call before the flow stops.
+    int Drain()
+    {
+        while (h && got < enq)
+            if (Collect(2000000)) return -1;
+        return 0;
+    }
+    int Stop() override
+    {
+        if (h) {
+            if (got < enq) std::clog << "[" << ModuleName << "] Stop: " << (enq - got) << " fixes not collected (Drain() before Stop)" << std::endl;
+            dpe_chm_dev_destroy(h);
+        }
+        h = nullptr;
+        if (fp) std::fclose(fp);
+        fp = nullptr;
+        return 0;
+    }
+    const dpe_fix_record &LastFix() const { return last; }
+    long long Collected() const { return got; }
+
+  private:
+    int Collect(int timeoutMicros)
+    {
+        dpe_fix_record r;
+        const int rc = dpe_chm_dev_fix(h, got, &r, timeoutMicros);
+        if (rc) { std::cerr << "[" << ModuleName << "] fix " << got << ": " << (rc == 1 ? "timed out" : dpe_last_error()) << std::endl; return -1; }
+        if (r.status && !warned) { std::clog << "[" << ModuleName << "] status " << r.status << " at window " << got << std::endl; warned = true; }
+        if (fp)
+            for (int i = 0; i < 8; ++i) std::fprintf(fp, i + 1 < 8 ? "%f, " : "%f\n", r.zVal[i]);
+        last = r;
+        ++got;
+        return 0;
+    }
+    BatchCorrScores *bcs;
+    BatchCorrManifold *bcm;
+    dpe_chm_dev *h = nullptr;
+    int K = 0, dopplerSign = 1, fixLag = 8;
+    long long enq = 0, got = 0;
+    bool warned = false;
+    char xFilename[512] = "";
+    FILE *fp = nullptr;
+    dpe_fix_record last = {};
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -1,5 +1,7 @@
 """Closed-loop latency of the C++ flow (host/dpe_flow): one window per Update, fix fed back to the channel
-manager, on a synthetic sample file.  Prints us per iteration for a 9^4 and the reference-default 25^4 grid."""
+manager, on a synthetic sample file.  Prints us per iteration for a 9^4 and the reference-default 25^4 grid: host-driven
+loop (cuChanMgr / cuEKF on the host, the fix read back every window), the same with hipGraph replay, and --device-loop
+(cuChanMgr on the device, nothing read back; rows must equal the host-driven loop's)."""
 import sys, os, subprocess, numpy as np, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import navlab_dpe_sdr_amd as dpe
@@ -12,9 +14,14 @@ with open(dpe.workload.HANDOFF_CSV) as f, open(ho_path, "w") as g:
     for line in f:
         g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
 exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
-for dim, extra in ((9, []), (9, ["--graph"]), (25, []), (25, ["--graph"])):
-    r = subprocess.run([exe, "--samples", dat, "--handoff", ho_path, "--out", os.path.join(d, "X.csv"), "--iters", str(W), "--grid-dim", str(dim), "--spacing", "1.0"] + extra, capture_output=True, text=True)
+base = {}
+for dim, extra in ((9, []), (9, ["--device-loop"]), (9, ["--graph"]), (25, []), (25, ["--device-loop"]), (25, ["--device-loop", "--fix-lag", "2"]), (25, ["--graph"])):
+    r = subprocess.run([exe, "--samples", dat, "--handoff", ho_path, "--out", os.path.join(d, "X.csv"), "--iters", str(W), "--grid-dim", str(dim), "--spacing", "1.0"] + extra, capture_output=True, text=True, timeout=120)
     print(dim, extra, [l for l in r.stderr.splitlines() if "iterations" in l or "LoadFlow" in l])
     rows = np.loadtxt(os.path.join(d, "X.csv"), delimiter=",")
     ho = dpe.handoff.read_handoff(ho_path)
     print("  max |fix - truth| m:", np.abs(rows[:, :3] - ho["X_ECEF"][:3]).max(), "rows", rows.shape)
+    if not extra:
+        base[dim] = rows
+    elif extra[0] == "--device-loop":
+        print("  max |fix - host-driven loop| m:", np.abs(rows - base[dim]).max())

@@ -4,8 +4,9 @@ the host form dpe_chm_* (itself pinned by the oracle and fixtures O4 / O5 / O7, 
 reads nothing back per window against the host-driven loop.
 
 Tolerances.  The two forms share their functions; what differs is the maths library (sin / cos / atan2 of the device against
-glibc's: last-bit differences) and the satellite states, which the device form advances from an expansion made ahead of the
-window (second-order remainder 3e-11 m).  Frequencies, phases, satellite states, ENU matrix: 1e-12 relative.  Code phases:
+glibc's: last-bit differences) and the satellite states: the device form starts its Kepler iterations from the previous
+window's anomaly (same fixed point) and takes a window's second state from the first along a difference quotient (remainder
+3e-11 m).  Frequencies, phases, satellite states, ENU matrix: 1e-12 relative.  Code phases:
 the reference forms them as (rxTime - pr / C - ...) x 1.023e6 with rxTime ~ 4e5 s, i.e. on a 5.8e-11 s = 6e-5 chip raster
 (DESIGN.md 2.5); a last-bit difference in pr can move the result by one step of that raster, so they are held to 1e-4 chips
 (in the cases below they agree to 1e-9)."""
@@ -48,15 +49,11 @@ def _compare(dev, host, K):
     return worst
 
 
-@pytest.mark.parametrize("ahead", [True, False])
-def test_device_channel_manager_matches_the_host_form(monkeypatch, ahead):
+@pytest.mark.parametrize("K", [8, 1])
+def test_device_channel_manager_matches_the_host_form(K):
     """Start + 5 Updates with a moving fix (tens of metres and m/s per window, clock terms included), time grid of 9 entries:
-    every port of the device form against dpe_chm_outputs.  ahead = False (DPE_CHM_NO_AHEAD=1 at create) evaluates every
-    satellite state inside the per-window kernel, as the reference does; ahead = True is the shipped form."""
+    every port of the device form against dpe_chm_outputs."""
     import torch
-    if not ahead:
-        monkeypatch.setenv("DPE_CHM_NO_AHEAD", "1")
-    K = 8
     ho = dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV)
     T = 0.02
     tg = np.linspace(-12.0, 12.0, 9)
@@ -74,7 +71,7 @@ def test_device_channel_manager_matches_the_host_form(monkeypatch, ahead):
         a, b = torch.from_numpy(x1).to("cuda:0"), torch.from_numpy(xk).to("cuda:0")
         dev.Update(a, b)
         w = _compare(dev.outputs(with_batch=True), host.outputs(with_batch=True), K)
-        assert dev.status == 0, dev.status     # no Kepler failure, no transmit time outside the expansion's range
+        assert dev.status == 0, dev.status     # no Kepler failure
         x = x1
     print("worst differences after 5 Updates:", {k: float("%.3g" % v) for k, v in w.items()})
     dev.Stop(); host.Stop()
@@ -140,3 +137,27 @@ def test_device_ports_feed_the_dev_update_forms():
     a, b = out
     assert a["posIndex"] == b["posIndex"] and a["velIndex"] == b["velIndex"] and a["posScore"] == b["posScore"] and a["velScore"] == b["velScore"]
     assert np.array_equal(a["zVal"], b["zVal"])
+
+
+def test_cpp_flow_device_loop_matches_the_host_driven_flow(tmp_path):
+    """host/dpe_flow --device-loop (cuChanMgrDev module: device ports, one kernel behind the scan, fixes from the pinned ring,
+    the flow thread 3 windows ahead) writes the X-file rows of the host-driven flow (cuChanMgr + cuEKF + XECEFLogger)."""
+    import os
+    import subprocess
+    W, fs, S, K = 30, 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=5, amp=200.0)
+    dat = str(tmp_path / "synthetic_2500kHz.dat")
+    iq.tofile(dat)
+    ho_path = str(tmp_path / "handoff.csv")
+    with open(dpe.workload.HANDOFF_CSV) as f, open(ho_path, "w") as g:
+        for line in f:
+            g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
+    rows = {}
+    for name, extra in (("host", []), ("dev", ["--device-loop", "--fix-lag", "3"]), ("dev1", ["--device-loop", "--fix-lag", "1"])):
+        out = str(tmp_path / ("X_%s.csv" % name))
+        subprocess.check_call([exe, "--samples", dat, "--handoff", ho_path, "--out", out, "--iters", str(W), "--grid-dim", "9",
+                               "--spacing", "1.0", "--init-delta", "2", "-1", "1", "3"] + extra)
+        rows[name] = np.loadtxt(out, delimiter=",")
+        assert rows[name].shape == (W, 8)
+    assert np.array_equal(rows["dev"], rows["host"]) and np.array_equal(rows["dev1"], rows["host"])     # "%f" rows
