@@ -127,13 +127,15 @@ def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0):
     return out
 
 
-def acq_line(modes=("coherent", "textbook"), cpu_budget_s=5.0):
+def acq_line(modes=("coherent", "textbook", "noncoherent"), cpu_budget_s=5.0):
     """Cold-start acquisition (BASELINE.json configs[4]) as a measured line: 32 PRNs x 125 Doppler bins x all
     2500 code delays of a 10 ms / 2.5 Msps window, the whole search (wipe-off + fold, forward rocFFT, spectrum product + inverse
     transforms + |.| surface + per-delay maximum -- one fused kernel in the coherent mode --, peak statistics) timed between HIP
     events on its stream.
     `value` = search cells (PRN x bin x delay) per second of the reference's coherent semantics (fixture O8); `modes` holds the
-    textbook "1 ms coherent x 10 non-coherent" form too (BASELINE's wording; not a reference algorithm).  Roofline: the
+    textbook "1 ms coherent x 10 non-coherent" form too (BASELINE's wording; not a reference algorithm) and the reference's
+    non-coherent mode (coherent = False: one 25 000-point correlation per bin, |.| over the ten lag aliases) -- on the same 125-bin
+    raster, and on the raster the reference itself uses for it (25 bins x 500 Hz, correlator.py:13).  Roofline: the
     search is memory-bound by construction -- its batched transforms are 6e8 flop per window against 40 MB of surface -- so the
     stanza prices the algorithmic bytes (samples read once + the |.| surface written once) against the HBM peak and quotes
     the transform flop rate beside it.  cpu_baseline: the oracle's numpy restatement of coarse_acquisition on a bounded sample."""
@@ -173,6 +175,20 @@ def acq_line(modes=("coherent", "textbook"), cpu_budget_s=5.0):
             found = sorted(r["prn"] for r in res if r["found"])
             assert found == sorted(int(p) for p in ch["prn"]), "acquisition did not find the simulated PRNs"
         del acq
+        if mode == "noncoherent":     # ... and on DOPPLER_SEARCH_MATRIX_NONCOHERENT, the raster the reference pairs with this mode
+            b25 = np.arange(-12, 13) * 500.0
+            acq = dpe.Acquisition(fs, S, prns, b25, mode=mode, prn_chunk=32)
+            for _ in range(5):
+                acq.search(d)
+            torch.cuda.synchronize()
+            t = dpe.engine.HipEventTimer()
+            t.start()
+            for _ in range(n):
+                acq.search(d)
+            t.stop()
+            ms25 = t.elapsed_ms() / n
+            per_mode["noncoherent_25x500Hz"] = {"ms_per_window": ms25, "cells_per_s": len(prns) * b25.size * M / (ms25 * 1e-3)}
+            del acq
     ms0 = per_mode[modes[0]]["ms_per_window"]
     alg_bytes = 4.0 * S + 4.0 * cells                    # int16 I/Q once + the fp32 |.| surface once
     n_fft = bins.size + len(prns) * bins.size            # forward (time-folded rows) + inverse transforms of length M

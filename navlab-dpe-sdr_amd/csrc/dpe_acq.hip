@@ -180,8 +180,14 @@ constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequ
 // nSeg = 1: X[b][2500] holds the time-folded window (coherent mode).  nSeg = N: X[b][N][2500] holds the N code periods
 // of the window (textbook mode, "1 ms coherent x N non-coherent"): the magnitudes of the N transforms are summed in
 // registers -- a thread's ten outputs have the same indices in every segment -- before they go out.
+// ALIAS (the reference's coherent = False at 10 x 2 500 samples, correlator.py:77-82): one 25 000-point correlation per (PRN,
+// bin), surface[j] = sum_n |y[j + 2500 n]|.  X = Z[p][b][k0][2500], the output of acq_radix10_kernel -- product and first
+// decimation-in-frequency stage already applied -- so y[10 m' + k0] = IFFT2500(Z[..][k0])[m'] and the ten lag aliases of delay
+// j = 10 r + k0 are the outputs r + 250 n of transform k0: exactly the ten values thread r holds.  nSeg = 10 transforms per
+// (PRN, bin), no multiply, each transform's ten-fold sums written at stride 10.
+template <bool ALIAS>
 __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc,
-                                                              const float2 *__restrict__ tw, int B, int nSeg,
+                                                              const float2 *__restrict__ tw, int B, int nSeg, int binsPerBlock, int pOffset,
                                                               float *__restrict__ surf, unsigned int *__restrict__ mpBits)
 {
     constexpr int N = kAcqFusedLen, SS = kAcqSubStride;
@@ -193,11 +199,13 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     if (act) sW250[t] = tw[10 * t];
     if (t < 25) sW25[t] = tw[100 * t];
     // the PRN's spectrum and the pass-1 twiddles W^(t k1) of this thread's ten elements stay in registers across the bins
-    af2 rc[10], w1[10];
+    af2 rc[ALIAS ? 1 : 10], w1[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
-        const float2 r = Rc[(size_t)p * N + tt + 250 * q];
-        rc[q] = af2{r.x, r.y};
+        if constexpr (!ALIAS) {
+            const float2 r = Rc[(size_t)p * N + tt + 250 * q];
+            rc[q] = af2{r.x, r.y};
+        }
         const float2 a = tw[tt * q];   // t k1 <= 249 * 9 < 2500
         w1[q] = af2{a.x, a.y};
     }
@@ -205,10 +213,10 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     float mx[10], macc[2][5];
 #pragma unroll
     for (int q = 0; q < 10; ++q) mx[q] = 0.f;
-    const int b0 = blockIdx.x * kAcqFusedBins;
-    const int nb = (B - b0) < kAcqFusedBins ? (B - b0) : kAcqFusedBins;
-    const int nTr = nb * nSeg;   // transforms of this block: rows b0 nSeg .. of X, consecutive
-    const float2 *x0 = X + (size_t)b0 * nSeg * N;
+    const int b0 = blockIdx.x * binsPerBlock;
+    const int nb = (B - b0) < binsPerBlock ? (B - b0) : binsPerBlock;
+    const int nTr = nb * nSeg;   // transforms of this block: rows b0 nSeg .. of X (ALIAS: of this PRN's Z), consecutive
+    const float2 *x0 = X + ((ALIAS ? (size_t)p * B : (size_t)0) + (size_t)b0) * nSeg * N;
     float2 xn[10];   // the next transform's spectrum, fetched under this one
 #pragma unroll
     for (int q = 0; q < 10; ++q) xn[q] = x0[tt + 250 * q];
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
             // spectrum product (correlator.py:75) and pass 1: radix 10 over the stride-250 elements, twiddle W^(t k1)
             af2 v[10];
 #pragma unroll
-            for (int q = 0; q < 10; ++q) v[q] = acq_cmul(af2{xn[q].x, xn[q].y}, rc[q]);
+            for (int q = 0; q < 10; ++q) v[q] = ALIAS ? af2{xn[q].x, xn[q].y} : acq_cmul(af2{xn[q].x, xn[q].y}, rc[ALIAS ? 0 : q]);
             if (e + 1 < nTr) {
 #pragma unroll
                 for (int q = 0; q < 10; ++q) xn[q] = x0[(size_t)(e + 1) * N + t + 250 * q];
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
         }
         __syncthreads();
         float *sMag = reinterpret_cast<float *>(sB);   // (pass 2's output is consumed: its buffer takes the magnitudes in natural order)
-        const bool last = seg == nSeg - 1;              // block-uniform
+        const bool last = ALIAS || seg == nSeg - 1;     // block-uniform
         if (act) {
             // pass 4: the last radix 5; output index k = k1 + 10 (k2 + 10 (k3a + 5 k3b)), sq = 10 k1 + k2
 #pragma unroll
@@ -289,13 +297,22 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     const float mg = __builtin_amdgcn_sqrtf(d[k].x * d[k].x + d[k].y * d[k].y);   // | . |  (correlator.py:80; v_sqrt_f32, 1 ulp)
-                    macc[h][k] = seg == 0 ? mg : macc[h][k] + mg;
+                    macc[h][k] = (ALIAS || seg == 0) ? mg : macc[h][k] + mg;
                     if (last) sMag[k1 + 10 * (k2 + 10 * (k3a + 5 * k))] = macc[h][k];
                 }
             }
         }
         __syncthreads();   // (also orders this pass's reads of sA before the next transform's pass-1 writes)
-        if (last) {
+        if constexpr (ALIAS) {
+            if (act) {
+                float sv = 0.f;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) sv += sMag[t + 250 * q];   // the ten lag aliases of delay 10 t + seg (correlator.py:80-82)
+                surf[((size_t)(pOffset + p) * B + b) * N + 10 * t + seg] = sv;
+                atomicMax(&mpBits[(size_t)(pOffset + p) * N + 10 * t + seg], __float_as_uint(sv));   // max over the bins (:87)
+            }
+            if (++seg == nSeg) { seg = 0; ++b; }
+        } else if (last) {
             if (act) {
                 float *o = surf + ((size_t)p * B + b) * N;
 #pragma unroll
@@ -309,9 +326,41 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
             // (sB / sMag is rewritten only after the next transform's pass-1 barrier)
         } else ++seg;
     }
-    if (act) {
+    if (!ALIAS && act) {
 #pragma unroll
         for (int q = 0; q < 10; ++q) atomicMax(&mpBits[(size_t)p * N + t + 250 * q], __float_as_uint(mx[q]));
+    }
+}
+
+// The reference's non-coherent search at S = 10 x 2 500: spectrum product (correlator.py:75) and the first, radix-10
+// decimation-in-frequency stage of the 25 000-point inverse transform, twiddles included:
+//     Z[p][b][k0][m] = W^(m k0) sum_q X[b][m + 2500 q] Rc[p][m + 2500 q] W10^(q k0),   W = exp(+j 2 pi / 25000)
+// (n = m + 2500 q, k = k0 + 10 m':  W^(n k) = W^(m k0) W2500^(m m') W10^(q k0)).  The 25 000-point rocFFT pass, the product
+// buffer it transformed in place and the fold pass over it are replaced by this kernel and ten 2 500-point transforms per
+// (PRN, bin) in acq_corr2500_kernel<true>.
+__global__ __launch_bounds__(256) void acq_radix10_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc, const float2 *__restrict__ tw25k,
+                                                         int B, float2 *__restrict__ Z)
+{
+    constexpr int M = kAcqFusedLen, S = 10 * kAcqFusedLen;
+    const int m = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, p = blockIdx.z;
+    if (m >= M) return;
+    const float2 *x = X + (size_t)b * S + m, *r = Rc + (size_t)p * S + m;
+    af2 v[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const float2 a = x[M * q], c = r[M * q];
+        v[q] = acq_cmul(af2{a.x, a.y}, af2{c.x, c.y});
+    }
+    acq_idft10(v);
+    float2 *z = Z + ((size_t)p * B + b) * S + m;
+#pragma unroll
+    for (int k0 = 0; k0 < 10; ++k0) {
+        af2 y = v[k0];
+        if (k0) {
+            const float2 w = tw25k[m * k0];   // m k0 <= 2499 * 9 < 25000
+            y = acq_cmul(y, af2{w.x, w.y});
+        }
+        z[(size_t)k0 * M] = make_float2(y.x, y.y);
     }
 }
 
@@ -602,8 +651,9 @@ struct dpe_acq {
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
     float *surf_d = nullptr, *mp_d = nullptr;
     int *peakIdx_d = nullptr;   // [2][P]: max_code_idx, max_dopp_idx
-    float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused coherent search (acq_corr2500_kernel), else null
-    bool fused = false;
+    float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused searches (acq_corr2500_kernel), else null
+    float2 *tw25k_d = nullptr;  // exp(+j 2 pi n / 25000): the radix-10 stage of the fused non-coherent search
+    bool fused = false, fusedAlias = false;
     dpe::AcqStats *stats_d = nullptr, *stats_h = nullptr;   // per-PRN peak statistics; pinned host copy
     bool searched = false;
     // fine-frequency stage, allocated on first use
@@ -625,7 +675,7 @@ int dpe_acq_destroy(dpe_acq *h)
     h->planFwd.destroy();
     h->planInv.destroy();
     h->planFine.destroy();
-    void *bufs[] = {h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->stats_d};
+    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->stats_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->stats_h) (void)hipHostFree(h->stats_h);
     delete h;
@@ -649,10 +699,16 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     h->len = (cfg->mode == 1) ? h->S : h->M;
     h->SX = (cfg->mode == 0) ? h->M : h->S;
     h->chunk = cfg->prnChunk > 0 ? std::min(cfg->prnChunk, h->P) : std::min(8, h->P);
+    // (the fused non-coherent form wants every PRN in one launch pair -- 32 PRNs x 25 bins: 0.19 ms at one chunk, 0.24 at chunks of
+    //  8, 1.16 at chunks of 1 -- while its stage buffer stays modest: 160 MB at the reference's raster)
+    if (cfg->prnChunk <= 0 && cfg->mode == 1 && h->M == 2500 && h->N == 10 && (size_t)h->P * h->B * h->S * sizeof(float2) <= ((size_t)1 << 30)) h->chunk = h->P;
     const size_t S = h->SX, B = h->B, P = h->P;
     // coherent / textbook search at 2 500 delays per code period: the fused kernel, which needs neither the product buffer nor
     // the inverse plan (DPE_ACQ_NO_FUSED=1 keeps the rocFFT chain, for A/B runs and as the cross-check of the parity tests)
     const bool wantFused = (cfg->mode == 0 || cfg->mode == 2) && h->M == kAcqFusedLen && !getenv("DPE_ACQ_NO_FUSED");
+    // the reference's non-coherent search at 10 x 2 500 samples: radix-10 stage + ten fused 2 500-point transforms per (PRN, bin);
+    // the product buffer holds the radix-10 stage's output, no inverse plan
+    const bool wantAlias = cfg->mode == 1 && h->M == kAcqFusedLen && h->N == 10 && !getenv("DPE_ACQ_NO_FUSED");
     h->X_d = dev_alloc<float2>(B * S);
     h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
     h->Y_d = dev_alloc<float2>(wantFused ? 1 : (size_t)h->chunk * B * S);
@@ -667,7 +723,8 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         return -1;
     }
     const int batchFwd = (int)(B * (S / h->len)), batchInv = (int)(h->chunk * B * (S / h->len));
-    if (h->planFwd.create((size_t)h->len, (size_t)batchFwd, false) || (!wantFused && h->planInv.create((size_t)h->len, (size_t)batchInv, true))) {
+    if (h->planFwd.create((size_t)h->len, (size_t)batchFwd, false) ||
+        (!wantFused && !wantAlias && h->planInv.create((size_t)h->len, (size_t)batchInv, true))) {
         dpe_acq_destroy(h);   // (the message is rocFFT's, from dpe_fft.h)
         return -1;
     }
@@ -697,7 +754,19 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     };
     int rc = finish();
     pr.destroy();
-    if (!rc && wantFused) {
+    if (!rc && wantAlias) {
+        std::vector<float2> tw(10 * kAcqFusedLen);
+        for (int n = 0; n < 10 * kAcqFusedLen; ++n) {
+            const double a = 6.283185307179586476925286766559 * (double)n / (double)(10 * kAcqFusedLen);
+            tw[n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        h->tw25k_d = dev_alloc<float2>(tw.size());
+        if (!h->tw25k_d || hipMemcpy(h->tw25k_d, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("[Acquisition] create: twiddle table");
+            rc = -1;
+        } else h->fusedAlias = true;
+    }
+    if (!rc && (wantFused || wantAlias)) {
         std::vector<float2> tw(kAcqFusedLen);
         for (int n = 0; n < kAcqFusedLen; ++n) {
             const double a = 6.283185307179586476925286766559 * (double)n / (double)kAcqFusedLen;
@@ -707,7 +776,7 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         if (!h->tw_d || hipMemcpy(h->tw_d, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess) {
             set_error("[Acquisition] create: twiddle table");
             rc = -1;
-        } else h->fused = true;
+        } else h->fused = wantFused;
     }
     if (rc) {
         dpe_acq_destroy(h);
@@ -731,10 +800,18 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                            h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M);
     if (h->planFwd.exec(st, h->X_d)) return -1;
     if (h->fused)
-        hipLaunchKernelGGL(acq_corr2500_kernel, dim3((B + kAcqFusedBins - 1) / kAcqFusedBins, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
-                           B, h->cfg.mode == 0 ? 1 : h->N, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+        hipLaunchKernelGGL(acq_corr2500_kernel<false>, dim3((B + kAcqFusedBins - 1) / kAcqFusedBins, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
+                           B, h->cfg.mode == 0 ? 1 : h->N, kAcqFusedBins, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
+        if (h->fusedAlias) {
+            hipLaunchKernelGGL(acq_radix10_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->X_d, h->Rc_d + (size_t)p0 * h->len, h->tw25k_d,
+                               B, h->Y_d);
+            // one bin per block: 10 transforms each, B x pc blocks (25 x 32 = 800 at the reference's raster: one round of the chip)
+            hipLaunchKernelGGL(acq_corr2500_kernel<true>, dim3(B, pc), dim3(256), 0, st, h->Y_d, (const float2 *)nullptr, h->tw_d, B, h->N, 1, p0,
+                               h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+            continue;
+        }
         hipLaunchKernelGGL(acq_mul_kernel, dim3((S + 1023) / 1024, B, pc), dim3(256), 0, st, h->X_d,
                            h->Rc_d + (size_t)p0 * h->len, S, h->len, B, h->Y_d);
         // a short last chunk still runs the full-batch plan over stale rows; they are never read
@@ -749,7 +826,9 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         const double posLo = (double)(M - 1) * 5.0 / 100.0, posHi = (double)(M - 1) * 95.0 / 100.0;
         const int iLo = (int)std::floor(posLo), iHi = (int)std::floor(posHi);
         const int maskS = (int)std::ceil(h->cfg.samplingFrequency / kFCA);                      // :96-99
-        const int rowInLds = (size_t)M * sizeof(float) <= 64 * 1024 ? 1 : 0;
+        // (the kernel's static LDS is ~17 KB: the row joins it only while the sum stays below the 64 KB a launch gets without
+        //  an opt-in -- M <= 10 240 -- and is read from memory beyond)
+        const int rowInLds = (size_t)M * sizeof(float) <= 40 * 1024 ? 1 : 0;
         hipLaunchKernelGGL(acq_stats_kernel, dim3(P), dim3(256), rowInLds ? (size_t)M * sizeof(float) : 0, st, h->surf_d, h->mp_d, B, M,
                            rowInLds, maskS, iLo, posLo - (double)iLo, iHi, posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P,
                            h->stats_d);

@@ -850,7 +850,9 @@ namespace dpe {
 // momLen = samples per moment block (kSub for the per-sample kernels, kPass for the chip kernel); nValid = entries of a
 // block partial that hold lags (65, or 64 for the chip kernel whose lanes cover lagShift - 32 .. lagShift + 31).
 // (batch form with 4 moments: held to 128 registers = four blocks per CU -- the kernel is a chain of latencies, 0.033 -> 0.030 ms at R)
-template <int kNMom, bool FUSE>
+// (NG = bin groups a block walks: 1 for the split shape, the handle's group count for the fat one -- the per-group registers of
+//  unused groups made the 4-moment batch form spill 28 bytes under its 128-register bound)
+template <int kNMom, bool FUSE, int NG>
 __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finalize_kernel(BcsParamBlock pb, int inl, int S, int K, int nSub, int nBlk, int LH, int L, int B, int wide, int lagShift,
                                                            int momLen, int nValid, long long C, const BcsChanDev *__restrict__ chan,
                                                            const float2 *__restrict__ part,
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finali
     }
     // ---- Doppler bins: F[b] = sum_sub tw(sub,b) * sum_p (-j theta)^p / p! * M_p[sub]
     // 16 bins per group, 16 thread groups striding the sub-tiles; a fat block walks all bin groups per chunk
-    constexpr int kMaxFatGroups = 4;
+    constexpr int kMaxFatGroups = NG;
     const int nGroups = (2 * B + 1 + 15) / 16;
     const int gFirst = fat ? 0 : (int)blockIdx.x - 1, gCount = fat ? nGroups : 1;   // host: fat only if nGroups <= kMaxFatGroups
     const int grp = tid >> 4;
@@ -1677,13 +1679,20 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     if (h->fatForce >= 0) fatFinalize = nBinBlk <= 4 && h->fatForce == 1;   // (experiment builds)
     const dim3 fgrid((fatFinalize || lagShift != 0) ? 1 : 1 + nBinBlk, nChan, nWindows);
 #define DPE_LAUNCH_FIN(NM, FS)                                                                                          \
-    hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, chip ? nBlkUse : h->nSub, nBlkUse, h->LH, \
+    do {                                                                                                                \
+        const int ng = (fatFinalize && lagShift == 0) ? nBinBlk : 1;                                                   \
+        if (ng <= 1) DPE_LAUNCH_FIN_G(NM, FS, 1); else if (ng == 2) DPE_LAUNCH_FIN_G(NM, FS, 2);                        \
+        else if (ng == 3) DPE_LAUNCH_FIN_G(NM, FS, 3); else DPE_LAUNCH_FIN_G(NM, FS, 4);                                \
+    } while (0)
+#define DPE_LAUNCH_FIN_G(NM, FS, NGV)                                                                                   \
+    hipLaunchKernelGGL((bcs_finalize_kernel<NM, FS, NGV>), fgrid, dim3(256), 0, stream, pb, inl, S, nChan, chip ? nBlkUse : h->nSub, nBlkUse, h->LH, \
                        h->cfg.lagHalfWidth, h->cfg.binHalfWidth, wide ? 1 : 0, lagShift, momLenUse, chip ? 64 : 65, h->C, h->chan_d, h->part_d, h->mom_d,  \
                        h->codeBank_d, h->carrBank_d, h->info_d, h->cfg.maxChannels, h->momRep_d, h->sums_d, sumSlotsUsed)
     const bool fuseFin = fuse && lagShift == 0;
     if (nMomUse == 4) { if (fuseFin) DPE_LAUNCH_FIN(4, true); else DPE_LAUNCH_FIN(4, false); }
     else { if (fuseFin) DPE_LAUNCH_FIN(6, true); else DPE_LAUNCH_FIN(6, false); }
 #undef DPE_LAUNCH_FIN
+#undef DPE_LAUNCH_FIN_G
     h->prof.end(2, stream);
     }   // chunk
     const bool captured = h->graphs.capturing;

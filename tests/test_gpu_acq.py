@@ -117,6 +117,65 @@ def test_fused_coherent_search_equals_the_rocfft_chain():
     assert {4, 9, 16, 23, 29} <= {r["prn"] for r in r0 if r["found"]}   # (cppm > 2 also lets a cross-correlation peak through: both forms alike)
 
 
+def test_fused_noncoherent_search_equals_the_rocfft_chain():
+    """The reference's non-coherent mode (coherent = False: one 25 000-point correlation per bin, |.| summed over the ten lag
+    aliases, correlator.py:77-82) at 10 x 2 500 samples runs as a radix-10 stage + ten fused 2 500-point transforms per (PRN,
+    bin); DPE_ACQ_NO_FUSED=1 keeps multiply kernel, 25 000-point rocFFT and fold kernel.  Same surface to fp32 rounding, same
+    peak cells and statistics -- 32 PRNs x the reference's 25 x 500 Hz raster, PRNs in chunks of 8 and of 5 (a short last chunk)."""
+    import os
+    import torch
+    fs, S = 2.5e6, 25000
+    ch = dpe.synth.random_channels(93, 5, prns=[4, 9, 16, 23, 29])
+    ch["cp_ref"] = ch["cp"].copy()
+    iq = torch.from_numpy(dpe.synth.gen_iq(94, fs, S, ch, amp=120.0, flip=np.zeros(5, dtype=bool))).to("cuda:0")
+    bins = np.arange(-12, 13) * 500.0
+    out = {}
+    for form, chunk in (("fused", 8), ("fused5", 5), ("rocfft", 8)):
+        old = os.environ.get("DPE_ACQ_NO_FUSED")
+        if form == "rocfft":
+            os.environ["DPE_ACQ_NO_FUSED"] = "1"
+        try:
+            acq = dpe.Acquisition(fs, S, list(range(1, 33)), bins, mode="noncoherent", prn_chunk=chunk)
+        finally:
+            if form == "rocfft":
+                if old is None:
+                    os.environ.pop("DPE_ACQ_NO_FUSED", None)
+                else:
+                    os.environ["DPE_ACQ_NO_FUSED"] = old
+        acq.search(iq)
+        out[form] = (acq.results(), acq.read_surface().copy())
+        acq.close()
+    (r0, s0), (r5, s5), (r1, s1) = out["fused"], out["fused5"], out["rocfft"]
+    assert s0.shape == s1.shape == (32, 25, 2500)
+    assert np.array_equal(s0, s5)
+    assert np.abs(s0 - s1).max() < 3e-6 * s1.max()
+    for a, b in zip(r0, r1):
+        assert a["max_code_idx"] == b["max_code_idx"] and a["max_dopp_idx"] == b["max_dopp_idx"] and a["found"] == b["found"]
+        assert abs(a["cppm"] / b["cppm"] - 1) < 1e-5 and abs(a["cppr"] / b["cppr"] - 1) < 1e-5
+    assert {4, 9, 23, 29} <= {r["prn"] for r in r0 if r["found"]}   # (PRN 16, the weakest, stays below cppm = 2 on this raster in both forms)
+
+
+def test_acq_statistics_with_a_long_delay_row(oracle):
+    """16.368 Msps x 1 ms: 16 368 delays per PRN -- the statistics kernel's row no longer fits the LDS a launch gets without an
+    opt-in beside its 17 KB of static LDS and is read from memory instead.  Peak cell and statistics against the
+    oracle."""
+    import torch
+    fs, S = 16.368e6, 16368
+    ch = dpe.synth.random_channels(95, 2, prns=[6, 21])
+    ch["cp_ref"] = ch["cp"].copy()
+    iq = dpe.synth.gen_iq(96, fs, S, ch, amp=400.0, flip=np.zeros(2, dtype=bool))
+    bins = np.arange(-8, 9) * 500.0
+    acq = dpe.Acquisition(fs, S, [6, 21, 13], bins, mode="coherent")
+    acq.search(torch.from_numpy(iq).to("cuda:0"))
+    res = acq.results()
+    for p, prn in enumerate([6, 21, 13]):
+        ref = oracle.coarse_acquisition(iq, fs, prn, bins, coherent=True)
+        assert res[p]["max_code_idx"] == ref["max_code_idx"] and res[p]["max_dopp_idx"] == ref["max_dopp_idx"]
+        assert res[p]["found"] == ref["found"] == (prn != 13)
+        assert abs(res[p]["cppm"] / ref["cppm"] - 1) < 2e-4 and abs(res[p]["cppr"] / ref["cppr"] - 1) < 2e-4
+    acq.close()
+
+
 @pytest.mark.gpu
 def test_o9_fine_frequency_and_two_window_driver(golden):
     """HIP search_signal (coarse + fine frequency) and the two-window driver against the reference's own
