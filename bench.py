@@ -231,6 +231,7 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.use_dist = self.world > 1 or os.environ.get("DPE_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL self-test
+        self.comm = None        # --comm dpe: the dpe_comm handle that carries the data-path exchange
         self.backend = os.environ.get("DPE_BENCH_BACKEND", "nccl")
         self.dist = None
         self.dev = None
@@ -320,7 +321,9 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
         loc_v = device_view(bcm.VelScores, (W, bcm.VelScoresPitch), "<f4", dev)[:, :G]
 
     def gather_banks():
-        if ctx.backend == "nccl":
+        if ctx.comm is not None:      # --comm dpe: the C-ABI's own exchange (dpe_bcs_allgather_banks)
+            bcs.allgather_banks(ctx.comm, code_ptr, carr_ptr, stream=stream)
+        elif ctx.backend == "nccl":
             dist.all_gather_into_tensor(full_code, loc_code)
             dist.all_gather_into_tensor(full_carr, loc_carr)
         else:   # gloo (functional tests on one GPU): through host memory
@@ -335,7 +338,9 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
             gather_banks()
         bcm.Update(code_ptr, carr_ptr, bw, ce, stream=stream)
         if ctx.use_dist:
-            if args.exchange == "keys":
+            if ctx.comm is not None:  # --comm dpe: dpe_bcm_exchange_keys, all-reduce(MAX) in place on the handle's keys
+                bcm.exchange_keys(ctx.comm, stream=stream, to_host=False)
+            elif args.exchange == "keys":
                 dpe.sharding.allreduce_argmax(keys_tensor(), dist)
             else:
                 glob_p.zero_(); glob_v.zero_()
@@ -481,6 +486,7 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
             "config": {"workload": cfg["name"], "samples_per_window": S, "svs": K, "grid_points_per_manifold_per_gpu": G,
                        "grid_points_per_manifold_global": G_global, "manifolds": 2, "windows_per_step": W, "distinct_windows": distinct,
                        "lag_half_width": L, "bin_half_width": B, "exchange": args.exchange if ctx.use_dist else "none",
+                       "comm": ("dpe_comm (C-ABI)" if ctx.comm is not None else "torch.distributed") if ctx.use_dist else "none",
                        "stage1": ("sharded by window + bank all-gather" if shard1 else "replicated") if ctx.use_dist else "local",
                        "scores_written": write_scores},
             "timing": {"timed_batches": args.batches, "steps_per_timed_batch": reps * steps, "batch_ms_per_step": batch_ms,
@@ -540,6 +546,10 @@ def main():
                          "strong scaling over the GPUs).  Without it: H (N = 1) and M lines first, then the R headline")
     ap.add_argument("--no-extras", action="store_true", help="only the headline configuration")
     ap.add_argument("--extra-windows", type=int, default=None, help="windows per step of the extra (non-headline) lines")
+    ap.add_argument("--comm", choices=["torch", "dpe"], default="torch",
+                    help="who carries the N > 1 data-path exchange: torch.distributed (RCCL through PyTorch), or the C-ABI's own "
+                         "dpe_comm (RCCL bound by libdpe_hip.so; host files when the ranks share one GPU in the functional tests) "
+                         "-- dpe_bcs_allgather_banks + dpe_bcm_exchange_keys, what a C++ host (dpe_flow --ranks) uses")
     ap.add_argument("--exchange", choices=["keys", "scores"], default="keys",
                     help="multi-GPU exchange: packed arg-max keys (8 B/window/manifold) or the north-star-literal "
                          "all-reduce(SUM) of the zero-initialised full score vectors")
@@ -584,6 +594,19 @@ def main():
         else:
             dist.init_process_group(ctx.backend, rank=ctx.rank, world_size=ctx.world)
         ctx.dist = dist
+        if args.comm == "dpe":
+            if args.exchange != "keys":
+                sys.stderr.write("bench.py: --comm dpe carries the key exchange (--exchange keys) only\n")
+                sys.exit(2)
+            # rendezvous directory: the same for every rank of this launch, fresh per launch (rank 0's pid travels over the
+            # control plane); dpe_comm itself trusts nothing it finds there by name
+            tag = [os.getpid() if ctx.rank == 0 else 0]
+            if ctx.world > 1:
+                dist.broadcast_object_list(tag, src=0)
+            rdv = os.path.join(os.environ.get("DPE_BENCH_RENDEZVOUS", "/tmp"), "dpe_bench_rdv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), tag[0]))
+            os.makedirs(rdv, exist_ok=True)
+            shared_gpu = os.environ.get("DPE_BENCH_SHARE_GPU") == "1"
+            ctx.comm = dpe.engine.Comm(ctx.rank, ctx.world, rdv, dpe.engine.Comm.HOSTFILES if shared_gpu else dpe.engine.Comm.RCCL)
     else:
         torch.cuda.set_device(0)
     ctx.dev = torch.device("cuda", ctx.local_rank if ctx.use_dist else 0)
@@ -618,6 +641,8 @@ def main():
     if ctx.use_dist:
         dist.barrier()
     emit(out)
+    if ctx.comm is not None:
+        ctx.comm.close()
     if ctx.use_dist:
         dist.destroy_process_group()
 

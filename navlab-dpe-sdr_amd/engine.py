@@ -281,6 +281,11 @@ class BatchCorrScores:
         self._W, self._K = 1, int(n_chan)
         return 0
 
+    def allgather_banks(self, comm, code_all, carr_all, stream=None):
+        """Stage 1 sharded by window: this rank's banks of the last Update into code_all / carr_all (device pointers,
+        [nRanks * W_local][maxChannels][2L+1 | 2B+1] float2), rank-major (dpe_bcs_allgather_banks)."""
+        _check(lib().dpe_bcs_allgather_banks(self._h, comm._h, _ptr(code_all), _ptr(carr_all), _stream(stream)))
+
     def dev_status(self, stream=None):
         st = C.c_int32()
         _check(lib().dpe_bcs_dev_status(self._h, C.byref(st), _stream(stream)))
@@ -456,9 +461,12 @@ class BatchCorrManifold:
                      velOutOfWindow=r.velOutOfWindow, zValMean=np.array(r.zValMean),
                      weightedSums=np.array([list(r.weightedSums[0]), list(r.weightedSums[1])])) for r in res]
 
-    def exchange_keys(self, comm, stream=None):
+    def exchange_keys(self, comm, stream=None, to_host=True):
         """All-reduce(MAX) of the last Update's packed keys across the ranks of `comm` (dpe_bcm_exchange_keys);
-        returns the reduced host keys [W, 2] for results_from_keys."""
+        returns the reduced host keys [W, 2] for results_from_keys (to_host=False: in place on the device only, asynchronous)."""
+        if not to_host:
+            _check(lib().dpe_bcm_exchange_keys(self._h, comm._h, None, _stream(stream)))
+            return None
         keys = np.zeros((self._W, 2), dtype=np.uint64)
         _check(lib().dpe_bcm_exchange_keys(self._h, comm._h, keys.ctypes.data_as(C.POINTER(C.c_uint64)), _stream(stream)))
         return keys

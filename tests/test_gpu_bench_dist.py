@@ -112,3 +112,28 @@ def test_one_rank_rccl_self_test():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["config"]["exchange"] == "keys" and d["value"] > 0
     assert d["config"]["stage1"].startswith("sharded")     # the banks went through all_gather_into_tensor on device views
+
+
+def test_two_ranks_with_the_exchange_behind_the_c_abi():
+    """--comm dpe: the bank all-gather and the key all-reduce of the timed step go through dpe_bcs_allgather_banks /
+    dpe_bcm_exchange_keys (dpe_comm; host files here, where both ranks share the one GPU) instead of torch.distributed -- the
+    exchange a C++ host (dpe_flow --ranks) uses.  Config M (the same global grid whatever the rank count): the decoded ML points
+    equal the torch.distributed run's."""
+    a = _launch(29566, ["--config", "M", "--windows", "4", "--comm", "dpe"])
+    b = _launch(29567, ["--config", "M", "--windows", "4"])
+    assert len(a) == 1 and len(b) == 1
+    assert a[0]["config"]["comm"] == "dpe_comm (C-ABI)" and b[0]["config"]["comm"] == "torch.distributed"
+    assert a[0]["config"]["stage1"].startswith("sharded") and a[0]["n_gpus"] == 2 and a[0]["value"] > 0
+    assert a[0]["fixes"] == b[0]["fixes"]
+
+
+def test_one_rank_rccl_self_test_through_the_c_abi():
+    """DPE_BENCH_FORCE_DIST=1 --comm dpe: one rank, dpe_comm binds RCCL itself (ncclCommInitRank), all-gathers the banks and
+    reduces the keys on the box; bench.py asserts that the exchanged keys decode to the handle's own fix."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DPE_BENCH_BACKEND")}
+    env.update(DPE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29568", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "R", "--windows", "4", "--comm", "dpe"] + FAST
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["comm"] == "dpe_comm (C-ABI)" and d["value"] > 0
