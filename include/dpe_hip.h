@@ -129,6 +129,8 @@ typedef struct dpe_bcs_ports_dev {
 } dpe_bcs_ports_dev;
 int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, const dpe_bcs_ports_dev *ports_dev_ptrs,
                        dpe_stream_t stream);
+/* (The device-parameter forms -- *_update_dev, *_update_prepared -- always launch eagerly: dpe_bcs_set_graph / dpe_bcm_set_graph
+ * apply to the host-parameter Updates only.) */
 /* Input check of the last dpe_bcs_update_dev (synchronises): bit 0 = a PRN outside 1..37 (clamped), bit 1 = a non-positive
  * code frequency or negative code phase.  0 = clean. */
 int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream);

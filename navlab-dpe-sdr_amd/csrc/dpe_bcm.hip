@@ -525,7 +525,9 @@ struct dpe_bcm {
     std::vector<double> refWsum;            // [W][5] corrections of the weighted sums (patched - scanned score at offset x,y,z,t)
     long long refPatched = 0;               // points patched by the last Update (diagnostic)
     std::vector<dpe_bcm_window> win_h;
-    dpe::BcmDevWin *devWin_h = nullptr, *devWin_hd = nullptr;   // pinned: window frame of a device-parameter Update (written by bcm_prep_kernel)
+    dpe::BcmDevWin *devWin_h = nullptr, *devWin_hd = nullptr;   // pinned [2]: window frame of a device-parameter Update (written by bcm_prep_kernel),
+                                                                // one per alternating key set, so that the results of Update n can still be
+                                                                // decoded after Update n + 1 has been enqueued
     bool lastDev = false;
     int lastW = 0;
     double posExtent = 0, velExtent = 0;
@@ -849,7 +851,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->wsum_d = dev_alloc<double>(2 * h->wsumHalf);
     if ((cfg->writeScores && (!h->posScores_d || !h->velScores_d)) || !h->sv_d || !h->keys_d || !h->wsum_d ||
         hipHostMalloc((void **)&h->svBase_h, dpe_bcm::kStaging * 2 * W * K * sizeof(BcmSvDev), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&h->devWin_h, sizeof(BcmDevWin), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->devWin_h, 2 * sizeof(BcmDevWin), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->keys_h, (4 * W + 8) * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrManifold] create: device allocation failed");
         dpe_bcm_destroy(h);
@@ -1078,7 +1080,7 @@ int dpe_bcm_update_dev(dpe_bcm *h, const float *codeBank_dev, const float *carrB
     const size_t W = h->cfg.maxWindows, maxK = h->cfg.maxChannels;
     hipLaunchKernelGGL(bcm_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, rxTime, (const double *)nullptr, h->cfg.samplingFrequency,
                        (double)h->cfg.numFFTPoints, h->cfg.samplesPerWindow, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, (long long)h->cfg.numFFTPoints,
-                       h->sv_d, h->sv_d + W * maxK, h->devWin_hd);
+                       h->sv_d, h->sv_d + W * maxK, h->devWin_hd + (h->cur ^ 1));   // (the frame of the key set this Update reduces into)
     return bcm_update_impl(h, codeBank_dev, carrBank_dev, 1, nChan, nullptr, nullptr, stream);
 }
 
@@ -1104,7 +1106,7 @@ int dpe_bcm_hook_get(dpe_bcm *h, dpe_bcm_hook *out)
     }
     out->svPos_d = h->sv_d;
     out->svVel_d = h->sv_d + W * maxK;
-    out->devWin_hd = h->devWin_hd;
+    out->devWin_hd = h->devWin_hd + (h->cur ^ 1);   // the frame of the NEXT Update's key set (re-queried per window by the channel manager)
     out->keys_d[0] = h->keys_d;
     out->keys_d[1] = h->keys_d + 4 * W;
     out->posGrid64_d = h->posGrid64_d;
@@ -1151,10 +1153,11 @@ static void decode_key(unsigned long long key, float *score, int64_t *index)
 static int fetch_device_frame(dpe_bcm *h)
 {
     if (!h->lastDev) return 0;
-    DPE_REQUIRE(!h->devWin_h->bad, "[BatchCorrManifold] results: DopplerSign on the device is not +/-1");
-    memcpy(h->win_h[0].xCurrkk1, h->devWin_h->xCurrkk1, sizeof(double) * 8);
-    memcpy(h->win_h[0].enu2ecef, h->devWin_h->enu2ecef, sizeof(double) * 9);
-    h->win_h[0].dopplerSign = h->devWin_h->dopplerSign;
+    const dpe::BcmDevWin &fw = h->devWin_h[h->cur];
+    DPE_REQUIRE(!fw.bad, "[BatchCorrManifold] results: DopplerSign on the device is not +/-1");
+    memcpy(h->win_h[0].xCurrkk1, fw.xCurrkk1, sizeof(double) * 8);
+    memcpy(h->win_h[0].enu2ecef, fw.enu2ecef, sizeof(double) * 9);
+    h->win_h[0].dopplerSign = fw.dopplerSign;
     return 0;
 }
 

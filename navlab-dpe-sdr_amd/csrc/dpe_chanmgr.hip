@@ -176,6 +176,7 @@ static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1,
     }
     if (h->bcs) { a.bcsChan = h->hb.chan_d; a.bcsStatus = h->hb.status_d; a.fs = h->hb.fs; a.S = h->hb.S; }
     if (h->bcm) {
+        if (dpe_bcm_hook_get(h->bcm, &h->hm)) return -1;   // (the window frame alternates with the key sets)
         a.svPos = h->hm.svPos_d; a.svVel = h->hm.svVel_d; a.devWin = h->hm.devWin_hd;
         a.fs = h->hm.fs; a.Cf = h->hm.Cf; a.S = h->hm.S; a.L = h->hm.L; a.B = h->hm.B; a.C = h->hm.C;
     }

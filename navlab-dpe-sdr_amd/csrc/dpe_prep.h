@@ -140,7 +140,7 @@ int dpe_bcs_cotask_set(dpe_bcs *h, const void *args, size_t bytes);
 int dpe_bcs_cotask_flush(dpe_bcs *h, void *stream);
 struct dpe_bcm_hook {
     dpe::BcmSvDev *svPos_d, *svVel_d;          // [maxWindows][maxChannels] each; window 0 is the single-window block
-    dpe::BcmDevWin *devWin_hd;                 // pinned window frame (device address)
+    dpe::BcmDevWin *devWin_hd;                 // pinned window frame (device address) the NEXT Update's results will be decoded with
     const unsigned long long *keys_d[2];       // the two alternating key sets: {pos, vel} keys then {pos, vel} out-of-window counts per window
     const double *posGrid64_d, *velGrid64_d;   // fp64 copies of the local grids (made by the first call of dpe_bcm_hook_get)
     long long posG, velG, posOffset, velOffset;

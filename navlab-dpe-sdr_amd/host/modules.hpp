@@ -331,10 +331,16 @@ class BatchCorrScores : public Module {
             carrSTot = (int)nfft;
             const int64_t nLag = 2 * lagHalf + 1, nBin = 2 * binHalf + 1;
             if (dpe_device_alloc((void **)&codeAll, sizeof(float) * 2 * DPE_MAX_CHAN * nLag) ||
-                dpe_device_alloc((void **)&carrAll, sizeof(float) * 2 * DPE_MAX_CHAN * nBin)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+                dpe_device_alloc((void **)&carrAll, sizeof(float) * 2 * DPE_MAX_CHAN * nBin)) {
+                ReleaseShard();
+                DPE_MOD_FAIL("Start: " << dpe_last_error());
+            }
             const std::string dir = std::string(commRendezvous) + "/stage1";   // a rendezvous of its own beside BatchCorrManifold's
             (void)::mkdir(dir.c_str(), 0777);
-            if (dpe_comm_create(shardRank, shardCount, dir.c_str(), commBackend, &comm)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+            if (dpe_comm_create(shardRank, shardCount, dir.c_str(), commBackend, &comm)) {
+                ReleaseShard();   // (Started is still false: Stop() would return at once and leave the buffers behind)
+                DPE_MOD_FAIL("Start: " << dpe_last_error());
+            }
             UpdateOutput(0, (uint32_t)nLag, (void *)codeAll, lagHalf);
             UpdateOutput(1, (uint32_t)nBin, (void *)carrAll, binHalf);
             UpdateOutput(2, 1, &carrSTot, 0);
@@ -374,14 +380,14 @@ class BatchCorrScores : public Module {
         }
         dpe_stream_t st = flow_stream(flowStream);
         if (sharded) {
-            if (K % shardCount) DPE_MOD_FAIL("Update: ShardStage1 needs the " << K << " channels to divide over " << shardCount << " ranks");
+            if (K % shardCount) { Stop(); DPE_MOD_FAIL("Update: ShardStage1 needs the " << K << " channels to divide over " << shardCount << " ranks"); }
             const int Kl = K / shardCount;
             if (!h) {
                 cfgKeep.maxChannels = Kl;       // the gathered rows are then channel-major: rank r's block holds channels r Kl ...
                 if (dpe_bcs_create(&cfgKeep, &h)) { Stop(); return -1; }
                 shardK = K;
             }
-            if (K != shardK) DPE_MOD_FAIL("Update: channel count changed from " << shardK << " to " << K << " under ShardStage1");
+            if (K != shardK) { Stop(); DPE_MOD_FAIL("Update: channel count changed from " << shardK << " to " << K << " under ShardStage1"); }
             if (dpe_bcs_update(h, (const int16_t *)inputs[0]->Data, S, 1, Kl, ch + shardRank * Kl, st) ||
                 dpe_bcs_allgather_banks(h, comm, codeAll, carrAll, st)) {
                 std::cerr << "[" << ModuleName << "] Update: " << dpe_last_error() << std::endl;
@@ -415,6 +421,13 @@ class BatchCorrScores : public Module {
     dpe_bcs *Handle() const { return h; }
 
   private:
+    void ReleaseShard()
+    {
+        if (comm) dpe_comm_destroy(comm);
+        if (codeAll) dpe_device_free(codeAll);
+        if (carrAll) dpe_device_free(carrAll);
+        comm = nullptr; codeAll = carrAll = nullptr;
+    }
     dpe_bcs *h = nullptr;
     bool Started = false, deviceLoop = false;
     bool shardStage1 = false, sharded = false;

@@ -163,6 +163,18 @@ def test_device_resident_ports_match_the_host_form(golden, oracle):
     bcs.UpdateDev(iq_d, K, dict(codePhaseStart=keep["rc"], carrierPhaseStart=keep["ri"], codeFrequency=keep["fc"],
                                 carrierFrequency=keep["fi"], cpElapsedStart=keep["ela"], cpReference=keep["ref"], validPRNs=keep["prn"]))
     assert bcs.dev_status() & 1
+    # ... and a negative code phase / non-positive code frequency is flagged, with nominal values in the kernels' place (the
+    # chip-table index of a negative phase would fall in front of the table) -- ADVICE r3
+    keep["prn"][0] = int(ho["prn_list"][0])
+    keep["rc"][1] = -3.25
+    keep["fc"][2] = 0.0
+    bcs.UpdateDev(iq_d, K, dict(codePhaseStart=keep["rc"], carrierPhaseStart=keep["ri"], codeFrequency=keep["fc"],
+                                carrierFrequency=keep["fi"], cpElapsedStart=keep["ela"], cpReference=keep["ref"], validPRNs=keep["prn"]))
+    assert bcs.dev_status() == 2
+    code2, _ = bcs.read_banks()
+    assert np.isfinite(code2).all()
+    for k in (0, 3, 4, 5, 6, 7):     # the channels with sane inputs are what they were
+        assert np.abs(code2[0][k] - code0[0][k]).max() < 2e-7 * np.abs(code0[0][k]).max()
     bcm.Stop(); bcs.Stop()
 
 
