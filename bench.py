@@ -220,8 +220,8 @@ def acq_line(modes=("coherent", "textbook", "noncoherent"), cpu_budget_s=5.0):
 
 def acq_main(mode):
     """`bench.py --acq MODE`: the acquisition line alone, for the chosen mode first."""
-    modes = (mode,) + tuple(m for m in ("coherent", "textbook") if m != mode)
-    print(json.dumps(acq_line(modes=modes if mode != "noncoherent" else (mode,), cpu_budget_s=8.0)))
+    modes = (mode,) + tuple(m for m in ("coherent", "textbook", "noncoherent") if m != mode)
+    print(json.dumps(acq_line(modes=modes, cpu_budget_s=8.0)))
 
 
 class Ctx:

@@ -12,11 +12,11 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --no-extras ${DPE_BENCH_ARGS:-} > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras ${DPE_BENCH_ARGS:-} \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --no-pipelined ${DPE_BENCH_ARGS:-} \
     > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err
 cp $OUT/${TAG}_stats/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --batches 1 --min-batch-s 0 --no-extras --no-cpu-baseline ${DPE_BENCH_ARGS:-} \
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --batches 1 --min-batch-s 0 --no-extras --no-cpu-baseline --no-pipelined ${DPE_BENCH_ARGS:-} \
         > /dev/null 2> $OUT/${TAG}_pmc_$C.err
     cp $OUT/${TAG}_pmc_$C/*/*_counter_collection.csv $OUT/${TAG}_pmc_${C}_counter_collection.csv
 done
