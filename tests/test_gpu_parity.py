@@ -1,9 +1,18 @@
 """GPU parity tests (run with -m gpu on the MI355X box): HIP path through the C-ABI vs the fp64
 oracle on the same seeded inputs, and vs the golden fixtures from the reference's Python twin.
 
-Tolerance (north_star: "within stated fp32 tolerance"): 2e-6 relative to the peak magnitude of a
-score bank / the maximum manifold score; identical arg-max index (an fp32 tie is the only accepted
-difference); DC mean and nav-bit bookkeeping bit-exact."""
+Tolerances (north_star: "within stated fp32 tolerance"), all relative to the peak magnitude of a score bank / the maximum
+manifold score of the window:
+  * code and Doppler banks, velocity-manifold scores: 2e-6 (TOL) against the fp64 oracle and the PyGNSS fixtures;
+  * position-manifold scores: 2e-6 against the oracle evaluated with the EXTENDED-precision (long double) centre index, and
+    1e-4 (helpers.POS_REF_NOISE; 3e-4 in the randomised sweep) against the FAITHFUL fp64 oracle and the PyGNSS fixture O7 --
+    the reference's own rxTime - pr / C (batchcorrmanifold.cu:1784, rxTime ~ 4e5 s) rounds at 5.8e-11 s = 1.4e-4 samples per
+    (point, SV), so the faithful evaluation differs from its own long-double twin by 2.5e-5; 1e-4 is that noise, not fp32's;
+  * identical arg-max index (an fp32 tie is the only accepted difference) and identical fix; DC mean and nav-bit bookkeeping
+    bit-exact;
+  * with banks deliberately narrower than the grid reaches, helpers.assert_parity sets aside at most 16 + pairs / 2000 position
+    points and two velocity points per window (pairs within the reference's index noise of the bank edge) -- never when
+    posOutOfWindow == 0."""
 import ctypes as C
 
 import numpy as np
