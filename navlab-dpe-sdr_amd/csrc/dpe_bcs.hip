@@ -1123,6 +1123,10 @@ struct dpe_bcs {
     double *tTable_d = nullptr;   // ns-rounded sample times (always allocated; used only when useTable)
     bool useTable = false;
     long long *sums_d = nullptr;
+    unsigned long long *rideWord_d = nullptr;   // [maxWindows][kSumSlots] {epoch, I, Q} words of the sums computed inside the chip2 launch
+    unsigned rideEpoch = 0;                     // cycles 1 .. 15
+    int rideW = 0, rideSlots = 0;               // the slot set the last such launch wrote
+    bool rideAllowed = true;                    // DPE_BCS_NO_SUMRIDE=1: DC-sum kernel in front of the chip2 kernel, as before (A/B runs)
     dpe::BcsChanDev *chan_d = nullptr;
     // pinned parameter staging: a ring of kStaging blocks, each guarded by an event recorded once its H2D copy (or the
     // graph that contains it) has been enqueued -- Updates may be issued kStaging - 1 deep without waiting
@@ -1224,6 +1228,9 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         h->useTable = needTable;
     }
     h->sums_d = dev_alloc<long long>(2 * W * kSumSlots);
+    h->rideWord_d = dev_alloc<unsigned long long>(W * kSumSlots);
+    if (h->rideWord_d) (void)hipMemset(h->rideWord_d, 0, sizeof(unsigned long long) * W * kSumSlots);
+    h->rideAllowed = !(getenv("DPE_BCS_NO_SUMRIDE") && atoi(getenv("DPE_BCS_NO_SUMRIDE")) != 0);
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     // chip-boundary kernel (dpe_bcs_chip.h): lag windows of 17..31 samples (wider: chunks of 64 lags) at sampling rates where a
     // sub-tile holds few chips, plain n/fs sample times; its moment block is one pass of kPass samples, and a chip's
@@ -1269,7 +1276,8 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->carrBank_d = dev_alloc<float2>(W * K * (2 * cfg->binHalfWidth + 1));
     h->info_d = dev_alloc<int>(W * K);
     h->status_d = dev_alloc<int>(1);
-    if (!h->status_d || !h->tTable_d || !h->chipTable_d || !h->chipBits_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
+    if (h->status_d) (void)hipMemset(h->status_d, 0, sizeof(int));
+    if (!h->status_d || !h->rideWord_d || !h->tTable_d || !h->chipTable_d || !h->chipBits_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
         !h->info_d || hipHostMalloc((void **)&h->chanBase_h, dpe_bcs::kStaging * W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrScores] create: device allocation failed");
         dpe_bcs_destroy(h);
@@ -1323,7 +1331,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
 int dpe_bcs_destroy(dpe_bcs *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->tTable_d, h->chipTable_d, h->chipBits_d, h->sums_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
+    void *bufs[] = {h->tTable_d, h->chipTable_d, h->chipBits_d, h->sums_d, h->rideWord_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
     h->planS3.destroy(); h->planS2.destroy(); h->planC.destroy();
@@ -1475,7 +1483,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // the per-kernel event timing and the graph replay exclude each other
     const bool useGraph = h->graphs.enabled && !h->prof.enabled && !dev;
     GraphCache::Guard graphGuard{h->graphs, stream};
-    const int sumBlocks = sum_blocks(S, nWindows);
+    int sumBlocks = sum_blocks(S, nWindows);
     if (useGraph) {
         const int rc = h->graphs.begin({samples_dev, nullptr, (long long)windowStrideSamples, nWindows, nChan,
                                         (h->wideAllowed ? 1 : 0) | (h->bank16Allowed ? 2 : 0) | (h->slot << 8), stream}, stream);
@@ -1568,6 +1576,36 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // single windows (<= 37 (window, channel) pairs) with a dense stage-1 kernel: no separate DC-sum launch, the
     // sums ride along in the bank kernel (FUSE) and the finalize kernel applies the mean
     const bool fuse = nWindows * nChan <= DPE_MAX_CHAN && !use16 && !wide && !chip && h->LH <= 16 && h->cfg.lagHalfWidth <= 32 && h->fuseAllowed;
+    // chip2 batches: the DC sums ride in the chip2 launch (sum blocks interleaved ahead of the correlator blocks, dpe_bcs_chip2.h);
+    // the parameter upload keeps a small kernel of its own (riding as well, every correlator block had to poll for it first thing:
+    // 0.7035 against 0.696 ms per step)
+    bool ride = chip2 && !dev && !h->graphs.capturing && vecOK && h->rideAllowed && nWindows >= 8;
+    int rideF = 0, rideSB = 0;
+    if (ride) {   // a sum block's lanes fetch their share in whole rounds of kRideLoads loads: slots of two rounds when 64 slots allow it
+        const int n4 = S >> 2, per = (kRideLoads >= 32 ? 1 : 2) * kRideLoads * 64;
+        const int sb = (n4 + per - 1) / per < 1 ? 1 : ((n4 + per - 1) / per > kSumSlots ? kSumSlots : (n4 + per - 1) / per);
+        if (4 * ((n4 + sb - 1) / sb) + 3 >= 16384) ride = false;   // 30-bit sum fields
+        else sumBlocks = sb;
+    }
+    if (ride) {
+        const long long totalSum = (long long)nWindows * sumBlocks, NG = ((long long)c2nBlk * nWindows + 7) / 8;
+        const int lookAhead = 4;   // windows: a window's sums are complete >= 3 windows' worth of correlator blocks before its own
+        rideF = (int)(((long long)lookAhead * sumBlocks + 7) / 8 * 8);
+        const long long groupsAvail = NG - ((long long)lookAhead * c2nBlk + 7) / 8 - 1;
+        if (rideF >= totalSum || groupsAvail < 1) rideF = (int)((totalSum + 7) / 8 * 8);
+        else rideSB = (int)((((totalSum - rideF) + groupsAvail - 1) / groupsAvail + 7) / 8 * 8);
+        if (nWindows > h->rideW || sumBlocks > h->rideSlots)   // slots this launch reads that the last one did not write: clear the words
+            DPE_CHECK_HIP(hipMemsetAsync(h->rideWord_d, 0, sizeof(unsigned long long) * (size_t)h->cfg.maxWindows * kSumSlots, stream));
+        h->rideW = nWindows;
+        h->rideSlots = sumBlocks;
+        h->rideEpoch = h->rideEpoch % 15 + 1;
+        if (upInSum) {
+            h->prof.begin(0, stream);
+            upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
+            h->prof.end(0, stream);
+            DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
+        }
+    }
     const int sumSlotsUsed = fuse ? nBlk : sumBlocks;
     // a pending task of the device-resident channel manager: an extra block of the FUSE form's launch, a kernel of its own in
     // front of every other form
@@ -1575,7 +1613,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     if (h->coPending && !coRide) hipLaunchKernelGGL(chm_k2_kernel, dim3(1), dim3(256), 0, stream, h->co);
     h->coPending = false;
     h->lastSumBlocks = sumSlotsUsed;
-    if (!fuse) {
+    if (!fuse && !ride) {
         h->prof.begin(0, stream);
         hipLaunchKernelGGL(bcs_sum_kernel, dim3(sumBlocks, nWindows), dim3(256), 0, stream, samples_dev,
                            (long long)windowStrideSamples, S, h->sums_d, (uint4 *)h->chan_d,
@@ -1620,11 +1658,17 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         else DPE_LAUNCH_BANK2(LHV, 6);  \
     } while (0)
     if (c2) {
-        const dim3 cgrid(((c2nBlk * nWindows + 7) / 8) * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
-#define DPE_LAUNCH_CHIP2(NM, LV)                                                                                               \
-    hipLaunchKernelGGL((bcs_bank_chip2_kernel<NM, LV>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
-                       nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->chipBits_d, h->part_d, h->mom_d)
-#define DPE_LAUNCH_CHIP2_L(LV) case LV: if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, LV); else DPE_LAUNCH_CHIP2(6, LV); break
+        const int c2Groups = (c2nBlk * nWindows + 7) / 8;
+        const dim3 cgrid(ride ? rideF + c2Groups * (rideSB + 8 * nChan) : c2Groups * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
+#define DPE_LAUNCH_CHIP2(NM, LV, RD)                                                                                           \
+    hipLaunchKernelGGL((bcs_bank_chip2_kernel<NM, LV, RD>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
+                       nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->chipBits_d, h->part_d, h->mom_d,      \
+                       h->rideWord_d, h->rideEpoch, rideF, rideSB, h->status_d)
+#define DPE_LAUNCH_CHIP2_L(LV)                                                                        \
+    case LV:                                                                                          \
+        if (ride) { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, LV, true); else DPE_LAUNCH_CHIP2(6, LV, true); }   \
+        else { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, LV, false); else DPE_LAUNCH_CHIP2(6, LV, false); }      \
+        break
         switch (c2L1) {
             DPE_LAUNCH_CHIP2_L(16); DPE_LAUNCH_CHIP2_L(17); DPE_LAUNCH_CHIP2_L(18); DPE_LAUNCH_CHIP2_L(19); DPE_LAUNCH_CHIP2_L(20);
             DPE_LAUNCH_CHIP2_L(21); DPE_LAUNCH_CHIP2_L(22); DPE_LAUNCH_CHIP2_L(23); DPE_LAUNCH_CHIP2_L(24);
@@ -1762,7 +1806,7 @@ int dpe_bcs_hook_get(dpe_bcs *h, dpe_bcs_hook *out)
 
 int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream)
 {
-    DPE_REQUIRE(h && status && h->lastDev, "[BatchCorrScores] dev_status: no device-parameter Update yet");
+    DPE_REQUIRE(h && status && (h->lastDev || h->rideEpoch != 0), "[BatchCorrScores] dev_status: no device-parameter Update (and no batch whose DC sums ride in the chip2 launch) yet");
     DPE_CHECK_HIP(hipMemcpyAsync(status, h->status_d, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return 0;

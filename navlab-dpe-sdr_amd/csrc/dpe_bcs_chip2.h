@@ -71,14 +71,104 @@ __device__ __forceinline__ float mask_pm1(unsigned long long m)
     return r;
 }
 
-template <int kNMom, int L1>
+// RIDE: the DC sums of the batch are computed by extra one-wave blocks of THIS launch instead of a kernel in front of it
+// (bcs_sum_kernel reads all samples at the HBM rate while the chip kernel, which is arithmetic-bound, waits behind it: 0.04 of a
+// 0.72 ms step at config H).  The launch's linear block index interleaves them with the correlator blocks -- rideF sum blocks
+// first, then rideSB of them in front of every group of 8 K correlator blocks (both multiples of 8, so a correlator block's index
+// mod 8 is still its XCD) -- far enough ahead (the host's choice of rideF / rideSB: >= 3 windows) that a correlator block all but
+// never waits.  Hand-over: ONE 64-bit word per slot of kSumSlots, {epoch : 4, I sum : 30, Q sum : 30} (the host takes this form only
+// when a slot holds < 16384 samples), written with an agent-scope atomic store and read with agent-scope atomic loads (lane <->
+// slot): tag and data arrive together, in one round trip that the block issues first thing and consumes after its set-up.  The
+// sum block also leaves the int64 sums in the ordinary slots for the kernels behind this launch.  Epochs cycle 1 .. 15 and every
+// launch rewrites every word it will read; the host clears the words when the set of slots grows, so no older word can carry
+// the current epoch.  Forward progress: work groups are dispatched in index order per XCD and a sum block waits for nothing, so the
+// lowest-index undispatched sum block is never behind a full house of waiting blocks.  A wait that exceeds kRideSpinMax polls sets
+// bit 2 of *status and gives up (every later block then skips its wait): wrong means, no hang.
+constexpr int kRideSpinMax = 200000;
+#ifndef DPE_RIDE_LOADS
+#define DPE_RIDE_LOADS 16
+#endif
+constexpr int kRideLoads = DPE_RIDE_LOADS;   // loads in flight per lane of a sum block (24 or 32 push the kernel over its 170-register budget: scratch, 0.675 ms)
+__device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, long long winStride, int S, int nW, int nSumBlk, int sidx,
+                                               long long *__restrict__ sums, unsigned long long *__restrict__ rideWord, unsigned epoch)
+{
+    const int w = sidx / nSumBlk, b = sidx - w * nSumBlk;
+    if (w >= nW) return;
+    const int lane = threadIdx.x;
+    const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);   // (the host takes this form only for 16-byte aligned windows)
+    const int4 *x4 = reinterpret_cast<const int4 *>(x);
+    const int n4 = S >> 2, per = (n4 + nSumBlk - 1) / nSumBlk;
+    const int lo = b * per, hi = (lo + per < n4) ? lo + per : n4;
+    int sI = 0, sQ = 0;   // a block adds < 16384 samples
+    auto add4 = [&](const int4 v) {
+        sI += (short)(v.x & 0xFFFF) + (short)(v.y & 0xFFFF) + (short)(v.z & 0xFFFF) + (short)(v.w & 0xFFFF);
+        sQ += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
+    };
+    // kRideLoads loads in flight per lane, each under its own range check: the block is a short latency chain, and it holds a
+    // correlator block's slot for that time
+    int n0 = lo;
+    for (; n0 + kRideLoads * 64 <= hi; n0 += kRideLoads * 64) {   // whole rounds (wave-uniform bound)
+        int4 v[kRideLoads];
+#pragma unroll
+        for (int j = 0; j < kRideLoads; ++j) v[j] = x4[n0 + lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < kRideLoads; ++j) add4(v[j]);
+    }
+    for (int n = n0 + lane; n < hi; n += 64) add4(x4[n]);
+    if (b == nSumBlk - 1)
+        for (int m = (n4 << 2) + lane; m < S; m += 64) { const int v = x[m]; sI += (short)(v & 0xFFFF); sQ += v >> 16; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sI += __shfl_xor(sI, off, 64);
+        sQ += __shfl_xor(sQ, off, 64);
+    }
+    if (lane == 0) {
+        long long *o = sums + ((size_t)w * kSumSlots + b) * 2;
+        o[0] = sI; o[1] = sQ;
+        const unsigned long long word = ((unsigned long long)epoch << 60) | ((unsigned long long)((unsigned)sI & 0x3FFFFFFFu) << 30) | (unsigned long long)((unsigned)sQ & 0x3FFFFFFFu);
+        __hip_atomic_store(rideWord + (size_t)w * kSumSlots + b, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// the consumer's side: window_mean (dpe_bcs.hip) from the words that blocks of the same launch publish; `first` = the word this
+// lane fetched when the block started
+__device__ __forceinline__ void ride_window_mean(const unsigned long long *__restrict__ rideWord, unsigned long long first, unsigned epoch, int *__restrict__ status,
+                                                 int w, int nSumBlk, int S, float &mRe, float &mIm)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long *wd = rideWord + (size_t)w * kSumSlots + lane;
+    unsigned long long v = first;
+    for (int it = 0;; ++it) {
+        if (__ballot(lane < nSumBlk && (unsigned)(v >> 60) != epoch) == 0ull) break;
+        if (it >= kRideSpinMax || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) {
+            if (lane == 0) atomicOr(status, 4);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+        if (lane < nSumBlk) v = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    long long tI = 0, tQ = 0;
+    if (lane < nSumBlk) {   // 30-bit two's-complement fields
+        tI = (long long)((int)((unsigned)(v >> 30) << 2) >> 2);
+        tQ = (long long)((int)((unsigned)v << 2) >> 2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tI += __shfl_xor(tI, off, 64);
+        tQ += __shfl_xor(tQ, off, 64);
+    }
+    mRe = (float)((double)tI / (double)(float)S);
+    mIm = (float)((double)tQ / (double)(float)S);
+}
+
+template <int kNMom, int L1, bool RIDE = false>
 __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
                                                                int S, int K, int nW, int Lt, int nBlk, int nSumBlk,
                                                                const BcsChanDev *__restrict__ chan,
                                                                const long long *__restrict__ sums,
                                                                const int8_t *__restrict__ chipTable,
                                                                const uint32_t *__restrict__ chipBits,
-                                                               float2 *__restrict__ part, float2 *__restrict__ mom)
+                                                               float2 *__restrict__ part, float2 *__restrict__ mom,
+                                                               unsigned long long *__restrict__ rideWord, unsigned epoch, int rideF, int rideSB, int *__restrict__ status)
 {
     constexpr int NL = 65;   // partial layout shared with the other stage-1 kernels: entry j <-> lag j - 32 (j = 64 unused)
     __shared__ float2 sQ[k2QLen];
@@ -86,10 +176,27 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
 
     // Block -> (window, tile, SV), XCD-aware as in the first form: the K blocks of a tile are congruent mod 8
     const int lane = threadIdx.x;
-    const int slot = blockIdx.x >> 3, k = slot % K, tg = (slot / K) * 8 + (blockIdx.x & 7);
+    int bx = blockIdx.x;
+    if constexpr (RIDE) {
+        int sidx = -1;
+        if (bx < rideF) sidx = bx;
+        else {
+            const int per = rideSB + 8 * K, r = bx - rideF, gI = r / per, o = r - gI * per;
+            if (o < rideSB) sidx = rideF + gI * rideSB + o;
+            else bx = gI * 8 * K + (o - rideSB);
+        }
+        if (sidx >= 0) {
+            ride_sum_block(iq, winStride, S, nW, nSumBlk, sidx, const_cast<long long *>(sums), rideWord, epoch);
+            return;
+        }
+    }
+    const int slot = bx >> 3, k = slot % K, tg = (slot / K) * 8 + (bx & 7);
     if (tg >= nBlk * nW) return;
     const int w = tg / nBlk, blk = tg - w * nBlk;
     (void)pb;
+    unsigned long long rideFirst = 0ull;
+    if constexpr (RIDE)
+        if (lane < nSumBlk) rideFirst = __hip_atomic_load(rideWord + (size_t)w * kSumSlots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const BcsChanDev ch = params_ptr(chan, inl)[(size_t)w * K + k];
     const int8_t *chips = chipTable + (ch.prn - 1) * 1024;
     // the same chips as sign bits: lane l keeps word l of the PRN's (periodically extended) bit table for the whole tile, and a
@@ -97,9 +204,6 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
     // (A first version read them with scalar loads: the s_waitcnt that follows an s_load is lgkmcnt(0), which also drains the
     // wave's LDS queue -- 0.81 against 0.57 ms per 128 windows at H.)
     const int bitsV = (int)(lane < k2BitWords ? chipBits[(ch.prn - 1) * k2BitWords + lane] : 0u);
-    float mRe, mIm;
-    window_mean(sums, w, nSumBlk, S, mRe, mIm);
-    const f2 meanv = f2{mRe, mIm};
     const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);
 
     // chip index of replica index m (phases are >= 0: the truncating conversion is the floor, :347-349)
@@ -142,6 +246,10 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
         thA = f2{readlane_f(t.x, 26), readlane_f(t.y, 26)};
         thB = f2{readlane_f(t.x, 27), readlane_f(t.y, 27)};
     }
+    float mRe, mIm;   // (behind the block's set-up: with RIDE the word fetched first thing has arrived by now)
+    if constexpr (RIDE) ride_window_mean(rideWord, rideFirst, epoch, status, w, nSumBlk, S, mRe, mIm);
+    else window_mean(sums, w, nSumBlk, S, mRe, mIm);
+    const f2 meanv = f2{mRe, mIm};
     float2 *momOut = mom + ((((size_t)w * K + k) * 2) * nBlk + blk) * kNMom;   // [side][nBlk][kNMom]
     const size_t momSide = (size_t)nBlk * kNMom;
 

@@ -213,3 +213,50 @@ def test_device_ports_at_a_high_sampling_rate_take_the_chip_kernel():
             assert np.abs(got - ref).max() < TOL * np.abs(ref).max()
         assert np.abs(code1[0][k] - code0[0][k]).max() < 2e-7 * np.abs(code0[0][k]).max()
         assert np.abs(carr1[0][k] - carr0[0][k]).max() < 2e-7 * np.abs(carr0[0][k]).max()
+
+
+def test_sums_riding_in_the_chip2_launch_equal_the_sum_kernel():
+    """Batches of >= 8 windows through the second form: the DC sums are computed by extra blocks of the chip2 launch itself
+    (ride_sum_block, dpe_bcs_chip2.h) and handed to the correlator blocks through {epoch, I, Q} words; DPE_BCS_NO_SUMRIDE=1 keeps
+    the DC-sum kernel in front.  Same integer sums => bit-identical means and banks; a window length with S % 4 = 2 (the last
+    slot's tail; the padding between the windows must not be summed), a batch that grows between calls (slots the previous launch did not write are cleared), the wait never
+    times out (device status 0)."""
+    import torch
+    from oracle import oracle as o
+    case = helpers.make_case(seed=23, fs=25e6, S=100002, K=3, G=64, amp=60.0, W=9)
+    iq, cs, _, _ = helpers.pack_gpu_inputs(case)
+    stride = case["S"] + 2                  # windows 16-byte aligned (the riding form's condition) with S % 4 = 2 samples in each
+    pad = np.full((9, 2 * stride), 1234, dtype=np.int16)
+    pad[:, :2 * case["S"]] = iq
+    d = torch.from_numpy(pad).to("cuda:0")
+    out = {}
+    for name, env in (("ride", {}), ("kernel", {"DPE_BCS_NO_SUMRIDE": "1"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            bcs = dpe.BatchCorrScores(case["fs"], samples_per_window=case["S"], lag_half_width=31, bin_half_width=16, max_windows=9, max_channels=3)
+            bcs.Start()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        res = []
+        for nw in (8, 9, 8, 9):          # 8 -> 9: the slot set grows; then epochs cycle
+            bcs.Update(d, cs[:nw], window_stride=stride)
+            assert bcs.stage1_kernel == "bcs_bank_chip2_kernel"
+            code, carr = bcs.read_banks()
+            res.append((code[:nw].copy(), carr[:nw].copy(), bcs.read_info()[2][:nw].copy()))
+        for _ in range(20):              # more launches than there are epochs
+            bcs.Update(d, cs, window_stride=stride)
+        code, carr = bcs.read_banks()
+        res.append((code.copy(), carr.copy(), bcs.read_info()[2].copy()))
+        if name == "ride":
+            assert bcs.dev_status() == 0          # no correlator block gave up waiting for its window's sums
+        bcs.Stop()
+        out[name] = res
+    for a, b in zip(out["ride"], out["kernel"]):
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for wi, w in enumerate(case["wins"]):
+        s = w["start"]
+        _, _, inf = o.bcs_sv(w["iq"], case["fs"], int(s["prn"][0]), s["rc"][0], s["ri"][0], s["fc"][0], s["fi"][0], int(s["cp"][0]),
+                             int(s["cp_ref"][0]), -31, 31, -16, 16, case["C"])
+        assert out["ride"][-1][2][wi] == inf["mean"]
