@@ -133,7 +133,7 @@ int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, co
  * apply to the host-parameter Updates only.) */
 /* Input check of the last dpe_bcs_update_dev (synchronises): bit 0 = a PRN outside 1..37 (clamped), bit 1 = a non-positive
  * code frequency or negative code phase.  0 = clean.  Bit 2 belongs to the host-parameter batches of the high-rate chip kernel
- * (>= 8 windows at >= 16 samples per chip), whose DC sums are computed by blocks of the stage-1 launch itself: set when a
+ * (>= 48 windows at >= 16 samples per chip), whose DC sums are computed by blocks of the stage-1 launch itself: set when a
  * correlator block gave up waiting for them (never observed; the banks of that Update are then wrong).  DPE_BCS_NO_SUMRIDE=1 at
  * create keeps the separate DC-sum kernel. */
 int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream);

@@ -1001,11 +1001,11 @@ __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finali
         }
 #pragma unroll
         for (int i = 0; i < kNMom; ++i) {
-            float ax = r0[i].x + sgn * r1[i].x, ay = r0[i].y + sgn * r1[i].y;
+            float ax = fmaf(sgn, r1[i].x, r0[i].x), ay = fmaf(sgn, r1[i].y, r0[i].y);
             if (FUSE) {
-                const float qx = s0[i].x + sgn * s1[i].x, qy = s0[i].y + sgn * s1[i].y;
-                ax -= mRe * qx - mIm * qy;
-                ay -= mRe * qy + mIm * qx;
+                const float qx = fmaf(sgn, s1[i].x, s0[i].x), qy = fmaf(sgn, s1[i].y, s0[i].y);
+                ax = fmaf(-mRe, qx, fmaf(mIm, qy, ax));
+                ay = fmaf(-mRe, qy, fmaf(-mIm, qx, ay));
             }
             sMom[tid + 256 * i] = make_float2(ax, ay);
         }
@@ -1030,13 +1030,15 @@ __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finali
                     const long long tt = (((long long)(2 * momLen) * sub + (momLen - 1)) * (long long)bb[g]) & (2 * C - 1);
                     sincospif((float)tt * invC, &sn[g], &cs[g]);  // angle = pi * tt / C
                 } else {
-                    const float nc = cs[g] * stepC[g] - sn[g] * stepS[g];
-                    sn[g] = sn[g] * stepC[g] + cs[g] * stepS[g];
+                    // (explicit FMAs, here and below: the two launch shapes are different instantiations (NG), and left to the
+                    // compiler's contraction their sums would round differently -- the shapes are bit-identical by test)
+                    const float nc = fmaf(cs[g], stepC[g], -(sn[g] * stepS[g]));
+                    sn[g] = fmaf(sn[g], stepC[g], cs[g] * stepS[g]);
                     cs[g] = nc;
                 }
                 // (cs - j sn) * (ar + j ai)
-                F[g].x += cs[g] * ar + sn[g] * ai;
-                F[g].y += cs[g] * ai - sn[g] * ar;
+                F[g].x = fmaf(cs[g], ar, fmaf(sn[g], ai, F[g].x));
+                F[g].y = fmaf(cs[g], ai, fmaf(-sn[g], ar, F[g].y));
             }
         }
     }
@@ -1127,6 +1129,7 @@ struct dpe_bcs {
     unsigned rideEpoch = 0;                     // cycles 1 .. 15
     int rideW = 0, rideSlots = 0;               // the slot set the last such launch wrote
     bool rideAllowed = true;                    // DPE_BCS_NO_SUMRIDE=1: DC-sum kernel in front of the chip2 kernel, as before (A/B runs)
+    int rideMinW = 48;                          // smallest batch that takes the riding form (measured at H: 8 / 16 windows slower, 32 equal, 64 -1.2 %, 128 -2.6 %); DPE_BCS_SUMRIDE_MIN
     dpe::BcsChanDev *chan_d = nullptr;
     // pinned parameter staging: a ring of kStaging blocks, each guarded by an event recorded once its H2D copy (or the
     // graph that contains it) has been enqueued -- Updates may be issued kStaging - 1 deep without waiting
@@ -1231,6 +1234,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->rideWord_d = dev_alloc<unsigned long long>(W * kSumSlots);
     if (h->rideWord_d) (void)hipMemset(h->rideWord_d, 0, sizeof(unsigned long long) * W * kSumSlots);
     h->rideAllowed = !(getenv("DPE_BCS_NO_SUMRIDE") && atoi(getenv("DPE_BCS_NO_SUMRIDE")) != 0);
+    if (getenv("DPE_BCS_SUMRIDE_MIN") && atoi(getenv("DPE_BCS_SUMRIDE_MIN")) >= 1) h->rideMinW = atoi(getenv("DPE_BCS_SUMRIDE_MIN"));
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     // chip-boundary kernel (dpe_bcs_chip.h): lag windows of 17..31 samples (wider: chunks of 64 lags) at sampling rates where a
     // sub-tile holds few chips, plain n/fs sample times; its moment block is one pass of kPass samples, and a chip's
@@ -1579,7 +1583,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // chip2 batches: the DC sums ride in the chip2 launch (sum blocks interleaved ahead of the correlator blocks, dpe_bcs_chip2.h);
     // the parameter upload keeps a small kernel of its own (riding as well, every correlator block had to poll for it first thing:
     // 0.7035 against 0.696 ms per step)
-    bool ride = chip2 && !dev && !h->graphs.capturing && vecOK && h->rideAllowed && nWindows >= 8;
+    bool ride = chip2 && !dev && !h->graphs.capturing && vecOK && h->rideAllowed && nWindows >= h->rideMinW;
     int rideF = 0, rideSB = 0;
     if (ride) {   // a sum block's lanes fetch their share in whole rounds of kRideLoads loads: slots of two rounds when 64 slots allow it
         const int n4 = S >> 2, per = (kRideLoads >= 32 ? 1 : 2) * kRideLoads * 64;

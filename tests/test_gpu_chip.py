@@ -216,7 +216,7 @@ def test_device_ports_at_a_high_sampling_rate_take_the_chip_kernel():
 
 
 def test_sums_riding_in_the_chip2_launch_equal_the_sum_kernel():
-    """Batches of >= 8 windows through the second form: the DC sums are computed by extra blocks of the chip2 launch itself
+    """Large batches through the second form (>= 48 windows by default, >= 8 here): the DC sums are computed by extra blocks of the chip2 launch itself
     (ride_sum_block, dpe_bcs_chip2.h) and handed to the correlator blocks through {epoch, I, Q} words; DPE_BCS_NO_SUMRIDE=1 keeps
     the DC-sum kernel in front.  Same integer sums => bit-identical means and banks; a window length with S % 4 = 2 (the last
     slot's tail; the padding between the windows must not be summed), a batch that grows between calls (slots the previous launch did not write are cleared), the wait never
@@ -230,7 +230,7 @@ def test_sums_riding_in_the_chip2_launch_equal_the_sum_kernel():
     pad[:, :2 * case["S"]] = iq
     d = torch.from_numpy(pad).to("cuda:0")
     out = {}
-    for name, env in (("ride", {}), ("kernel", {"DPE_BCS_NO_SUMRIDE": "1"})):
+    for name, env in (("ride", {"DPE_BCS_SUMRIDE_MIN": "8"}), ("kernel", {"DPE_BCS_NO_SUMRIDE": "1"})):   # (default: batches of >= 48 windows ride)
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
