@@ -494,6 +494,8 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
     __shared__ float sF[4];
     __shared__ double sD[4];
     __shared__ unsigned long long sB[4];
+    __shared__ float sCand[2][64];
+    __shared__ unsigned int sCnt[2];
     auto block_argmax = [&](unsigned long long best) -> int {   // packed (value bits, ~index): larger value, then smaller index
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -508,11 +510,20 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
         return (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
     };
     unsigned long long best = 0ull;
+    float rowSum = 0.f;   // (only sets the bin width of the selection below: any positive value gives the same result)
     for (int j = tid; j < M; j += 256) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(m[j]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
+        const float mj = m[j];
+        rowSum += mj;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(mj) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)j);
         best = key > best ? key : best;
     }
-    const int ci = block_argmax(best);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rowSum += __shfl_xor(rowSum, off, 64);
+    if ((tid & 63) == 0) sF[tid >> 6] = rowSum;
+    for (unsigned int i = tid; i < 2048u; i += 256) hist[i] = 0u;
+    if (tid < 2) sCnt[tid] = 0u;
+    const int ci = block_argmax(best);   // (its barriers also publish sF, the cleared histogram and the counters)
+    const float binScale = 256.0f * (float)M / fmaxf((sF[0] + sF[1]) + (sF[2] + sF[3]), 1e-30f);   // 256 bins per row mean
     // the peak's column of the surface: loads issued here, reduced at the end (they arrive under the selection passes)
     unsigned long long bestD = 0ull;
     for (int b = tid; b < B; b += 256) {
@@ -531,7 +542,76 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
     // patterns (>= 0, so unsigned order is float order) in three passes of 11 / 11 / 10 bits with one histogram per rank --
     // two ranks x four 8-bit passes one after the other were ~50 block barriers of a 26 us kernel
     float selV[2], mxT = 0.f;
+    bool selected = false;
     {
+        // Fast path: ONE histogram over 2048 linear bins of width mean / 256 (monotone in the value, so the k-th smallest lies in
+        // the bin where the running count passes k), then the handful of values of that bin -- a few per bin for a noise-like row --
+        // are ranked by counting inside one wave.  Exact like the radix passes below, which remain for rows whose selected bins
+        // hold more than 64 values (constant rows, heavy ties): five block barriers instead of twelve.
+        auto bin_of = [&](float v) -> unsigned int {
+            const float t = v * binScale;
+            return t >= 2047.f ? 2047u : (unsigned int)t;
+        };
+        for (int j = tid; j < M; j += 256) {
+            const float vj = val(j);
+            mxT = fmaxf(mxT, vj);
+            atomicAdd(&hist[bin_of(vj)], 1u);
+        }
+        __syncthreads();
+        unsigned int tot = 0u;
+        for (unsigned int q = 0; q < 8u; ++q) tot += hist[tid * 8u + q];
+        unsigned int inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(inc, off, 64);
+            if ((tid & 63) >= off) inc += o;
+        }
+        if ((tid & 63) == 63) sTmp[tid >> 6] = inc;
+        __syncthreads();
+        unsigned int excl0 = inc - tot;
+        for (int q = 0; q < (tid >> 6); ++q) excl0 += sTmp[q];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned int kr = (unsigned int)(r ? iHi : iLo);
+            if (tot && kr >= excl0 && kr < excl0 + tot) {   // the rank lies among this thread's bins
+                unsigned int excl = excl0;
+                for (unsigned int q = 0; q < 8u; ++q) {
+                    const unsigned int c = hist[tid * 8u + q];
+                    if (kr < excl + c) { sSel[2 * r] = tid * 8u + q; sSel[2 * r + 1] = kr - excl; break; }
+                    excl += c;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned int selBin[2] = {sSel[0], sSel[2]}, kIn[2] = {sSel[1], sSel[3]};
+        const unsigned int nC[2] = {hist[selBin[0]], hist[selBin[1]]};
+        if (nC[0] <= 64u && nC[1] <= 64u) {   // (block-uniform)
+            for (int j = tid; j < M; j += 256) {
+                const float vj = val(j);
+                const unsigned int b = bin_of(vj);
+                if (b == selBin[0]) sCand[0][atomicAdd(&sCnt[0], 1u)] = vj;
+                if (b == selBin[1]) sCand[1][atomicAdd(&sCnt[1], 1u)] = vj;
+            }
+            __syncthreads();
+            const int r = tid >> 6, l = tid & 63;
+            if (r < 2) {
+                const int n = (int)nC[r];
+                const float v = l < n ? sCand[r][l] : 3.0e38f;
+                unsigned int below = 0u;
+                for (int j = 0; j < n; ++j) {
+                    const float cj = sCand[r][j];
+                    below += (cj < v || (cj == v && j < l)) ? 1u : 0u;
+                }
+                if (l < n && below == kIn[r]) sF[r] = v;
+            }
+            __syncthreads();
+            selV[0] = sF[0];
+            selV[1] = sF[1];
+            selected = true;
+        }
+    }
+    if (!selected) {
+        __syncthreads();   // (the fast path's histogram is dead: the passes below clear and reuse it)
         unsigned int prefix[2] = {0u, 0u}, kk[2] = {(unsigned int)iLo, (unsigned int)iHi}, mask = 0u;
         const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
         for (int pass = 0; pass < 3; ++pass) {
@@ -654,7 +734,7 @@ struct dpe_acq {
     float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused searches (acq_corr2500_kernel), else null
     float2 *tw25k_d = nullptr;  // exp(+j 2 pi n / 25000): the radix-10 stage of the fused non-coherent search
     bool fused = false, fusedAlias = false;
-    dpe::AcqStats *stats_d = nullptr, *stats_h = nullptr;   // per-PRN peak statistics; pinned host copy
+    dpe::AcqStats *stats_hd = nullptr, *stats_h = nullptr;  // per-PRN peak statistics: pinned host memory the statistics kernel writes itself (_hd: its device address)
     bool searched = false;
     // fine-frequency stage, allocated on first use
     int fineC = 0, fineLo = 0, fineHi = -1;
@@ -675,7 +755,7 @@ int dpe_acq_destroy(dpe_acq *h)
     h->planFwd.destroy();
     h->planInv.destroy();
     h->planFine.destroy();
-    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->stats_d};
+    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->stats_h) (void)hipHostFree(h->stats_h);
     delete h;
@@ -715,9 +795,9 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
     h->peakIdx_d = dev_alloc<int>(2 * P);
-    h->stats_d = dev_alloc<AcqStats>(P);
     if (hipHostMalloc((void **)&h->stats_h, P * sizeof(AcqStats), hipHostMallocDefault) != hipSuccess) h->stats_h = nullptr;
-    if (!h->X_d || !h->Rc_d || !h->Y_d || !h->surf_d || !h->mp_d || !h->peakIdx_d || !h->stats_d || !h->stats_h) {
+    if (h->stats_h && hipHostGetDevicePointer((void **)&h->stats_hd, h->stats_h, 0) != hipSuccess) h->stats_hd = nullptr;
+    if (!h->X_d || !h->Rc_d || !h->Y_d || !h->surf_d || !h->mp_d || !h->peakIdx_d || !h->stats_hd || !h->stats_h) {
         set_error("[Acquisition] create: device allocation failed");
         dpe_acq_destroy(h);
         return -1;
@@ -831,8 +911,7 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         const int rowInLds = (size_t)M * sizeof(float) <= 40 * 1024 ? 1 : 0;
         hipLaunchKernelGGL(acq_stats_kernel, dim3(P), dim3(256), rowInLds ? (size_t)M * sizeof(float) : 0, st, h->surf_d, h->mp_d, B, M,
                            rowInLds, maskS, iLo, posLo - (double)iLo, iHi, posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P,
-                           h->stats_d);
-        DPE_CHECK_HIP(hipMemcpyAsync(h->stats_h, h->stats_d, sizeof(AcqStats) * P, hipMemcpyDeviceToHost, st));
+                           h->stats_hd);   // (48 bytes per PRN straight into the pinned mirror: a D2H copy command behind the kernel cost ~5 us of stream time)
     }
     DPE_CHECK_HIP(hipGetLastError());
     h->searched = true;
@@ -843,7 +922,7 @@ int dpe_acq_results(dpe_acq *h, dpe_acq_result *out, dpe_stream_t stream)
 {
     using namespace dpe;
     DPE_REQUIRE(h && out && h->searched, "[Acquisition] results: no search yet");
-    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));   // the statistics were copied to stats_h behind the search
+    DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));   // the statistics kernel wrote stats_h itself
     const int P = h->P;
     const double fs = h->cfg.samplingFrequency;
     for (int p = 0; p < P; ++p) {

@@ -176,6 +176,28 @@ def test_acq_statistics_with_a_long_delay_row(oracle):
     acq.close()
 
 
+def test_acq_statistics_of_a_nearly_constant_row(oracle):
+    """The statistics kernel selects its two order statistics through one histogram of linear bins (mean / 256 wide) and ranks
+    the few values of the selected bins inside a wave; rows whose selected bin holds more than 64 values fall back to the radix
+    passes.  A DC window (+-1 LSB of noise) is such a row: the 0 Hz bin's correlation is the same for every delay (DC x the code's chip sum),
+    so the 2500 values of max_percode differ by a few percent and share some ten bins.  cppr and cppm (both ~ 1) against the oracle; nothing is found."""
+    import torch
+    fs, S = 2.5e6, 25000
+    iq = np.random.default_rng(5).integers(-1, 2, size=2 * S).astype(np.int16)   # +-1 LSB of noise: the values differ, in the 4th digit
+    iq[0::2] += 1000
+    iq[1::2] -= 300
+    bins = np.arange(-4, 5) * 100.0
+    acq = dpe.Acquisition(fs, S, [1, 9, 30], bins, mode="coherent")
+    acq.search(torch.from_numpy(iq).to("cuda:0"))
+    res = acq.results()
+    for p, prn in enumerate([1, 9, 30]):
+        ref = oracle.coarse_acquisition(iq, fs, prn, bins, coherent=True)
+        assert not res[p]["found"] and not ref["found"]
+        assert abs(res[p]["cppm"] / ref["cppm"] - 1) < 2e-4 and abs(res[p]["cppr"] / ref["cppr"] - 1) < 2e-4
+        assert 0.9 < res[p]["cppm"] < 1.1      # (a few percent of spread: some 250 values per bin)
+    acq.close()
+
+
 @pytest.mark.gpu
 def test_o9_fine_frequency_and_two_window_driver(golden):
     """HIP search_signal (coarse + fine frequency) and the two-window driver against the reference's own
