@@ -348,6 +348,9 @@ __global__ __launch_bounds__(256) void bcm_scan_kernel(BcmParamBlock pb, int inl
     // Thread 0 issued this block's key / counter atomics and has their return values, i.e. they are
     // performed at the device's coherence point; its ticket follows in program order.  The block that
     // draws the last ticket therefore reads final values with agent-scope loads.
+    // (done == nullptr: nobody reads the host mirror -- the device-resident loop's next kernel takes the keys from device memory
+    //  behind the kernel boundary -- so the ticket, the agent-scope reads and the stores over the host link are skipped)
+    if (!done) return;
     __shared__ unsigned int sLast;
     if (threadIdx.x == 0) {
         const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
@@ -530,6 +533,8 @@ struct dpe_bcm {
                                                                 // decoded after Update n + 1 has been enqueued
     bool lastDev = false;
     int lastW = 0;
+    bool publish = true;        // false: the scan leaves keys / counts in device memory only (set by the device-resident channel manager's attach)
+    bool lastPublished = true;  // what the last Update did
     double posExtent = 0, velExtent = 0;
     dpe::KernelProfiler prof;  // slot 0: the fused position + velocity scan
     dpe::GraphCache graphs;
@@ -1024,13 +1029,15 @@ static int bcm_update_impl(dpe_bcm *h, const float *codeBank_dev, const float *c
                     h->cfg.weightedMean ? h->wsum_d + h->wsumHalf : nullptr, h->cfg.velGridSize, h->cfg.velGridIndexOffset, h->velPitch, nBin,
                     (int)h->lastSplit[1]};
     a.keys = keys; a.oob = oob; a.clr = other; a.clrN = 4 * W;
-    a.done = h->done_d; a.hostKeys = h->keys_hd; a.hostOob = h->keys_hd + 2 * W;
+    const bool publishNow = h->publish || !dev || h->cfg.weightedMean;   // (only the device-parameter forms may skip it)
+    a.done = publishNow ? h->done_d : nullptr; a.hostKeys = h->keys_hd; a.hostOob = h->keys_hd + 2 * W;
+    h->lastPublished = publishNow;
     a.seq = ++h->seq;
     // (a replayed graph carries a stale sequence argument: polling only for eager single-window launches whose mirror
     //  has the sequence word right behind the results, i.e. maxWindows == 1)
     // (with the weighted-mean estimator the per-block sums are fetched with a copy after the results arrive: that copy must
     //  see the finished kernel, so the stream is waited for instead)
-    h->pollable = nWindows == 1 && W == 1 && !h->graphs.capturing && h->pollAllowed && !h->cfg.weightedMean;
+    h->pollable = nWindows == 1 && W == 1 && !h->graphs.capturing && h->pollAllowed && !h->cfg.weightedMean && publishNow;
     a.grid = dim3(h->lastSplit[0] > h->lastSplit[1] ? h->lastSplit[0] : h->lastSplit[1], nWindows, 2);
     a.lds = (size_t)nChan * (nLag > nBin ? nLag : nBin) * (h->compact ? 12 : 16);
     a.st = stream;
@@ -1120,6 +1127,13 @@ int dpe_bcm_hook_get(dpe_bcm *h, dpe_bcm_hook *out)
     return 0;
 }
 
+int dpe_bcm_hook_set_publish(dpe_bcm *h, int enable)
+{
+    DPE_REQUIRE(h, "[BatchCorrManifold] hook: null argument");
+    h->publish = enable != 0;
+    return 0;
+}
+
 int dpe_bcm_set_graph(dpe_bcm *h, int32_t enable)
 {
     DPE_REQUIRE(h, "[BatchCorrManifold] set_graph: null handle");
@@ -1175,6 +1189,11 @@ int dpe_bcm_results(dpe_bcm *h, dpe_bcm_result *results, dpe_stream_t stream)
     }
     if (!arrived) DPE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     const int W = h->lastW;
+    if (!h->lastPublished) {   // the scan did not write the host mirror (device-resident loop): fetch keys and counts of the set it used
+        const size_t Wm = h->cfg.maxWindows;
+        DPE_CHECK_HIP(hipMemcpy(h->keys_h, h->keys_d + (size_t)h->cur * 4 * Wm, sizeof(unsigned long long) * 2 * Wm, hipMemcpyDeviceToHost));
+        DPE_CHECK_HIP(hipMemcpy(h->oob_h, h->keys_d + (size_t)h->cur * 4 * Wm + 2 * Wm, sizeof(unsigned long long) * 2 * Wm, hipMemcpyDeviceToHost));
+    }
     if (fetch_device_frame(h)) return -1;
     const unsigned long long *keys = h->keys_h, *oob = h->oob_h;
     std::vector<double> ws;   // per-block weighted sums: fetched only when the estimator is on (this call sits on the

@@ -150,6 +150,7 @@ struct dpe_chm_dev {
     dpe_bcs_hook hb{};
     dpe_bcm_hook hm{};
     dpe_fix_record *ring_h = nullptr, *ring_hd = nullptr;
+    dpe_fix_record *stage_d = nullptr;   // the window's record between chm_k1 (which forms it) and the chm_k2 behind it (which sends it)
     int ringDepth = 0;
     long long enqueued = 0;          // Updates enqueued since Start
     hipStream_t lastStream = nullptr;
@@ -173,6 +174,7 @@ static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1,
         a.posG = h->hm.posG; a.velG = h->hm.velG; a.posOff = h->hm.posOffset; a.velOff = h->hm.velOffset;
         a.ring = h->ring_hd;
         a.ringDepth = h->ringDepth;
+        a.stage = h->stage_d;
     }
     if (h->bcs) { a.bcsChan = h->hb.chan_d; a.bcsStatus = h->hb.status_d; a.fs = h->hb.fs; a.S = h->hb.S; }
     if (h->bcm) {
@@ -261,6 +263,7 @@ int dpe_chm_dev_destroy(dpe_chm_dev *h)
     (void)hipFree(h->st_d);
     (void)hipFree(h->portBuf_d);
     if (h->ring_h) (void)hipHostFree(h->ring_h);
+    (void)hipFree(h->stage_d);
     delete h;
     return 0;
 }
@@ -279,11 +282,14 @@ int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRi
         DPE_REQUIRE(h->hm.maxWindows == 1, "[cuChanMgr] attach: the BatchCorrManifold handle must be a single-window one (the closed loop)");
         DPE_REQUIRE(h->hm.maxChannels >= h->K, "[cuChanMgr] attach: the BatchCorrManifold handle holds %d channels, %d tracked", h->hm.maxChannels, h->K);
         h->bcm = bcm;
+        if (dpe_bcm_hook_set_publish(bcm, 0)) return -1;   // chm_k1 reads the keys on the device; the fix goes out through the ring
         if (!h->ring_h) {
             DPE_CHECK_HIP(hipHostMalloc((void **)&h->ring_h, sizeof(dpe_fix_record) * (size_t)fixRingDepth, hipHostMallocDefault));
             memset(h->ring_h, 0, sizeof(dpe_fix_record) * (size_t)fixRingDepth);
             DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->ring_hd, h->ring_h, 0));
             h->ringDepth = fixRingDepth;
+            h->stage_d = dpe::dev_alloc<dpe_fix_record>(1);
+            DPE_REQUIRE(h->stage_d, "[cuChanMgr] attach: device allocation failed");
         }
     }
     return 0;
@@ -341,6 +347,9 @@ int dpe_chm_dev_fix(dpe_chm_dev *h, int64_t window, dpe_fix_record *out, int32_t
 {
     DPE_REQUIRE(h && out && h->ring_h, "[cuChanMgr] fix: no fix ring (dpe_chm_dev_attach)");
     DPE_REQUIRE(window >= 0 && window < h->enqueued, "[cuChanMgr] fix: window %lld not enqueued yet", (long long)window);
+    // (the record of a window is sent by the time update that FOLLOWS its measurement kernel -- normally an extra block of the next
+    //  window's stage-1 launch; the newest window's has not been picked up yet: run it now)
+    if (window == h->enqueued - 1 && h->bcs && dpe_bcs_cotask_flush(h->bcs, h->lastStream)) return -1;
     const dpe_fix_record *r = h->ring_h + (window % h->ringDepth);
     const unsigned long long want = (unsigned long long)window + 1ull;
     timespec t0;

@@ -259,6 +259,7 @@ struct ChmKArgs {
     long long posG, velG, posOff, velOff;
     dpe_fix_record *ring;           // pinned, device address
     int ringDepth;
+    dpe_fix_record *stage;          // device memory: chm_k1 leaves the window's record here, the chm_k2 that follows it sends it over the host link
     // parameter blocks of the attached handles for the NEXT window (nullptr: not attached)
     BcsChanDev *bcsChan;
     int *bcsStatus;
@@ -396,17 +397,20 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
                 atomicOr(&sFlags, measBad);
             }
             for (int i = 0; i < 8; ++i) { sX1[i] = z[i]; a.p.zVal[i] = z[i]; a.p.xk1k1[i] = z[i]; a.p.xkk1[i] = z[i]; }   // EKF_PassMeas: both state ports
-            // the fix for the host: the record's fields go out over the host link now, its sequence word at the end of the kernel
-            dpe_fix_record *r = a.ring + (st->window % a.ringDepth);
-            for (int i = 0; i < 8; ++i) __hip_atomic_store(&r->zVal[i], z[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->rxTime, rxTime, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->posIndex, (long long)(ip + a.posOff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->velIndex, (long long)(iv + a.velOff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->posOutOfWindow, (long long)a.keys[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->velOutOfWindow, (long long)a.keys[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->posScore, __uint_as_float((unsigned)(kp >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->velScore, __uint_as_float((unsigned)(kv >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&r->status, st->status | measBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the fix for the host: staged in device memory; the chm_k2 behind this kernel (which has time to spare) sends it over
+            // the host link -- stores to the pinned ring and the wait for them cost this kernel, which the next window's
+            // correlator waits for, ~2 us
+            dpe_fix_record *r = a.stage;
+            for (int i = 0; i < 8; ++i) r->zVal[i] = z[i];
+            r->rxTime = rxTime;
+            r->posIndex = (long long)(ip + a.posOff);
+            r->velIndex = (long long)(iv + a.velOff);
+            r->posOutOfWindow = (long long)a.keys[2];
+            r->velOutOfWindow = (long long)a.keys[3];
+            r->posScore = __uint_as_float((unsigned)(kp >> 32));
+            r->velScore = __uint_as_float((unsigned)(kv >> 32));
+            r->status = st->status | measBad;
+            r->seq = (unsigned long long)(st->window + 1);
         } else {
             for (int i = 0; i < 8; ++i) {
                 const double x1 = a.xk1k1[i], xk = a.xkk1[i];
@@ -440,10 +444,6 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
         if (sFlags) st->status |= sFlags;
         if (a.bcsStatus) *a.bcsStatus = (sFlags >> 3) & 3;
     }
-    if (k == 63 && a.meas) {   // the record is complete once its fields have arrived: sequence word last
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&(a.ring + (st->window % a.ringDepth))->seq, (unsigned long long)(st->window + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 __device__ __forceinline__ static void chm_k2(const ChmKArgs &a)
@@ -458,6 +458,24 @@ __device__ __forceinline__ static void chm_k2(const ChmKArgs &a)
     const bool live = wave < 2 && k < K;
     if (tid == 0) sFlags = 0;
     if (tid < 8) sXk[tid] = a.p.xkk1[tid];
+    // the fix record chm_k1 staged: its fields go out over the host link now (one otherwise idle lane), the sequence word at the end
+    // of this kernel, when they have long arrived
+    dpe_fix_record *ringRec = nullptr;
+    unsigned long long ringSeq = 0ull;
+    if (a.meas && tid == nThreads - 1) {
+        const dpe_fix_record rec = *a.stage;
+        ringSeq = rec.seq;
+        ringRec = a.ring + ((long long)(ringSeq - 1ull) % a.ringDepth);
+        for (int i = 0; i < 8; ++i) __hip_atomic_store(&ringRec->zVal[i], rec.zVal[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->rxTime, rec.rxTime, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->posIndex, rec.posIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->velIndex, rec.velIndex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->posOutOfWindow, rec.posOutOfWindow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->velOutOfWindow, rec.velOutOfWindow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->posScore, rec.posScore, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->velScore, rec.velScore, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&ringRec->status, rec.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     Chan c;
     double wE = 0.0, wM = 0.0;
     int wOk = 0;
@@ -497,6 +515,12 @@ __device__ __forceinline__ static void chm_k2(const ChmKArgs &a)
         for (int i = 0; i < 9; ++i) { sR[i] = Rm[i]; a.p.enu2ecef[i] = Rm[i]; }
         a.p.rxTime[0] = rxTime + T;
         a.p.dopplerSign[0] = ds;
+        if (a.devWin) {   // the window frame dpe_bcm_results would read (pinned): sent now, it has arrived long before the kernel ends
+            for (int i = 0; i < 8; ++i) a.devWin->xCurrkk1[i] = sXk[i];
+            for (int i = 0; i < 9; ++i) a.devWin->enu2ecef[i] = Rm[i];
+            a.devWin->dopplerSign = ds;
+            a.devWin->bad = 0;
+        }
     }
     __syncthreads();
     // ---- 3. wave 0: the rest of the time update; the state at the back-calculated transmit time along the difference quotient
@@ -556,12 +580,10 @@ __device__ __forceinline__ static void chm_k2(const ChmKArgs &a)
         st->rxTime = rxTime + T;   // :1121, :1249
         if (a.mode == 1) st->window += 1;
         if (sFlags) st->status |= sFlags;
-        if (a.devWin) {   // the window frame dpe_bcm_results would read (pinned)
-            for (int i = 0; i < 8; ++i) a.devWin->xCurrkk1[i] = sXk[i];
-            for (int i = 0; i < 9; ++i) a.devWin->enu2ecef[i] = sR[i];
-            a.devWin->dopplerSign = ds;
-            a.devWin->bad = 0;
-        }
+    }
+    if (ringRec) {   // the record is complete once its fields have arrived: sequence word last
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ringRec->seq, ringSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

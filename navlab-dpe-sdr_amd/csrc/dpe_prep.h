@@ -149,4 +149,7 @@ struct dpe_bcm_hook {
     long long C;
 };
 int dpe_bcm_hook_get(dpe_bcm *h, dpe_bcm_hook *out);
+// enable = 0: the device-parameter Updates of this handle leave keys and counts in device memory only (no ticket, no stores over the
+// host link at the end of the scan); dpe_bcm_results then fetches them with a copy.  Set by dpe_chm_dev_attach.
+int dpe_bcm_hook_set_publish(dpe_bcm *h, int enable);
 }
