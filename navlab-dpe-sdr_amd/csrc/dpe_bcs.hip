@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void bcs_bank_kernel(BcsParamBlock pb, int inl
         static_assert(FUSE && !TABLE, "the co-block rides in the single-window form");
         if (blkX == 0) {
             if (blockIdx.y == 0 && blockIdx.z == 0) chm_k2(co);
+            else if (blockIdx.y == 1 && blockIdx.z == 0) chm_k3(co);   // the NEXT time update's Kepler solutions, one window ahead
             return;
         }
         blkX -= 1;

@@ -166,6 +166,7 @@ static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1,
     a.xk1k1 = xk1k1;
     a.xkk1 = xkk1;
     a.meas = meas;
+    a.specPar = (int)(h->enqueued & 1);
     if (meas) {
         const uint64_t *keys = nullptr;
         if (dpe_bcm_keys(h->bcm, &keys)) return -1;
@@ -229,6 +230,7 @@ int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans
         const double *e = in.eph;
         c.eph = Eph{e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9], e[10], e[11], e[12], e[13], e[14],
                     e[15], e[16], e[17], e[18], e[19], e[20]};
+        s.ephC[k] = c.eph;
     }
     dpe_chm_dev *h = new dpe_chm_dev();
     h->K = cfg->nChan;

@@ -239,6 +239,15 @@ struct ChmDevState {
     int dopplerSign, K, dimT;
     int status;        // sticky: 1 Kepler iteration failed, 4 an arg-max key was 0 / out of range, 8 / 16 BatchCorrScores input flags
     long long window;  // windows completed (Start does not count)
+    // ---- speculative satellite states (chm_k3): the Kepler solutions of the NEXT time update, computed one window ahead beside
+    // the current one (two buffers, alternating with the window parity the host passes in ChmKArgs::specPar)
+    Eph ephC[DPE_MAX_CHAN];                 // the ephemerides again, never written after create (chm_k3 reads them while chm_k2 rewrites ch[])
+    double snapFc[DPE_MAX_CHAN], snapRcEnd[DPE_MAX_CHAN];   // chm_k1's snapshot of what chm_k3 needs of a channel (chm_k2 overwrites ch[] beside it)
+    int snapCpElaEnd[DPE_MAX_CHAN], snapCpRef[DPE_MAX_CHAN], snapCpRefTOW[DPE_MAX_CHAN];
+    double specTx[2][DPE_MAX_CHAN], specSat[2][2][DPE_MAX_CHAN][8];   // [buffer][at specTx | at specTx + kChmH]
+    int specOk[2][DPE_MAX_CHAN];
+    double specWE[2][DPE_MAX_CHAN], specWM[2][DPE_MAX_CHAN];          // chm_k3's own Kepler warm start, per wave
+    int specWOk[2][DPE_MAX_CHAN];
 };
 // The reference's output ports of cuChanMgr (cuchanmgr.cu:973-990,1136-1171) and cuEKF (cuekf.cu:277-279) as device arrays,
 // plus zVal (BatchCorrManifold, :2297) and the TimeGrid input
@@ -251,6 +260,7 @@ struct ChmKArgs {
     ChmDevState *st;
     ChmPorts p;
     int mode;                       // 0 Start (CHM_ComputeSatStates + time update), 1 Update (measurement + time update)
+    int specPar;                    // which speculative buffer chm_k2 reads; chm_k3 (same launch) fills the other one
     const double *xk1k1, *xkk1;     // inputs 10 / 12 on the device; ignored when meas != 0
     // measurement from the attached BatchCorrManifold's keys (BCM_MakePosMeas / MakeVelMeas + EKF_PassMeas)
     int meas;
@@ -434,6 +444,10 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
         st->ch[k].fi = bcFi;
         st->ch[k].fc = bcFc;
     }
+    if (k < K) {   // what chm_k3 needs of the channel (it runs beside chm_k2, which rewrites ch[])
+        st->snapFc[k] = c.fc; st->snapRcEnd[k] = c.rcEnd;
+        st->snapCpElaEnd[k] = c.cpElaEnd; st->snapCpRef[k] = c.cpRef; st->snapCpRefTOW[k] = c.cpRefTOW;
+    }
     if (k < K && a.bcsChan) {   // the next window starts where this one ended: rcEnd, riEnd, cpElaEnd with the new frequencies
         int bad;
         a.bcsChan[k] = bcs_prep_one(c.rcEnd, c.riEnd, c.fc, c.fi, c.cpElaEnd, c.cpRef, c.prn, a.fs, a.S, bad);
@@ -502,12 +516,29 @@ __device__ __forceinline__ static void chm_k2(const ChmKArgs &a)
     __syncthreads();
     // ---- 2. the satellite state at the predicted transmit time (wave 0) and a step later (wave 1), side by side; wave 2: the
     //         ENU -> ECEF matrix of the next grid centre (CHM_Dev_R_ENU2ECEF :54-73)
+    // A chm_k3 one window earlier has left both states at a transmit time within ~1e-7 s of this one (it could not know this window's
+    // fix): they are advanced along their own difference quotient -- the remainder, a delta^2 / 2 with a = 0.6 m/s^2, is 1e-14 m --
+    // and the two Kepler solutions, 5 us of a lone wave's fp64 libm calls, are off this kernel's path.  Without a usable
+    // speculation (Start, a standalone launch, a jump of the code phase) the solutions are computed here as before.
     double sp[8];
     if (live) {
-        const double tx = sTx[k] + (wave == 1 ? kChmH : 0.0);
-        if (sat_state_warm(c.eph, tx, sp, wE, wM, wOk)) atomicOr(&sFlags, 1);
-        if (wave == 1)
-            for (int i = 0; i < 8; ++i) sS1[k][i] = sp[i];
+        const int sb = a.specPar & 1;
+        const double dSpec = sTx[k] - st->specTx[sb][k];
+        if (a.mode == 1 && st->specOk[sb][k] && fabs(dSpec) < 1e-5) {
+            if (wave == 0) {
+                for (int i = 0; i < 8; ++i) {
+                    const double s0 = st->specSat[sb][0][k][i], s1 = st->specSat[sb][1][k][i];
+                    const double adv = (s1 - s0) / kChmH * dSpec;
+                    sp[i] = s0 + adv;
+                    sS1[k][i] = s1 + adv;
+                }
+            }
+        } else {
+            const double tx = sTx[k] + (wave == 1 ? kChmH : 0.0);
+            if (sat_state_warm(c.eph, tx, sp, wE, wM, wOk)) atomicOr(&sFlags, 1);
+            if (wave == 1)
+                for (int i = 0; i < 8; ++i) sS1[k][i] = sp[i];
+        }
     }
     if (tid == 128) {
         double Rm[9];
@@ -585,6 +616,32 @@ __device__ __forceinline__ static void chm_k2(const ChmKArgs &a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&ringRec->seq, ringSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// chm_k3 (two waves, beside chm_k2 in the stage-1 launch): the satellite states the NEXT time update will ask for.  That update's
+// transmit time follows from the channel as chm_k2 is leaving it right now and from the next fix; predicted from chm_k1's snapshot
+// -- two windows of code-phase advance at the present code frequency -- it is off by the next fix's correction, ~1e-7 s.
+__device__ __forceinline__ static void chm_k3(const ChmKArgs &a)
+{
+    ChmDevState *st = a.st;
+    const int tid = threadIdx.x, wave = tid >> 6, k = tid & 63, K = st->K;
+    const bool active = wave < 2 && k < K;
+    const int wb = (a.specPar & 1) ^ 1;
+    int bad = 0;
+    if (active) {
+        const double adv2 = 2.0 * (st->snapFc[k] * st->T) + st->snapRcEnd[k];
+        const double cp2 = st->snapCpElaEnd[k] + floor(adv2 / kLCA), rc2 = wrap_pos(adv2, (double)kLCA);
+        const double tx0 = st->snapCpRefTOW[k] + ((cp2 - st->snapCpRef[k]) * kTCA) + (rc2 / kFCA);
+        double wE = st->specWE[wave][k], wM = st->specWM[wave][k];
+        int wOk = st->specWOk[wave][k];
+        double out[8];
+        bad = sat_state_warm(st->ephC[k], tx0 + (wave == 1 ? kChmH : 0.0), out, wE, wM, wOk);
+        for (int i = 0; i < 8; ++i) st->specSat[wb][wave][k][i] = out[i];
+        st->specWE[wave][k] = wE; st->specWM[wave][k] = wM; st->specWOk[wave][k] = wOk;
+        if (wave == 0) { st->specTx[wb][k] = tx0; st->specOk[wb][k] = bad ? 0 : 1; }
+    }
+    __syncthreads();
+    if (active && wave == 1 && bad) st->specOk[wb][k] = 0;   // (behind wave 0's store: both waves of a channel run in this block)
 }
 
 __global__ __launch_bounds__(64) static void chm_k1_kernel(ChmKArgs a) { chm_k1(a); }
