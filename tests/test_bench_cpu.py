@@ -42,7 +42,7 @@ def test_weak_scaling_shards_are_slices_of_one_global_grid():
 def test_committed_pmc_traffic_is_found_per_configuration():
     import bench
     for cfg, w, kern, lo, hi in (("R", 256, "bcm_scan_kernel", 0.5e9, 2e9),
-                                 ("H", 128, "bcs_bank_chip2_kernel", 2.5e8, 5e8), ("M", 256, "bcm_scan_kernel", 1e9, 4e9)):
+                                 ("H", 128, "bcs_bank_chip2_kernel", 2.5e8, 7e8), ("M", 256, "bcm_scan_kernel", 1e9, 4e9)):
         t, src = bench.pmc_traffic(cfg, w, kern)
         assert t is not None and lo < t < hi and src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src))
         assert json.load(open(os.path.join(ROOT, src)))["config"] == cfg
