@@ -1127,9 +1127,10 @@ struct dpe_bcs {
     bool useTable = false;
     long long *sums_d = nullptr;
     unsigned long long *rideWord_d = nullptr;   // [maxWindows][kSumSlots] {epoch, I, Q} words of the sums computed inside the chip2 launch
-    unsigned rideEpoch = 0;                     // cycles 1 .. 15
+    unsigned rideEpoch = 0;                     // cycles 1 .. 3
     int rideW = 0, rideSlots = 0;               // the slot set the last such launch wrote
     bool rideAllowed = true;                    // DPE_BCS_NO_SUMRIDE=1: DC-sum kernel in front of the chip2 kernel, as before (A/B runs)
+    int rideLA = 4;                             // look-ahead of the sum blocks in windows (DPE_BCS_RIDE_LA)
     int rideMinW = 48;                          // smallest batch that takes the riding form (measured at H: 8 / 16 windows slower, 32 equal, 64 -1.2 %, 128 -2.6 %); DPE_BCS_SUMRIDE_MIN
     dpe::BcsChanDev *chan_d = nullptr;
     // pinned parameter staging: a ring of kStaging blocks, each guarded by an event recorded once its H2D copy (or the
@@ -1236,6 +1237,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     if (h->rideWord_d) (void)hipMemset(h->rideWord_d, 0, sizeof(unsigned long long) * W * kSumSlots);
     h->rideAllowed = !(getenv("DPE_BCS_NO_SUMRIDE") && atoi(getenv("DPE_BCS_NO_SUMRIDE")) != 0);
     if (getenv("DPE_BCS_SUMRIDE_MIN") && atoi(getenv("DPE_BCS_SUMRIDE_MIN")) >= 1) h->rideMinW = atoi(getenv("DPE_BCS_SUMRIDE_MIN"));
+    if (getenv("DPE_BCS_RIDE_LA") && atoi(getenv("DPE_BCS_RIDE_LA")) >= 1) h->rideLA = atoi(getenv("DPE_BCS_RIDE_LA"));
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     // chip-boundary kernel (dpe_bcs_chip.h): lag windows of 17..31 samples (wider: chunks of 64 lags) at sampling rates where a
     // sub-tile holds few chips, plain n/fs sample times; its moment block is one pass of kPass samples, and a chip's
@@ -1585,25 +1587,32 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // the parameter upload keeps a small kernel of its own (riding as well, every correlator block had to poll for it first thing:
     // 0.7035 against 0.696 ms per step)
     bool ride = chip2 && !dev && !h->graphs.capturing && vecOK && h->rideAllowed && nWindows >= h->rideMinW;
-    int rideF = 0, rideSB = 0;
-    if (ride) {   // a sum block's lanes fetch their share in whole rounds of kRideLoads loads: slots of two rounds when 64 slots allow it
-        const int n4 = S >> 2, per = (kRideLoads >= 32 ? 1 : 2) * kRideLoads * 64;
-        const int sb = (n4 + per - 1) / per < 1 ? 1 : ((n4 + per - 1) / per > kSumSlots ? kSumSlots : (n4 + per - 1) / per);
-        if (4 * ((n4 + sb - 1) / sb) + 3 >= 16384) ride = false;   // 30-bit sum fields
-        else sumBlocks = sb;
+    int rideF = 0, rideSB = 0, rideGS = 1;
+    if (ride) {   // one sum slot per correlator tile (the sum block then shares its tile's XCD): <= 64 slots, 31-bit sum fields
+        if (c2nBlk > kSumSlots || c2Lt + 8 >= 32768) ride = false;
+        else sumBlocks = c2nBlk;
     }
     if (ride) {
         const long long totalSum = (long long)nWindows * sumBlocks, NG = ((long long)c2nBlk * nWindows + 7) / 8;
-        const int lookAhead = 4;   // windows: a window's sums are complete >= 3 windows' worth of correlator blocks before its own
+        const int lookAhead = h->rideLA;   // windows between a sum block and the correlator blocks of its tile
         rideF = (int)(((long long)lookAhead * sumBlocks + 7) / 8 * 8);
         const long long groupsAvail = NG - ((long long)lookAhead * c2nBlk + 7) / 8 - 1;
         if (rideF >= totalSum || groupsAvail < 1) rideF = (int)((totalSum + 7) / 8 * 8);
-        else rideSB = (int)((((totalSum - rideF) + groupsAvail - 1) / groupsAvail + 7) / 8 * 8);
+        else {
+            // sum blocks per group of 8 K correlator blocks at a STEADY lead (a lead that grows puts the samples a sum block fetched
+            // out of its XCD's L2 before the correlator blocks of the same tile read them): whole eights per group, or one eight
+            // every rideGS groups; what does not fit behind the look-ahead joins the blocks in front
+            const long long rest = totalSum - rideF;
+            if (rest >= 8 * groupsAvail) { rideSB = (int)(rest / (8 * groupsAvail)) * 8; rideGS = 1; }
+            else { rideSB = 8; rideGS = (int)((8 * groupsAvail) / rest); }
+            const long long cap = (long long)rideSB * (groupsAvail / rideGS);
+            if (totalSum - cap > rideF) rideF = (int)((totalSum - cap + 7) / 8 * 8);
+        }
         if (nWindows > h->rideW || sumBlocks > h->rideSlots)   // slots this launch reads that the last one did not write: clear the words
             DPE_CHECK_HIP(hipMemsetAsync(h->rideWord_d, 0, sizeof(unsigned long long) * (size_t)h->cfg.maxWindows * kSumSlots, stream));
         h->rideW = nWindows;
         h->rideSlots = sumBlocks;
-        h->rideEpoch = h->rideEpoch % 15 + 1;
+        h->rideEpoch = h->rideEpoch % 3 + 1;
         if (upInSum) {
             h->prof.begin(0, stream);
             upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
@@ -1664,11 +1673,11 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     } while (0)
     if (c2) {
         const int c2Groups = (c2nBlk * nWindows + 7) / 8;
-        const dim3 cgrid(ride ? rideF + c2Groups * (rideSB + 8 * nChan) : c2Groups * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
+        const dim3 cgrid(ride ? rideF + ((c2Groups + rideGS - 1) / rideGS) * (rideSB + rideGS * 8 * nChan) : c2Groups * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
 #define DPE_LAUNCH_CHIP2(NM, LV, RD)                                                                                           \
     hipLaunchKernelGGL((bcs_bank_chip2_kernel<NM, LV, RD>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
                        nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->chipBits_d, h->part_d, h->mom_d,      \
-                       h->rideWord_d, h->rideEpoch, rideF, rideSB, h->status_d)
+                       h->rideWord_d, h->rideEpoch, rideF, rideSB, rideGS, h->status_d)
 #define DPE_LAUNCH_CHIP2_L(LV)                                                                        \
     case LV:                                                                                          \
         if (ride) { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, LV, true); else DPE_LAUNCH_CHIP2(6, LV, true); }   \

@@ -74,12 +74,12 @@ __device__ __forceinline__ float mask_pm1(unsigned long long m)
 // RIDE: the DC sums of the batch are computed by extra one-wave blocks of THIS launch instead of a kernel in front of it
 // (bcs_sum_kernel reads all samples at the HBM rate while the chip kernel, which is arithmetic-bound, waits behind it: 0.04 of a
 // 0.72 ms step at config H).  The launch's linear block index interleaves them with the correlator blocks -- rideF sum blocks
-// first, then rideSB of them in front of every group of 8 K correlator blocks (both multiples of 8, so a correlator block's index
-// mod 8 is still its XCD) -- far enough ahead (the host's choice of rideF / rideSB: >= 3 windows) that a correlator block all but
-// never waits.  Hand-over: ONE 64-bit word per slot of kSumSlots, {epoch : 4, I sum : 30, Q sum : 30} (the host takes this form only
-// when a slot holds < 16384 samples), written with an agent-scope atomic store and read with agent-scope atomic loads (lane <->
+// first, then rideSB of them in front of every rideGS groups of 8 K correlator blocks (both multiples of 8, so a correlator block's
+// index mod 8 is still its XCD) -- a steady ~4 windows ahead of their consumers (the host's choice of rideF / rideSB / rideGS), so that
+// a correlator block all but never waits.  Hand-over: ONE 64-bit word per slot of kSumSlots, {epoch : 2, I sum : 31, Q sum : 31} (the host takes this form only
+// when a slot holds < 32768 samples), written with an agent-scope atomic store and read with agent-scope atomic loads (lane <->
 // slot): tag and data arrive together, in one round trip that the block issues first thing and consumes after its set-up.  The
-// sum block also leaves the int64 sums in the ordinary slots for the kernels behind this launch.  Epochs cycle 1 .. 15 and every
+// sum block also leaves the int64 sums in the ordinary slots for the kernels behind this launch.  Epochs cycle 1 .. 3 and every
 // launch rewrites every word it will read; the host clears the words when the set of slots grows, so no older word can carry
 // the current epoch.  Forward progress: work groups are dispatched in index order per XCD and a sum block waits for nothing, so the
 // lowest-index undispatched sum block is never behind a full house of waiting blocks.  A wait that exceeds kRideSpinMax polls sets
@@ -89,7 +89,7 @@ constexpr int kRideSpinMax = 200000;
 #define DPE_RIDE_LOADS 16
 #endif
 constexpr int kRideLoads = DPE_RIDE_LOADS;   // loads in flight per lane of a sum block (24 or 32 push the kernel over its 170-register budget: scratch, 0.675 ms)
-__device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, long long winStride, int S, int nW, int nSumBlk, int sidx,
+__device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, long long winStride, int S, int nW, int nSumBlk, int Lt, int sidx,
                                                long long *__restrict__ sums, unsigned long long *__restrict__ rideWord, unsigned epoch)
 {
     const int w = sidx / nSumBlk, b = sidx - w * nSumBlk;
@@ -97,9 +97,13 @@ __device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, l
     const int lane = threadIdx.x;
     const int *x = reinterpret_cast<const int *>(iq + (size_t)w * winStride * 2);   // (the host takes this form only for 16-byte aligned windows)
     const int4 *x4 = reinterpret_cast<const int4 *>(x);
-    const int n4 = S >> 2, per = (n4 + nSumBlk - 1) / nSumBlk;
-    const int lo = b * per, hi = (lo + per < n4) ? lo + per : n4;
-    int sI = 0, sQ = 0;   // a block adds < 16384 samples
+    // slot b = the samples of correlator tile b (Lt of them, cut at multiples of four): sum block (w, b) has the linear index of
+    // tile (w, b), mod 8 -- it runs on the XCD whose L2 that tile's K correlator blocks will read the same samples through
+    const int n4 = S >> 2;
+    const int lo = b == 0 ? 0 : (int)(((long long)b * Lt + 3) >> 2);
+    int hi = b == nSumBlk - 1 ? n4 : (int)(((long long)(b + 1) * Lt + 3) >> 2);
+    if (hi > n4) hi = n4;
+    int sI = 0, sQ = 0;   // a block adds < 32768 samples
     auto add4 = [&](const int4 v) {
         sI += (short)(v.x & 0xFFFF) + (short)(v.y & 0xFFFF) + (short)(v.z & 0xFFFF) + (short)(v.w & 0xFFFF);
         sQ += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
@@ -125,7 +129,7 @@ __device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, l
     if (lane == 0) {
         long long *o = sums + ((size_t)w * kSumSlots + b) * 2;
         o[0] = sI; o[1] = sQ;
-        const unsigned long long word = ((unsigned long long)epoch << 60) | ((unsigned long long)((unsigned)sI & 0x3FFFFFFFu) << 30) | (unsigned long long)((unsigned)sQ & 0x3FFFFFFFu);
+        const unsigned long long word = ((unsigned long long)epoch << 62) | ((unsigned long long)((unsigned)sI & 0x7FFFFFFFu) << 31) | (unsigned long long)((unsigned)sQ & 0x7FFFFFFFu);
         __hip_atomic_store(rideWord + (size_t)w * kSumSlots + b, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -138,7 +142,7 @@ __device__ __forceinline__ void ride_window_mean(const unsigned long long *__res
     const unsigned long long *wd = rideWord + (size_t)w * kSumSlots + lane;
     unsigned long long v = first;
     for (int it = 0;; ++it) {
-        if (__ballot(lane < nSumBlk && (unsigned)(v >> 60) != epoch) == 0ull) break;
+        if (__ballot(lane < nSumBlk && (unsigned)(v >> 62) != epoch) == 0ull) break;
         if (it >= kRideSpinMax || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) {
             if (lane == 0) atomicOr(status, 4);
             break;
@@ -147,9 +151,9 @@ __device__ __forceinline__ void ride_window_mean(const unsigned long long *__res
         if (lane < nSumBlk) v = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     long long tI = 0, tQ = 0;
-    if (lane < nSumBlk) {   // 30-bit two's-complement fields
-        tI = (long long)((int)((unsigned)(v >> 30) << 2) >> 2);
-        tQ = (long long)((int)((unsigned)v << 2) >> 2);
+    if (lane < nSumBlk) {   // 31-bit two's-complement fields
+        tI = (long long)((int)((unsigned)(v >> 31) << 1) >> 1);
+        tQ = (long long)((int)((unsigned)v << 1) >> 1);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -168,7 +172,8 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
                                                                const int8_t *__restrict__ chipTable,
                                                                const uint32_t *__restrict__ chipBits,
                                                                float2 *__restrict__ part, float2 *__restrict__ mom,
-                                                               unsigned long long *__restrict__ rideWord, unsigned epoch, int rideF, int rideSB, int *__restrict__ status)
+                                                               unsigned long long *__restrict__ rideWord, unsigned epoch, int rideF, int rideSB, int rideGS,
+                                                               int *__restrict__ status)
 {
     constexpr int NL = 65;   // partial layout shared with the other stage-1 kernels: entry j <-> lag j - 32 (j = 64 unused)
     __shared__ float2 sQ[k2QLen];
@@ -181,12 +186,12 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
         int sidx = -1;
         if (bx < rideF) sidx = bx;
         else {
-            const int per = rideSB + 8 * K, r = bx - rideF, gI = r / per, o = r - gI * per;
-            if (o < rideSB) sidx = rideF + gI * rideSB + o;
-            else bx = gI * 8 * K + (o - rideSB);
+            const int bankPer = rideGS * 8 * K, per = rideSB + bankPer, r = bx - rideF, sg = r / per, o = r - sg * per;
+            if (o < rideSB) sidx = rideF + sg * rideSB + o;
+            else bx = sg * bankPer + (o - rideSB);
         }
         if (sidx >= 0) {
-            ride_sum_block(iq, winStride, S, nW, nSumBlk, sidx, const_cast<long long *>(sums), rideWord, epoch);
+            ride_sum_block(iq, winStride, S, nW, nSumBlk, Lt, sidx, const_cast<long long *>(sums), rideWord, epoch);
             return;
         }
     }
