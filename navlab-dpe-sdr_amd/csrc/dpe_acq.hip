@@ -473,7 +473,9 @@ __global__ __launch_bounds__(256) void acq_radix10_kernel(const float2 *__restri
             const float2 w = tw25k[m * k0];   // m k0 <= 2499 * 9 < 25000
             y = acq_cmul(y, af2{w.x, w.y});
         }
-        z[(size_t)k0 * M] = make_float2(y.x, y.y);
+        // (streaming store: the 800 MB of Z written per 32 x 125 search must not push X and Rc -- re-read by every block -- out of L2)
+        __builtin_nontemporal_store(y.x, &z[(size_t)k0 * M].x);
+        __builtin_nontemporal_store(y.y, &z[(size_t)k0 * M].y);
     }
 }
 
