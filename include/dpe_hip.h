@@ -137,6 +137,16 @@ int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, co
  * correlator block gave up waiting for them (never observed; the banks of that Update are then wrong).  DPE_BCS_NO_SUMRIDE=1 at
  * create keeps the separate DC-sum kernel. */
 int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream);
+/* A promise about the values behind the device ports, for sampling rates of >= 16 samples per chip: which stage-1 kernel runs is
+ * a property of the channel values there, and without a promise dpe_bcs_update_dev reads back the <= 3 KB block its prep kernel
+ * derived -- one small copy and one stream wait per window.  flags bit 0 (DPE_DEV_HINT_CHIP): every channel has 2 pi |fi| <= 0.25 fc
+ * (|fi| below ~40 kHz) and a code frequency within 1e-5 of 1.023 MHz.  The call then decides from nominal values, reads nothing
+ * back and does not wait for the stream; the prep kernel checks the promise (and that the nav-bit boundary falls on a chip boundary
+ * of the replica, which it does unless fp64 rounding separates the two expressions -- about once in 1e10 windows): bit 3 of
+ * dpe_bcs_dev_status = it did not hold for that window (banks then within the chip kernel's error for such input, not within the
+ * stated tolerance; re-run the window without the hint).  0 clears the promise. */
+#define DPE_DEV_HINT_CHIP 1
+int dpe_bcs_set_dev_hint(dpe_bcs *h, int32_t flags);
 /* Output ports CodeScores / CarrScores / NumFFTPoints (batchcorrscores.cu:696-698,869-874).
  * codeBank_dev: float2 [maxWindows][maxChannels][2L+1]; entry j = reference
  * codeCorrOut_d[k*S + S/2 - L + j].  carrBank_dev: float2 [..][..][2B+1]; entry j = reference

@@ -1067,14 +1067,23 @@ struct BcsPortsDev {
     const int *cpEla, *cpRef;
     const unsigned char *prn;
 };
-__global__ void bcs_prep_kernel(BcsPortsDev p, int K, double fs, int S, BcsChanDev *__restrict__ out, int *__restrict__ status)
+// hintL1 > 0 (dpe_bcs_set_dev_hint): the host has chosen the chip kernels from NOMINAL channel values without reading this block back;
+// the conditions it could not check are checked here, bit 3 of the status = one of them does not hold (chips of hintL1 or hintL1 + 1
+// samples, code step within the assumed bound, 2 pi |fi| <= 0.25 fc, the nav-bit boundary on a chip boundary of the replica).
+__global__ void bcs_prep_kernel(BcsPortsDev p, int K, double fs, int S, BcsChanDev *__restrict__ out, int *__restrict__ status, int hintL1,
+                                double hintStepMax)
 {
     const int k = threadIdx.x;
     if (k == 0) *status = 0;
     __syncthreads();
     if (k >= K) return;
     int bad;
-    out[k] = bcs_prep_one(p.rc[k], p.ri[k], p.fc[k], p.fi[k], p.cpEla[k], p.cpRef[k], (int)p.prn[k], fs, S, bad);
+    const BcsChanDev d = bcs_prep_one(p.rc[k], p.ri[k], p.fc[k], p.fi[k], p.cpEla[k], p.cpRef[k], (int)p.prn[k], fs, S, bad);
+    out[k] = d;
+    if (hintL1 > 0) {
+        const bool offBoundary = d.hasFlip && (int)fma((double)d.idxNext, d.codeStep, d.rc) == (int)fma((double)(d.idxNext - 1), d.codeStep, d.rc);
+        if ((int)d.invStep != hintL1 || d.codeStep > hintStepMax || 6.283185307179586 * fabs(d.fi) > 0.25 * d.fc || offBoundary) bad |= 8;
+    }
     if (bad) atomicOr(status, bad);
 }
 
@@ -1147,6 +1156,7 @@ struct dpe_bcs {
     const char *lastKernel = "";   // stage-1 kernel of the last Update (dpe_bcs_stage1_kernel)
     dpe::ChmKArgs co{};            // a task of the device-resident channel manager for the next stage-1 launch (dpe_bcs_cotask_set)
     bool coPending = false;
+    int devHint = 0;               // dpe_bcs_set_dev_hint: bit 0 = the caller promises the chip kernels' conditions for the device-parameter form
     std::vector<int32_t> idxNext_h;
     dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
     dpe::GraphCache graphs;
@@ -1399,7 +1409,19 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // block bcs_prep_kernel has just derived -- <= 3 KB and one stream wait per window, against a 4-5 x slower stage 1;
     // at lower rates nothing is fetched and nothing the host decides depends on the values.
     bool chip = h->chipOK && h->chipAllowed;
-    if (chip && dev) {
+    if (chip && dev && (h->devHint & 1)) {
+        // the caller's promise (dpe_bcs_set_dev_hint): decide from nominal values -- code frequency F_CA within 1e-5 (ten times the
+        // largest code Doppler), carrier offset inside the closed-form DC term's range -- and let bcs_prep_kernel check what was
+        // promised (status bit 3); nothing is read back, the host does not wait for the stream
+        for (int i = 0; i < nWindows * nChan; ++i) {
+            BcsChanDev &d = h->chan_h[i];
+            d = BcsChanDev{};
+            d.fc = kFCA; d.fi = 0.0;
+            d.codeStep = kFCA / fs * (1.0 + 1e-5);
+            d.invStep = fs / kFCA;
+            d.hasFlip = 0;
+        }
+    } else if (chip && dev) {
         DPE_CHECK_HIP(hipMemcpyAsync(h->chan_h, h->chan_d, sizeof(BcsChanDev) * nWindows * nChan, hipMemcpyDeviceToHost, stream));
         DPE_CHECK_HIP(hipStreamSynchronize(stream));
     }
@@ -1776,9 +1798,18 @@ int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, co
                 ports->cpElapsedStart && ports->cpReference && ports->validPRNs, "[BatchCorrScores] Update: a device port pointer is null");
     const BcsPortsDev p = {ports->codePhaseStart, ports->carrierPhaseStart, ports->codeFrequency, ports->carrierFrequency,
                            ports->cpElapsedStart, ports->cpReference, ports->validPRNs};
+    const bool hinted = (h->devHint & 1) && h->chipOK && h->chipAllowed;
+    const double nomStep = kFCA / h->cfg.samplingFrequency;
     hipLaunchKernelGGL(bcs_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, h->cfg.samplingFrequency,
-                       h->cfg.samplesPerWindow, h->chan_d, h->status_d);
+                       h->cfg.samplesPerWindow, h->chan_d, h->status_d, hinted ? (int)(1.0 / nomStep) : 0, nomStep * (1.0 + 1e-5));
     return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
+}
+
+int dpe_bcs_set_dev_hint(dpe_bcs *h, int32_t flags)
+{
+    DPE_REQUIRE(h, "[BatchCorrScores] set_dev_hint: null handle");
+    h->devHint = flags;
+    return 0;
 }
 
 int dpe_bcs_update_prepared(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, dpe_stream_t stream)

@@ -31,7 +31,7 @@ EXPORTS = [
     "dpe_comm_allgather", "dpe_bcm_exchange_keys", "dpe_bcs_allgather_banks",
     "dpe_bcs_update_dev", "dpe_bcs_dev_status", "dpe_bcm_update_dev", "dpe_bcm_export_scores_f64",
     "dpe_chm_dev_create", "dpe_chm_dev_destroy", "dpe_chm_dev_attach", "dpe_chm_dev_ports", "dpe_chm_dev_start", "dpe_chm_dev_update",
-    "dpe_chm_dev_step", "dpe_chm_dev_fix", "dpe_chm_dev_read", "dpe_bcs_update_prepared", "dpe_bcm_update_prepared",
+    "dpe_chm_dev_step", "dpe_chm_dev_fix", "dpe_chm_dev_read", "dpe_bcs_update_prepared", "dpe_bcm_update_prepared", "dpe_bcs_set_dev_hint",
 ]
 
 
@@ -285,6 +285,10 @@ class BatchCorrScores:
         """Stage 1 sharded by window: this rank's banks of the last Update into code_all / carr_all (device pointers,
         [nRanks * W_local][maxChannels][2L+1 | 2B+1] float2), rank-major (dpe_bcs_allgather_banks)."""
         _check(lib().dpe_bcs_allgather_banks(self._h, comm._h, _ptr(code_all), _ptr(carr_all), _stream(stream)))
+
+    def set_dev_hint(self, flags=1):
+        """dpe_bcs_set_dev_hint: flags bit 0 = the chip kernels' conditions hold for every channel (no readback in UpdateDev)."""
+        _check(lib().dpe_bcs_set_dev_hint(self._h, C.c_int32(flags)))
 
     def dev_status(self, stream=None):
         st = C.c_int32()

@@ -192,17 +192,28 @@ def test_device_ports_at_a_high_sampling_rate_take_the_chip_kernel():
                  carrierFrequency=dv(s["fi"], np.float64), cpElapsedStart=dv(s["cp"], np.int32), cpReference=dv(s["cp_ref"], np.int32),
                  validPRNs=dv(s["prn"], np.uint8))
     out = {}
-    for form in ("host", "dev"):
+    for form in ("host", "dev", "hint"):
         bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=1, max_channels=K)
         bcs.Start()
         if form == "host":
             bcs.Update(d, cs)
         else:
+            if form == "hint":           # the caller's promise instead of the readback (dpe_bcs_set_dev_hint): same kernel, checked on the device
+                bcs.set_dev_hint(1)
             bcs.UpdateDev(d, K, ports)
             assert bcs.dev_status() == 0
         out[form] = (bcs.read_banks(), bcs.read_info(), bcs.stage1_kernel)
+        if form == "hint":               # a carrier offset beyond the promise is flagged (bit 3), the call still returns
+            bad = dict(ports)
+            bad["carrierFrequency"] = dv(np.asarray(s["fi"]) + 60e3, np.float64)
+            bcs.UpdateDev(d, K, bad)
+            assert bcs.dev_status() == 8
+            bcs.UpdateDev(d, K, ports)
+            assert bcs.dev_status() == 0
         bcs.Stop()
-    assert out["host"][2] == out["dev"][2] == "bcs_bank_chip2_kernel"
+    assert out["host"][2] == out["dev"][2] == out["hint"][2] == "bcs_bank_chip2_kernel"
+    for a, b in zip(out["hint"][0], out["dev"][0]):       # nominal tile length: the banks of the two device forms agree to rounding
+        assert np.abs(a - b).max() < 2e-7 * np.abs(b).max()
     (code0, carr0), info0, _ = out["host"]
     (code1, carr1), info1, _ = out["dev"]
     assert np.array_equal(info1[0], info0[0]) and np.array_equal(info1[1], info0[1]) and np.array_equal(info1[2], info0[2])
