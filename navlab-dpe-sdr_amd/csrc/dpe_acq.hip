@@ -185,17 +185,32 @@ constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequ
 // decimation-in-frequency stage already applied -- so y[10 m' + k0] = IFFT2500(Z[..][k0])[m'] and the ten lag aliases of delay
 // j = 10 r + k0 are the outputs r + 250 n of transform k0: exactly the ten values thread r holds.  nSeg = 10 transforms per
 // (PRN, bin), no multiply, each transform's ten-fold sums written at stride 10.
-template <bool ALIAS>
+// R10 (with ALIAS): the radix-10 stage of acq_radix10_kernel runs INSIDE this block -- spectrum product, 10-point butterflies and twiddles for
+// the block's (PRN, bin), written to a scratch slot of 25 000 complex values that the block then transforms from.  The slots are a small pool
+// (r10Slots x 200 KB, claimed with a compare-and-swap, released at the end) that is rewritten all the time: it lives in L2 / the Infinity Cache
+// instead of travelling to HBM and back as the 800 MB of Z of a 32 x 125 search did (X = the bins' spectra, Rc = the PRNs' spectra here).
+template <bool ALIAS, bool R10 = false>
 __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc,
                                                               const float2 *__restrict__ tw, int B, int nSeg, int binsPerBlock, int pOffset,
-                                                              float *__restrict__ surf, unsigned int *__restrict__ mpBits)
+                                                              float *__restrict__ surf, unsigned int *__restrict__ mpBits,
+                                                              const float2 *__restrict__ tw25k = nullptr, float2 *__restrict__ r10Scratch = nullptr,
+                                                              unsigned int *__restrict__ r10Busy = nullptr, int r10Slots = 0)
 {
+    static_assert(ALIAS || !R10, "the in-block radix-10 stage belongs to the 25 000-point form");
     constexpr int N = kAcqFusedLen, SS = kAcqSubStride;
     __shared__ float2 sA[10 * SS], sB[10 * SS];
     __shared__ float2 sW250[256], sW25[32];   // W250^n = tw[10 n], W25^n = tw[100 n]: the twiddles of passes 2 and 3
+    __shared__ int sSlot;
     const int t = threadIdx.x, p = blockIdx.y;
     const bool act = t < 250;
     const int tt = act ? t : 0;
+    if constexpr (R10) {
+        if (t == 0) {   // a free scratch slot: there are more slots than blocks resident at once, so the search ends
+            int sl = (int)((blockIdx.y * gridDim.x + blockIdx.x) % (unsigned)r10Slots);
+            while (atomicCAS(&r10Busy[sl], 0u, 1u) != 0u) sl = sl + 1 == r10Slots ? 0 : sl + 1;
+            sSlot = sl;
+        }
+    }
     if (act) sW250[t] = tw[10 * t];
     if (t < 25) sW25[t] = tw[100 * t];
     // the PRN's spectrum and the pass-1 twiddles W^(t k1) of this thread's ten elements stay in registers across the bins
@@ -217,6 +232,40 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     const int nb = (B - b0) < binsPerBlock ? (B - b0) : binsPerBlock;
     const int nTr = nb * nSeg;   // transforms of this block: rows b0 nSeg .. of X (ALIAS: of this PRN's Z), consecutive
     const float2 *x0 = X + ((ALIAS ? (size_t)p * B : (size_t)0) + (size_t)b0) * nSeg * N;
+    if constexpr (R10) {
+        __syncthreads();
+        float2 *z = r10Scratch + (size_t)sSlot * (10 * N);
+        if (act) {
+            const float2 *xb = X + (size_t)b0 * (10 * N), *rp = Rc + (size_t)p * (10 * N);
+            // the block's 2 500 values of m, ten per thread: Z[k0][m] = W^(m k0) sum_q P[m + 2500 q] W10^(q k0).  The next m's twenty
+            // spectrum values are fetched under this m's butterfly (rolled loop: one m at a time the phase was ten memory latencies long)
+            float2 na[10], nc[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) { na[q] = xb[t + N * q]; nc[q] = rp[t + N * q]; }
+#pragma unroll 1
+            for (int j = 0; j < 10; ++j) {
+                const int m = t + 250 * j;
+                af2 v[10];
+                float2 w[10];
+#pragma unroll
+                for (int k0 = 1; k0 < 10; ++k0) w[k0] = tw25k[m * k0];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) v[q] = acq_cmul(af2{na[q].x, na[q].y}, af2{nc[q].x, nc[q].y});
+                if (j < 9) {
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) { na[q] = xb[m + 250 + N * q]; nc[q] = rp[m + 250 + N * q]; }
+                }
+                acq_idft10(v);
+#pragma unroll
+                for (int k0 = 0; k0 < 10; ++k0) {
+                    const af2 y = k0 ? acq_cmul(v[k0], af2{w[k0].x, w[k0].y}) : v[k0];
+                    z[(size_t)k0 * N + m] = make_float2(y.x, y.y);
+                }
+            }
+        }
+        __syncthreads();   // (the block's own stores, written through to L2: visible to all of its waves behind the barrier)
+        x0 = z;
+    }
     float2 xn[10];   // the next transform's spectrum, fetched under this one
 #pragma unroll
     for (int q = 0; q < 10; ++q) xn[q] = x0[tt + 250 * q];
@@ -329,6 +378,10 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     if (!ALIAS && act) {
 #pragma unroll
         for (int q = 0; q < 10; ++q) atomicMax(&mpBits[(size_t)p * N + t + 250 * q], __float_as_uint(mx[q]));
+    }
+    if constexpr (R10) {
+        __syncthreads();
+        if (t == 0) atomicExch(&r10Busy[sSlot], 0u);
     }
 }
 
@@ -844,6 +897,9 @@ struct dpe_acq {
     int SX;                          // samples per Doppler row after the wipe-off (M in mode 0: time-folded)
     dpe::FftPlan planFwd, planInv;
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
+    unsigned int *r10Busy_d = nullptr;   // claim words of the scratch slots of the in-block radix-10 stage
+    int r10Slots = 0;
+    bool r10InBlock = true;              // DPE_ACQ_NO_R10_INBLOCK=1: acq_radix10_kernel + Z through memory, as before (A/B runs)
     float *surf_d = nullptr, *mp_d = nullptr;
     int *peakIdx_d = nullptr;   // [2][P]: max_code_idx, max_dopp_idx
     float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused searches (acq_corr2500_kernel), else null
@@ -871,7 +927,7 @@ int dpe_acq_destroy(dpe_acq *h)
     h->planFwd.destroy();
     h->planInv.destroy();
     h->planFine.destroy();
-    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d};
+    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->r10Busy_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->stats_h) (void)hipHostFree(h->stats_h);
     delete h;
@@ -961,6 +1017,16 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             set_error("[Acquisition] create: twiddle table");
             rc = -1;
         } else h->fusedAlias = true;
+        if (h->fusedAlias) {
+            h->r10InBlock = !(getenv("DPE_ACQ_NO_R10_INBLOCK") && atoi(getenv("DPE_ACQ_NO_R10_INBLOCK")) != 0);
+            const long long pairs = (long long)h->chunk * B;        // Y_d holds chunk x B rows of S: the pool is a part of it
+            h->r10Slots = (int)(pairs < 1024 ? pairs : 1024);       // > the 768 blocks resident at once (3 per CU)
+            h->r10Busy_d = dev_alloc<unsigned int>((size_t)h->r10Slots);
+            if (!h->r10Busy_d || hipMemset(h->r10Busy_d, 0, sizeof(unsigned int) * h->r10Slots) != hipSuccess) {
+                set_error("[Acquisition] create: scratch claim words");
+                rc = -1;
+            }
+        }
     }
     h->fusedFwd = !(getenv("DPE_ACQ_NO_FUSED_FWD") && atoi(getenv("DPE_ACQ_NO_FUSED_FWD")) != 0);
     if (!rc && (wantFused || wantAlias)) {
@@ -1009,6 +1075,11 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                            B, h->cfg.mode == 0 ? 1 : h->N, kAcqFusedBins, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
+        if (h->fusedAlias && h->r10InBlock) {
+            hipLaunchKernelGGL((acq_corr2500_kernel<true, true>), dim3(B, pc), dim3(256), 0, st, h->X_d, h->Rc_d + (size_t)p0 * h->len, h->tw_d, B, h->N, 1, p0,
+                               h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), h->tw25k_d, h->Y_d, h->r10Busy_d, h->r10Slots);
+            continue;
+        }
         if (h->fusedAlias) {
             hipLaunchKernelGGL(acq_radix10_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->X_d, h->Rc_d + (size_t)p0 * h->len, h->tw25k_d,
                                B, h->Y_d);
