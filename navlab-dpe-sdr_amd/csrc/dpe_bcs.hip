@@ -842,6 +842,7 @@ __global__ __launch_bounds__(256) void bcs_bank_wide_kernel(BcsParamBlock pb, in
 
 #include "dpe_bcs_chip.h"   // chip-boundary form of stage 1 (high sampling rates)
 #include "dpe_bcs_chip2.h"  // second form: lanes <-> chips in the prefix stage too (16 .. 25 samples per chip)
+#include "dpe_bcs_chip3.h"  // third form: SV-independent prefix arrays per tile, per-SV work per chip and per flip only
 #include "dpe_bcs_fft.h"    // full-length FFT form (fallback for very wide lag / bin windows)
 
 namespace dpe {
@@ -916,7 +917,9 @@ __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finali
         while (np2 < pairs) np2 <<= 1;
         const int T = 256 / np2;                     // pairs <= 130 -> T >= 1
         const int pair = tid / T, sub = tid - pair * T;
-        float2 acc = make_float2(0.f, 0.f);
+        // (compensated: a window's lag sums reach ~1e7 while a block partial is ~1e5 -- added plainly, a few hundred partials cost
+        //  the total 4e-7 of its value; the third chip form writes one partial per group of tiles)
+        float2 acc = make_float2(0.f, 0.f), comp = make_float2(0.f, 0.f);
         if (pair < pairs) {
             const int side = pair / NL, lag = pair - side * NL;
             for (int b0 = sub; b0 < nBlk; b0 += 8 * T) {
@@ -927,7 +930,12 @@ __global__ __launch_bounds__(256, (kNMom == 4 && !FUSE) ? 4 : 1) void bcs_finali
                     v[u] = bq < nBlk ? pp[(size_t)(bq * 2 + side) * NL + lag] : make_float2(0.f, 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; }
+                for (int u = 0; u < 8; ++u) {   // Kahan steps (no fast-math in this build: the compiler keeps them)
+                    const float yx = v[u].x - comp.x, yy = v[u].y - comp.y;
+                    const float tx = acc.x + yx, ty = acc.y + yy;
+                    comp.x = (tx - acc.x) - yx; comp.y = (ty - acc.y) - yy;
+                    acc.x = tx; acc.y = ty;
+                }
             }
         }
         sTmp[tid] = acc;
@@ -1114,6 +1122,10 @@ struct dpe_bcs {
     bool chip2Allowed = true;    // DPE_BCS_NO_CHIP2=1: never the lanes-as-chips form (dpe_bcs_chip2.h; A/B tests)
     int chip2Resident = 0;       // co-resident waves of that kernel on the whole device
     int chip2PForce = 0;         // DPE_BCS_CHIP2_P at create: passes per tile of that kernel (experiments)
+    bool chip3Allowed = true;    // DPE_BCS_NO_CHIP3=1: never the shared-prefix form (dpe_bcs_chip3.h; A/B tests)
+    int chip3TForce = 0;         // DPE_BCS_CHIP3_T at create: tiles per block of that kernel (experiments)
+    int chip3MinTiles = 0;       // smallest batch (tiles x windows) that takes it (DPE_BCS_CHIP3_MIN)
+    int cus = 256;
     int nPassChip = 0, nBlkAlloc = 0;
     // full-length FFT fallback (dpe_bcs_fft.h): lag windows beyond DPE_MAX_LAG_HALF_WIDTH, bin windows beyond the moment
     // expansion, or DPE_BCS_FORCE_FFT=1 at create (A/B tests)
@@ -1269,6 +1281,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         h->resident16 = ((h->LH <= 4 && !needTable) ? dpe::kB16Blocks : 3) * cus;   // the kernel's launch bounds
+        h->cus = cus;
     }
     if (h->chipOK) {
         // partial sums of up to 128 blocks per (window, SV); a handle for a few windows gets one block per pass
@@ -1335,6 +1348,10 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->chipAllowed = getenv("DPE_BCS_NO_CHIP") == nullptr;
     h->chip2Allowed = getenv("DPE_BCS_NO_CHIP2") == nullptr;
     if (const char *e = getenv("DPE_BCS_CHIP2_P")) h->chip2PForce = atoi(e);
+    h->chip3Allowed = getenv("DPE_BCS_NO_CHIP3") == nullptr && (getenv("DPE_BCS_CHIP3") != nullptr || getenv("DPE_BCS_CHIP3_MIN") != nullptr);   // (opt-in while it is being tuned)
+    if (const char *e = getenv("DPE_BCS_CHIP3_T")) h->chip3TForce = atoi(e);
+    h->chip3MinTiles = 3 * h->cus;   // a block per tile group: below ~one block per resident slot the one-wave blocks of the second form fill the chip better
+    if (const char *e = getenv("DPE_BCS_CHIP3_MIN")) h->chip3MinTiles = atoi(e);
     if (const char *e = getenv("DPE_BCS_CHIP_TPB")) h->chipTpbForce = atoi(e);
     if (const char *e = getenv("DPE_BCS_TPB16")) h->tpb16Force = atoi(e);
 #ifdef DPE_EXPERIMENTS   // ablation switches: never in the product library (the first one makes the banks wrong)
@@ -1600,7 +1617,45 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
             c2NMom = (std::pow(thc, 4) / 24.0 < 1e-7) ? 4 : 6;
         }
     }
-    h->lastKernel = chip2 ? "bcs_bank_chip2_kernel" : chip ? "bcs_bank_chip_kernel" : use16 ? "bcs_bank16_kernel" : wide ? "bcs_bank_wide_kernel" : "bcs_bank_kernel";
+    // third form (dpe_bcs_chip3.h): a block per group of T tiles serves all SVs from SV-independent prefix arrays; host-parameter
+    // batches only (it wants >= ~one block per resident slot), every carrier offset inside the second-order chip expansion
+    bool chip3 = chip2 && h->chip3Allowed && !dev;
+    int c3Lt = 0, c3T = 1, c3nBlk = 0, c3NMom = 6, c3NW = 4, c3NSV = 1, c3nKG = 1;
+    size_t c3Lds = 0;
+    for (int i = 0; chip3 && i < nWindows * nChan; ++i)
+        if (6.283185307179586 * std::fabs(h->chan_h[i].carrStep) * 0.5 * (c2L1 + 1) > (double)k3PhiMax) chip3 = false;
+    if (chip3) {
+        if (nChan <= 4) { c3NW = 4; c3NSV = 1; }
+        else if (nChan <= 8) { c3NW = 4; c3NSV = 2; }
+        else { c3NW = 6; c3NSV = 2; }
+        c3nKG = (nChan + c3NW * c3NSV - 1) / (c3NW * c3NSV);
+        const int maxEnt = c3NW == 4 ? Chip3Shape<4>::kMaxEntries : Chip3Shape<6>::kMaxEntries;
+        c3Lt = (int)std::floor(((double)k3MaxOwn - 1.01) / stepMax);   // <= 62 chip starts inside a tile, + the window's clipped first chip in tile 0
+        if (c3Lt > maxEnt - (k3HL + k3HR + 1)) c3Lt = maxEnt - (k3HL + k3HR + 1);
+        if (c3Lt > S) c3Lt = S;
+        if (const char *e = getenv("DPE_BCS_CHIP3_LT")) { const int v = atoi(e); if (v >= 256 && v < c3Lt) c3Lt = v; }   // (experiments: shorter tiles)
+        const int nTiles = (S + c3Lt - 1) / c3Lt;
+        const double thetaB = 6.283185307179586 * h->cfg.binHalfWidth / (double)h->C;
+        const double halfMax = std::pow(2e-7 * 720.0, 1.0 / 6.0) / thetaB;   // 6-moment Taylor radius (samples)
+        int Tmax = (int)((2.0 * (halfMax - 26.0)) / c3Lt);
+        const int Tmin = (nTiles + h->nBlkAlloc - 1) / h->nBlkAlloc;
+        if (Tmax > nTiles) Tmax = nTiles;
+        if (c3Lt < 256 || Tmax < 1 || Tmin > Tmax || (long long)nTiles * nWindows < h->chip3MinTiles) chip3 = false;
+        else {
+            // tiles per block: enough blocks for ~6 rounds of the resident set, as few block partials as that allows
+            const long long resident = 3ll * h->cus;
+            long long t = ((long long)nTiles * nWindows * c3nKG) / (6 * resident);
+            c3T = (int)(t < Tmin ? Tmin : (t > Tmax ? Tmax : t));
+            if (c3T < 1) c3T = 1;
+            if (h->chip3TForce >= Tmin && h->chip3TForce <= Tmax) c3T = h->chip3TForce;
+            c3nBlk = (nTiles + c3T - 1) / c3T;
+            const double thc = thetaB * (0.5 * c3T * c3Lt + 26.0);
+            c3NMom = (std::pow(thc, 4) / 24.0 < 1e-7) ? 4 : 6;
+            const size_t nEnt = (size_t)c3Lt + k3HL + k3HR + 1;
+            c3Lds = ((nEnt * 8 + 15) & ~(size_t)15) + nEnt * 16 + (size_t)c3NW * k3List * 16 + (size_t)c3NW * 6 * 4;
+        }
+    }
+    h->lastKernel = chip3 ? "bcs_bank_chip3_kernel" : chip2 ? "bcs_bank_chip2_kernel" : chip ? "bcs_bank_chip_kernel" : use16 ? "bcs_bank16_kernel" : wide ? "bcs_bank_wide_kernel" : "bcs_bank_kernel";
     const dim3 grid(nBlk, nChan, nWindows), block(256);
     // single windows (<= 37 (window, channel) pairs) with a dense stage-1 kernel: no separate DC-sum launch, the
     // sums ride along in the bank kernel (FUSE) and the finalize kernel applies the mean
@@ -1608,7 +1663,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // chip2 batches: the DC sums ride in the chip2 launch (sum blocks interleaved ahead of the correlator blocks, dpe_bcs_chip2.h);
     // the parameter upload keeps a small kernel of its own (riding as well, every correlator block had to poll for it first thing:
     // 0.7035 against 0.696 ms per step)
-    bool ride = chip2 && !dev && !h->graphs.capturing && vecOK && h->rideAllowed && nWindows >= h->rideMinW;
+    bool ride = chip2 && !chip3 && !dev && !h->graphs.capturing && vecOK && h->rideAllowed && nWindows >= h->rideMinW;
     int rideF = 0, rideSB = 0, rideGS = 1;
     if (ride) {   // one sum slot per correlator tile (the sum block then shares its tile's XCD): <= 64 slots, 31-bit sum fields
         if (c2nBlk > kSumSlots || c2Lt + 8 >= 32768) ride = false;
@@ -1683,17 +1738,37 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
                                  : (h->cfg.lagHalfWidth > 32 ? (h->cfg.lagHalfWidth - 32 + 64) / 65 : 0);
     for (int chunk = 0; chunk <= 2 * nSideChunks; ++chunk) {
     const int lagShift = chunk == 0 ? 0 : ((chunk + 1) / 2) * chunkLags * ((chunk & 1) ? 1 : -1);
-    const bool c2 = chip2 && lagShift == 0;   // the second form produces the centre chunk; side chunks of a wider window use the first
-    const int nMomUse = c2 ? c2NMom : chip ? chipNMom : h->nMom;
-    const int nBlkUse = c2 ? c2nBlk : nBlk;
-    const int momLenUse = c2 ? c2Lt : chip ? tpb * kPass : kSub;
+    const bool c3 = chip3 && lagShift == 0;   // the second / third form produce the centre chunk; side chunks of a wider window use the first
+    const bool c2 = chip2 && !chip3 && lagShift == 0;
+    const int nMomUse = c3 ? c3NMom : c2 ? c2NMom : chip ? chipNMom : h->nMom;
+    const int nBlkUse = c3 ? c3nBlk : c2 ? c2nBlk : nBlk;
+    const int momLenUse = c3 ? c3T * c3Lt : c2 ? c2Lt : chip ? tpb * kPass : kSub;
     h->prof.begin(1, stream);
 #define DPE_LAUNCH_BANK(LHV)            \
     do {                                \
         if (h->nMom == 4) DPE_LAUNCH_BANK2(LHV, 4); \
         else DPE_LAUNCH_BANK2(LHV, 6);  \
     } while (0)
-    if (c2) {
+    if (c3) {
+        const dim3 cgrid((unsigned)((long long)c3nBlk * nWindows * c3nKG));
+#define DPE_LAUNCH_CHIP3(NM, NWV, NSVV)                                                                                              \
+    hipLaunchKernelGGL((bcs_bank_chip3_kernel<NM, NWV, NSVV>), cgrid, dim3(64 * NWV), c3Lds, stream, pb, inl, samples_dev,          \
+                       (long long)windowStrideSamples, S, nChan, nWindows, c3Lt, c3T, c3nBlk, c3nKG, sumBlocks, h->chan_d, h->sums_d, \
+                       h->chipBits_d, h->part_d, h->mom_d)
+#define DPE_LAUNCH_CHIP3_S(NWV, NSVV) \
+    do { if (c3NMom == 4) DPE_LAUNCH_CHIP3(4, NWV, NSVV); else DPE_LAUNCH_CHIP3(6, NWV, NSVV); } while (0)
+        if (getenv("DPE_BCS_CHIP3_VERBOSE")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bcs_bank_chip3_kernel<6, 6, 2>, 384, c3Lds);
+            fprintf(stderr, "[chip3] Lt %d T %d nBlk %d NW %d NSV %d nKG %d lds %zu NMom %d blocks %u occupancy<6,6,2> %d blocks/CU\n", c3Lt, c3T, c3nBlk, c3NW, c3NSV, c3nKG,
+                    c3Lds, c3NMom, cgrid.x, nb);
+        }
+        if (c3NW == 4 && c3NSV == 1) DPE_LAUNCH_CHIP3_S(4, 1);
+        else if (c3NW == 4) DPE_LAUNCH_CHIP3_S(4, 2);
+        else DPE_LAUNCH_CHIP3_S(6, 2);
+#undef DPE_LAUNCH_CHIP3_S
+#undef DPE_LAUNCH_CHIP3
+    } else if (c2) {
         const int c2Groups = (c2nBlk * nWindows + 7) / 8;
         const dim3 cgrid(ride ? rideF + ((c2Groups + rideGS - 1) / rideGS) * (rideSB + rideGS * 8 * nChan) : c2Groups * 8 * nChan);   // one block per (tile, SV), tiles dealt to the XCDs (see the kernel)
 #define DPE_LAUNCH_CHIP2(NM, LV, RD)                                                                                           \
@@ -1818,6 +1893,17 @@ int dpe_bcs_update_prepared(dpe_bcs *h, const int16_t *samples_dev, int32_t nCha
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrScores] Update: nChan %d out of range", nChan);
     return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
 }
+
+#ifdef DPE_C3_DEBUG
+int dpe_c3_debug_read(float *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dpe::c3dbg), sizeof(float) * 64 * 32) == hipSuccess ? 0 : -1;
+}
+int dpe_c3_debug_read2(float *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dpe::c3dbg2), sizeof(float) * 64 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int dpe_bcs_cotask_set(dpe_bcs *h, const void *args, size_t bytes)
 {

@@ -47,19 +47,24 @@ def _check(case, L, B, tol=TOL):
     code0, carr0, info0, _ = _banks(case, L, B, {"DPE_BCS_NO_CHIP": "1"})
     code1, carr1, info1, p1 = _banks(case, L, B, {"DPE_BCS_NO_CHIP2": "1"})     # the first form of the chip kernel
     assert p1["kernel"] != "bcs_bank_chip2_kernel"
+    # the third form (shared prefix arrays; by default only batches that fill the chip take it): forced for any batch size
+    code3, carr3, info3, p3 = _banks(case, L, B, {"DPE_BCS_CHIP3_MIN": "1"})
+    _check.last_kernels = (p1["kernel"], p3["kernel"])
     worst = 0.0
     for wi, w in enumerate(case["wins"]):
         s = w["start"]
         for k in range(case["K"]):
             c, f, inf = o.bcs_sv(w["iq"], case["fs"], int(s["prn"][k]), s["rc"][k], s["ri"][k], s["fc"][k], s["fi"][k],
                                  int(s["cp"][k]), int(s["cp_ref"][k]), -L, L, -B, B, case["C"])
-            for got, ref in ((code[wi][k], c), (carr[wi][k], f), (code0[wi][k], c), (carr0[wi][k], f), (code1[wi][k], c), (carr1[wi][k], f)):
+            for name, got, ref in (("code", code[wi][k], c), ("carr", carr[wi][k], f), ("code/per-sample", code0[wi][k], c), ("carr/per-sample", carr0[wi][k], f),
+                                   ("code/chip", code1[wi][k], c), ("carr/chip", carr1[wi][k], f), ("code/chip3", code3[wi][k], c), ("carr/chip3", carr3[wi][k], f)):
                 err = np.abs(got - ref).max() / np.abs(ref).max()
                 worst = max(worst, err)
-                assert err < tol, "window %d SV %d: rel err %.3g" % (wi, k, err)
+                assert err < tol, "%s window %d SV %d: rel err %.3g" % (name, wi, k, err)
             assert info[0][wi, k] == inf["idx_next"] and bool(info[1][wi, k]) == inf["no_flip_larger"]
             assert bool(info0[1][wi, k]) == inf["no_flip_larger"] and bool(info1[1][wi, k]) == inf["no_flip_larger"]
-        assert info[2][wi] == info0[2][wi] == info1[2][wi] == inf["mean"]          # DC mean: exact integer sums in both paths
+            assert bool(info3[1][wi, k]) == inf["no_flip_larger"]
+        assert info[2][wi] == info0[2][wi] == info1[2][wi] == info3[2][wi] == inf["mean"]          # DC mean: exact integer sums in every path
     return worst
 
 
