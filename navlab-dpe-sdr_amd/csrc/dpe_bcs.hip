@@ -1625,11 +1625,16 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     for (int i = 0; chip3 && i < nWindows * nChan; ++i)
         if (6.283185307179586 * std::fabs(h->chan_h[i].carrStep) * 0.5 * (c2L1 + 1) > (double)k3PhiMax) chip3 = false;
     if (chip3) {
-        if (nChan <= 4) { c3NW = 4; c3NSV = 1; }
-        else if (nChan <= 8) { c3NW = 4; c3NSV = 2; }
-        else { c3NW = 6; c3NSV = 2; }
+        // One SV per wave, four waves per block (one per SIMD), ceil(K / 4) blocks per group of tiles -- each forms the tile's prefix
+        // arrays again.  Measured at config H (128 windows, 12 SVs; profiles/r5_ab_H_chip3.txt): 6 waves x 2 SVs 0.99 ms (the waves of a
+        // block are dealt to the SIMDs in a fixed order: two 6-wave blocks ask one SIMD for four wave slots, so only one is ever
+        // resident at 168 registers), 4 waves x 2 SVs in two SV groups 0.88, 12 waves x 1 SV (one block per CU, every wave in step at the
+        // tile barriers) 0.78, 4 waves x 1 SV in three groups 0.69 -- a wave's tile is one long dependent chain, so the SVs of a tile want
+        // to run side by side in blocks that do not wait for each other.
+        c3NSV = 1;
+        c3NW = 4;
         c3nKG = (nChan + c3NW * c3NSV - 1) / (c3NW * c3NSV);
-        const int maxEnt = c3NW == 4 ? Chip3Shape<4>::kMaxEntries : Chip3Shape<6>::kMaxEntries;
+        const int maxEnt = Chip3Shape<4>::kMaxEntries;
         c3Lt = (int)std::floor(((double)k3MaxOwn - 1.01) / stepMax);   // <= 62 chip starts inside a tile, + the window's clipped first chip in tile 0
         if (c3Lt > maxEnt - (k3HL + k3HR + 1)) c3Lt = maxEnt - (k3HL + k3HR + 1);
         if (c3Lt > S) c3Lt = S;
@@ -1759,13 +1764,11 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     do { if (c3NMom == 4) DPE_LAUNCH_CHIP3(4, NWV, NSVV); else DPE_LAUNCH_CHIP3(6, NWV, NSVV); } while (0)
         if (getenv("DPE_BCS_CHIP3_VERBOSE")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bcs_bank_chip3_kernel<6, 6, 2>, 384, c3Lds);
-            fprintf(stderr, "[chip3] Lt %d T %d nBlk %d NW %d NSV %d nKG %d lds %zu NMom %d blocks %u occupancy<6,6,2> %d blocks/CU\n", c3Lt, c3T, c3nBlk, c3NW, c3NSV, c3nKG,
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)bcs_bank_chip3_kernel<6, 4, 1>, 256, c3Lds);
+            fprintf(stderr, "[chip3] Lt %d T %d nBlk %d NW %d NSV %d nKG %d lds %zu NMom %d blocks %u occupancy<6,4,1> %d blocks/CU\n", c3Lt, c3T, c3nBlk, c3NW, c3NSV, c3nKG,
                     c3Lds, c3NMom, cgrid.x, nb);
         }
-        if (c3NW == 4 && c3NSV == 1) DPE_LAUNCH_CHIP3_S(4, 1);
-        else if (c3NW == 4) DPE_LAUNCH_CHIP3_S(4, 2);
-        else DPE_LAUNCH_CHIP3_S(6, 2);
+        DPE_LAUNCH_CHIP3_S(4, 1);
 #undef DPE_LAUNCH_CHIP3_S
 #undef DPE_LAUNCH_CHIP3
     } else if (c2) {
@@ -1893,17 +1896,6 @@ int dpe_bcs_update_prepared(dpe_bcs *h, const int16_t *samples_dev, int32_t nCha
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrScores] Update: nChan %d out of range", nChan);
     return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
 }
-
-#ifdef DPE_C3_DEBUG
-int dpe_c3_debug_read(float *out)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dpe::c3dbg), sizeof(float) * 64 * 32) == hipSuccess ? 0 : -1;
-}
-int dpe_c3_debug_read2(float *out)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dpe::c3dbg2), sizeof(float) * 64 * 16) == hipSuccess ? 0 : -1;
-}
-#endif
 
 int dpe_bcs_cotask_set(dpe_bcs *h, const void *args, size_t bytes)
 {

@@ -31,6 +31,7 @@ namespace dpe {
 constexpr int k3HL = 32;       // samples in front of a tile that its flips' lag windows reach
 constexpr int k3HR = 34;       // ... and behind it (lags up to +31 and the chip that straddles the tile's end)
 constexpr int k3MaxOwn = 63;   // chips that start inside a tile (lane nOwn looks one chip ahead)
+constexpr int k3Mid = 800;     // origin of the W1 / W2 weights (tile-local sample index)
 constexpr int k3List = 64 + 4; // flip list of a wave, zero-padded to a multiple of four
 #ifndef DPE_C3_WAVES
 #define DPE_C3_WAVES 3
@@ -77,10 +78,6 @@ __device__ __forceinline__ void wave_scan_incl(float (&v)[N])
 #undef DPE_SCAN_STEP
 }
 
-#ifdef DPE_C3_DEBUG
-__device__ float c3dbg[64 * 32];
-__device__ float c3dbg2[64 * 16];
-#endif
 
 template <int kNMom, int NW, int NSV>
 __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(BcsParamBlock pb, int inl, const int16_t *__restrict__ iq, long long winStride,
@@ -137,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
     bool live[NSV];
     int c0[NSV], cEnd[NSV], cB[NSV], curSide[NSV], spilled[NSV], flushed[NSV], bitsV[NSV];
     float phi[NSV];
-    f2 thA[NSV], thB[NSV];          // exp(-j phi (len - 1) / 2) for chips of L1 / L1 + 1 samples: boundary -> centre
+    f2 thP[NSV];                    // exp(-j phi L1 / 2): chip boundary -> expansion point of the chip (its first sample + L1 / 2)
     int L1[NSV];
     f2 G[NSV], SC[NSV], ZG[NSV], DE[NSV], M[NSV][kNMom];
 #pragma unroll
@@ -154,12 +151,10 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
         phi[s] = (float)(6.283185307179586476925286766559 * ch[s].carrStep);
         L1[s] = (int)ch[s].invStep;
         {
-            const double a = lane == 0 ? 0.5 * (double)(L1[s] - 1) : 0.5 * (double)L1[s];
-            double ph = a * ch[s].carrStep;
+            double ph = 0.5 * (double)L1[s] * ch[s].carrStep;
             ph -= floor(ph);
             const f2 t = wipe_seed((float)ph);
-            thA[s] = f2{readlane_f(t.x, 0), readlane_f(t.y, 0)};
-            thB[s] = f2{readlane_f(t.x, 1), readlane_f(t.y, 1)};
+            thP[s] = f2{readlane_f(t.x, 0), readlane_f(t.y, 0)};
         }
         G[s] = SC[s] = ZG[s] = DE[s] = f2{0.f, 0.f};
 #pragma unroll
@@ -197,13 +192,6 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
         wave_scan_incl2(pr, pi);
         const float p31r = readlane_f(pr, 31), p31i = readlane_f(pi, 31);
         f2 v = f2{corr0.x + dpp_shr1_f(pr) - p31r, corr0.y + dpp_shr1_f(pi) - p31i};
-#ifdef DPE_C3_DEBUG
-        if (w == 0 && blk == DPE_C3_DBG_BLK && kg == 0 && s == 0 && wave == 0) {
-            float *o = c3dbg2 + lane * 16;
-            o[0] = tot[0]; o[1] = tot[1]; o[2] = zg.x; o[3] = zg.y; o[4] = sc.x; o[5] = sc.y; o[6] = corr0.x; o[7] = corr0.y;
-            o[8] = G[s].x; o[9] = G[s].y; o[10] = dp.x; o[11] = dp.y; o[12] = v.x; o[13] = v.y; o[14] = (float)side; o[15] = M[s][0].x;
-        }
-#endif
         const bool again = (spilled[s] >> side) & 1;
         if (again) { const float2 old = partOut[lane]; v += f2{old.x, old.y}; }   // (the same lane wrote it: program order)
         partOut[lane] = make_float2(v.x, v.y);
@@ -250,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
             const int rv = rawN[i];
             const bool ok = n0 + i < NTs;
             z[i] = ok ? f2{(float)((int)(short)(rv & 0xFFFF) - mIntRe), (float)((rv >> 16) - mIntIm)} : f2{0.f, 0.f};
-            const float wt = (float)(((n0 + i) & 63) - 32);
+            const float wt = (float)(n0 + i - k3Mid);
             tot[0] += z[i].x; tot[1] += z[i].y;
             tot[2] = fmaf(wt, z[i].x, tot[2]); tot[3] = fmaf(wt, z[i].y, tot[3]);
             tot[4] = fmaf(wt * wt, z[i].x, tot[4]); tot[5] = fmaf(wt * wt, z[i].y, tot[5]);
@@ -278,7 +266,7 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
                 sC0[n] = make_float2(run[0], run[1]);
                 sW[n] = make_float4(run[2], run[3], run[4], run[5]);
             }
-            const float wt = (float)((n & 63) - 32);
+            const float wt = (float)(n - k3Mid);
             run[0] += z[i].x; run[1] += z[i].y;
             run[2] = fmaf(wt, z[i].x, run[2]); run[3] = fmaf(wt, z[i].y, run[3]);
             run[4] = fmaf(wt * wt, z[i].x, run[4]); run[5] = fmaf(wt * wt, z[i].y, run[5]);
@@ -327,15 +315,11 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
         const bool own = lane < nOwn;
         const int eNext = __builtin_amdgcn_update_dpp(0, e, 0x130, 0xf, 0xf, true);
         const int len = own ? eNext - e : 0;
-        const int la = e - tb, lb = la + len;
-        int ls = (la | 63) + 1;
-        ls = ls < lb ? ls : lb;
-        // prefix values at the chip's start, at the segment boundary inside it (or its end), and -- from the next lane -- at its end
+        const int la = e - tb;
+        // prefix values at the chip's start and -- from the next lane -- at its end
         const float2 c0a_ = sC0[la];
         const float4 wa_ = sW[la];
-        const float2 c0s_ = sC0[ls];
-        const float2 w1s_ = *reinterpret_cast<const float2 *>(&sW[ls]);
-        const f2 c0a = f2{c0a_.x, c0a_.y}, w1a = f2{wa_.x, wa_.y}, w2a = f2{wa_.z, wa_.w}, c0s = f2{c0s_.x, c0s_.y}, w1s = f2{w1s_.x, w1s_.y};
+        const f2 c0a = f2{c0a_.x, c0a_.y}, w1a = f2{wa_.x, wa_.y}, w2a = f2{wa_.z, wa_.w};
         const f2 c0b = dpp_shl1(c0a), w1b = dpp_shl1(w1a), w2b = dpp_shl1(w2a);
         // chip signs: bit i of rMask <-> chip cLo - 1 + i, from the PRN's periodically extended sign-bit table (lane l keeps word l)
         unsigned long long rMask;
@@ -348,42 +332,29 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
         }
         const unsigned long long ownMask = nOwn >= 64 ? ~0ull : ((1ull << nOwn) - 1ull);
         const float r = mask_pm1(rMask >> 1);   // lane l: sign of chip cLo + l
-        // raw moments of the chip about its centre, from the prefix differences (segment-centred weights: part A up to ls, part B behind)
-        const float lenf = (float)len;
-        const float ccl = 0.5f * (float)(2 * la + len - 1);          // chip centre, tile-local
-        const float dA = (float)((la & ~63) + 32) - ccl, dB = dA + 64.f;
-        const f2 dC1 = c0s - c0a, dC2 = c0b - c0s, dW1a = w1s - w1a, dW1b = w1b - w1s, dW2 = w2b - w2a;
-        const float g2 = lenf * (lenf * lenf - 1.f) * (1.f / 12.f);
-        const f2 R0 = dC1 + dC2 - mu * lenf;
-        const f2 R1 = (dW1a + dW1b) + dC1 * dA + dC2 * dB;
-        const f2 R2 = dW2 + (dW1a * dA + dW1b * dB) * 2.f + dC1 * (dA * dA) + dC2 * (dB * dB) - mu * g2;
+        // raw moments of the chip about its EXPANSION POINT p = first sample + L1 / 2 (the centre of a chip of L1 + 1 samples, half a
+        // sample behind the centre of one of L1: a fixed offset from the boundary, so that one block constant turns the boundary's
+        // wipe-off into the point's), from the prefix differences; W1 / W2 carry the weights (n - k3Mid), (n - k3Mid)^2
+        const float lenf = (float)len, hL = 0.5f * (float)L1[s];
+        const float pc = (float)(la - k3Mid) + hL;                  // p in the weights' coordinate
+        const f2 dC = c0b - c0a, dW1 = w1b - w1a, dW2 = w2b - w2a;
+        const float dm = 0.5f * (lenf - 1.f) - hL;                   // chip centre - p (0 or -1/2 for the regular lengths)
+        const float g2 = lenf * (lenf * lenf - 1.f) * (1.f / 12.f);  // sum over the chip of (n - centre)^2
+        const float s1 = lenf * dm, s2 = g2 + s1 * dm;               // sums of (n - p), (n - p)^2 over the chip
+        const f2 R0 = dC - mu * lenf;
+        const f2 R1 = dW1 - dC * pc - mu * s1;
+        const f2 R2 = dW2 - dW1 * (2.f * pc) + dC * (pc * pc) - mu * s2;
         const float ph1 = phi[s], hph2 = 0.5f * ph1 * ph1;
         const f2 E0 = add_mjs(R0 - R2 * hph2, ph1, R1);
         const f2 E1 = add_mjs(R1, ph1, R2);
-        const float Gj = lenf - hph2 * g2;   // sum over the chip of exp(-j phi d), to the same order
-        // wipe-off at the chip's first sample (the flip coefficient) and at its centre
+        const f2 Gj = f2{lenf - hph2 * s2, -ph1 * s1};   // sum over the chip of exp(-j phi (n - p)), to the same order
+        // wipe-off at the chip's first sample (the flip coefficient) and at p
         double phe = fma((double)e, c.carrStep, c.ri);
         phe -= floor(phe);
         const f2 we = wipe_seed((float)phe);
-        f2 wc;
-        const bool irregular = __ballot(own && len != L1[s] && len != L1[s] + 1) != 0ull;   // (the window's clipped first / last chip)
-        if (!irregular) wc = cmul(we, len == L1[s] ? thA[s] : thB[s]);
-        else {
-            double pc = fma((double)e + 0.5 * (double)(len - 1), c.carrStep, c.ri);
-            pc -= floor(pc);
-            wc = wipe_seed((float)pc);
-        }
+        const f2 wc = cmul(we, thP[s]);
         const f2 P0 = cmul(wc, E0), P1 = cmul(wc, E1);
-#ifdef DPE_C3_DEBUG
-        if (w == 0 && blk == DPE_C3_DBG_BLK && kg == 0 && s == 0 && wave == 0 && t0 == blk * T * Lt) {
-            float *o = c3dbg + lane * 32;
-            o[0] = (float)e; o[1] = (float)len; o[2] = R0.x; o[3] = R0.y; o[4] = R1.x; o[5] = R1.y; o[6] = R2.x; o[7] = R2.y;
-            o[8] = E0.x; o[9] = E0.y; o[10] = wc.x; o[11] = wc.y; o[12] = r; o[13] = (float)la; o[14] = (float)ls; o[15] = c0a.x; o[16] = c0a.y;
-            o[17] = c0b.x; o[18] = c0b.y; o[19] = we.x; o[20] = we.y; o[21] = (float)nOwn; o[22] = (float)cLo; o[23] = P0.x; o[24] = P0.y;
-            o[25] = w1a.x; o[26] = w2a.x; o[27] = c0s.x; o[28] = w1s.x; o[29] = mu.x; o[30] = mInt.x; o[31] = (float)kPure;
-        }
-#endif
-        const float xb = (float)(e - stBase) + 0.5f * (lenf - 1.f) - xOrigin;
+        const float xb = (float)(e - stBase) + hL - xOrigin;
         // the lag sums of a list of flips: G[l] += c C0[e + l] for the 64 lags of the wave (lane <-> l + 32)
         // (list entry = {c.re, c.im, byte offset of C0[e - 32], -}: the coefficient is the entry's first, 64-bit aligned register pair.
         //  All reads of a round of four flips are issued before any is consumed, and two running sums halve the dependent chain.)
@@ -410,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
         if constexpr (kPure) {
             const float rOwn = own ? r : 0.f;
             add_moments(M[s], P0 * rOwn, P1 * rOwn, xb);
-            ZG[s] += wc * (rOwn * Gj);
+            ZG[s] += cmul(wc, Gj) * rOwn;
             // flips: owned chips whose sign differs from the chip before; J = r_prev - r = -2 r
             const unsigned long long bm = (rMask ^ (rMask >> 1)) & ownMask;
             const int nb = __builtin_popcountll(bm);
@@ -455,7 +426,7 @@ __global__ __launch_bounds__(64 * NW, DPE_C3_WAVES) void bcs_bank_chip3_kernel(B
                     curSide[s] = side;
                 }
                 add_moments(M[s], P0 * rs, P1 * rs, xb);
-                ZG[s] += wc * (rs * Gj);
+                ZG[s] += cmul(wc, Gj) * rs;
                 const f2 cj = we * J;
                 // flips whose lag window stays inside the window: list + G form
                 const bool inside = e >= 32 && e + 31 <= S;
