@@ -132,10 +132,11 @@ int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, co
 /* (The device-parameter forms -- *_update_dev, *_update_prepared -- always launch eagerly: dpe_bcs_set_graph / dpe_bcm_set_graph
  * apply to the host-parameter Updates only.) */
 /* Input check of the last dpe_bcs_update_dev (synchronises): bit 0 = a PRN outside 1..37 (clamped), bit 1 = a non-positive
- * code frequency or negative code phase.  0 = clean.  Bit 2 belongs to the host-parameter batches of the high-rate chip kernel
- * (>= 48 windows at >= 16 samples per chip), whose DC sums are computed by blocks of the stage-1 launch itself: set when a
- * correlator block gave up waiting for them (never observed; the banks of that Update are then wrong).  DPE_BCS_NO_SUMRIDE=1 at
- * create keeps the separate DC-sum kernel. */
+ * code frequency or negative code phase.  0 = clean.  Bits 2 and 4 belong to the host-parameter batches of the high-rate chip kernel
+ * (>= 48 windows at >= 16 samples per chip), whose DC sums are computed by blocks of the stage-1 launch itself: a correlator block
+ * that waited too long for them added up its window's samples itself -- slower, the same exact sums, the banks are right either way.
+ * Bit 2 = happened in the last such launch, bit 4 = happened at least once since create (a diagnostic: never observed outside the
+ * test that forces it).  DPE_BCS_NO_SUMRIDE=1 at create keeps the separate DC-sum kernel. */
 int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream);
 /* A promise about the values behind the device ports, for sampling rates of >= 16 samples per chip: which stage-1 kernel runs is
  * a property of the channel values there, and without a promise dpe_bcs_update_dev reads back the <= 3 KB block its prep kernel

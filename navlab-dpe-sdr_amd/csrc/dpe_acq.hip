@@ -206,8 +206,11 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     const int tt = act ? t : 0;
     if constexpr (R10) {
         if (t == 0) {   // a free scratch slot: there are more slots than blocks resident at once, so the search ends
+            // A slot stays with ONE XCD: the block's linear id mod 8 is its XCD, the slot count is a multiple of 8 and the probe steps
+            // by 8.  The per-XCD L2s are write-back and not coherent with each other inside a kernel -- a slot handed from one XCD to
+            // another could be hit by a late write-back of its previous owner's lines after the new owner's were evicted.
             int sl = (int)((blockIdx.y * gridDim.x + blockIdx.x) % (unsigned)r10Slots);
-            while (atomicCAS(&r10Busy[sl], 0u, 1u) != 0u) sl = sl + 1 == r10Slots ? 0 : sl + 1;
+            while (atomicCAS(&r10Busy[sl], 0u, 1u) != 0u) sl = sl + 8 >= r10Slots ? (sl & 7) : sl + 8;
             sSlot = sl;
         }
     }
@@ -1020,7 +1023,10 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         if (h->fusedAlias) {
             h->r10InBlock = !(getenv("DPE_ACQ_NO_R10_INBLOCK") && atoi(getenv("DPE_ACQ_NO_R10_INBLOCK")) != 0);
             const long long pairs = (long long)h->chunk * B;        // Y_d holds chunk x B rows of S: the pool is a part of it
-            h->r10Slots = (int)(pairs < 1024 ? pairs : 1024);       // > the 768 blocks resident at once (3 per CU)
+            // a multiple of 8 (one class of slots per XCD): 128 per XCD > the 96 blocks an XCD holds at once (3 per CU); a small search
+            // gets fewer slots than blocks (a block then waits for one of its XCD's to come free), fewer than 8 pairs keep the separate stage
+            h->r10Slots = (int)(pairs < 1024 ? pairs / 8 * 8 : 1024);
+            if (h->r10Slots < 8) { h->r10Slots = 8; h->r10InBlock = false; }
             h->r10Busy_d = dev_alloc<unsigned int>((size_t)h->r10Slots);
             if (!h->r10Busy_d || hipMemset(h->r10Busy_d, 0, sizeof(unsigned int) * h->r10Slots) != hipSuccess) {
                 set_error("[Acquisition] create: scratch claim words");

@@ -1082,7 +1082,7 @@ __global__ void bcs_prep_kernel(BcsPortsDev p, int K, double fs, int S, BcsChanD
                                 double hintStepMax)
 {
     const int k = threadIdx.x;
-    if (k == 0) *status = 0;
+    if (k == 0) atomicAnd(status, ~15);   // (bits 0 .. 3 are this kernel's; bits 2 and 4 belong to the batches whose DC sums ride in the stage-1 launch)
     __syncthreads();
     if (k >= K) return;
     int bad;
@@ -1152,6 +1152,7 @@ struct dpe_bcs {
     int rideW = 0, rideSlots = 0;               // the slot set the last such launch wrote
     bool rideAllowed = true;                    // DPE_BCS_NO_SUMRIDE=1: DC-sum kernel in front of the chip2 kernel, as before (A/B runs)
     int rideLA = 4;                             // look-ahead of the sum blocks in windows (DPE_BCS_RIDE_LA)
+    int rideSpin = dpe::kRideSpinDefault;       // polls after which a correlator block sums its window itself (DPE_BCS_RIDE_SPIN; tests force 1)
     int rideMinW = 48;                          // smallest batch that takes the riding form (measured at H: 8 / 16 windows slower, 32 equal, 64 -1.2 %, 128 -2.6 %); DPE_BCS_SUMRIDE_MIN
     dpe::BcsChanDev *chan_d = nullptr;
     // pinned parameter staging: a ring of kStaging blocks, each guarded by an event recorded once its H2D copy (or the
@@ -1260,6 +1261,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->rideAllowed = !(getenv("DPE_BCS_NO_SUMRIDE") && atoi(getenv("DPE_BCS_NO_SUMRIDE")) != 0);
     if (getenv("DPE_BCS_SUMRIDE_MIN") && atoi(getenv("DPE_BCS_SUMRIDE_MIN")) >= 1) h->rideMinW = atoi(getenv("DPE_BCS_SUMRIDE_MIN"));
     if (getenv("DPE_BCS_RIDE_LA") && atoi(getenv("DPE_BCS_RIDE_LA")) >= 1) h->rideLA = atoi(getenv("DPE_BCS_RIDE_LA"));
+    if (getenv("DPE_BCS_RIDE_SPIN") && atoi(getenv("DPE_BCS_RIDE_SPIN")) >= -1) h->rideSpin = atoi(getenv("DPE_BCS_RIDE_SPIN"));
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     // chip-boundary kernel (dpe_bcs_chip.h): lag windows of 17..31 samples (wider: chunks of 64 lags) at sampling rates where a
     // sub-tile holds few chips, plain n/fs sample times; its moment block is one pass of kPass samples, and a chip's
@@ -1697,7 +1699,8 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
         h->rideEpoch = h->rideEpoch % 3 + 1;
         if (upInSum) {
             h->prof.begin(0, stream);
-            upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream);
+            // (the same kernel clears the status word's "a block of this launch gave up waiting" bit: a block behind such a block skips its own wait)
+            upload_params(h->chan_d, h->chanBase_hd + (h->chan_h - h->chanBase_h), sizeof(BcsChanDev) * nWindows * nChan, stream, h->status_d, 4);
             h->prof.end(0, stream);
             DPE_CHECK_HIP(hipEventRecord(h->stagingFree[h->slot], stream));
         }
@@ -1777,7 +1780,7 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
 #define DPE_LAUNCH_CHIP2(NM, LV, RD)                                                                                           \
     hipLaunchKernelGGL((bcs_bank_chip2_kernel<NM, LV, RD>), cgrid, dim3(64), 0, stream, pb, inl, samples_dev, (long long)windowStrideSamples, S, \
                        nChan, nWindows, c2Lt, c2nBlk, sumBlocks, h->chan_d, h->sums_d, h->chipTable_d, h->chipBits_d, h->part_d, h->mom_d,      \
-                       h->rideWord_d, h->rideEpoch, rideF, rideSB, rideGS, h->status_d)
+                       h->rideWord_d, h->rideEpoch, rideF, rideSB, rideGS, h->rideSpin, h->status_d)
 #define DPE_LAUNCH_CHIP2_L(LV)                                                                        \
     case LV:                                                                                          \
         if (ride) { if (c2NMom == 4) DPE_LAUNCH_CHIP2(4, LV, true); else DPE_LAUNCH_CHIP2(6, LV, true); }   \

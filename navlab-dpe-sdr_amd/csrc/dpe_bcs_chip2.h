@@ -82,9 +82,13 @@ __device__ __forceinline__ float mask_pm1(unsigned long long m)
 // sum block also leaves the int64 sums in the ordinary slots for the kernels behind this launch.  Epochs cycle 1 .. 3 and every
 // launch rewrites every word it will read; the host clears the words when the set of slots grows, so no older word can carry
 // the current epoch.  Forward progress: work groups are dispatched in index order per XCD and a sum block waits for nothing, so the
-// lowest-index undispatched sum block is never behind a full house of waiting blocks.  A wait that exceeds kRideSpinMax polls sets
-// bit 2 of *status and gives up (every later block then skips its wait): wrong means, no hang.
-constexpr int kRideSpinMax = 200000;
+// lowest-index undispatched sum block is never behind a full house of waiting blocks -- a property of the dispatcher that HIP does
+// not promise, so nothing depends on it for correctness: a correlator block whose wait exceeds `rideSpin` polls (200 000 by default;
+// DPE_BCS_RIDE_SPIN at create, the tests force 1) adds up its window's samples ITSELF -- slow (one wave reads the whole window) and
+// right: the same exact integer sums.  It also sets bit 2 of *status (this launch: cleared by the parameter-upload kernel in front of
+// every such launch; the blocks behind it then skip their own wait when their word is not there yet) and bit 4 (sticky since create:
+// the diagnostic dpe_bcs_dev_status reports).
+constexpr int kRideSpinDefault = 200000;
 #ifndef DPE_RIDE_LOADS
 #define DPE_RIDE_LOADS 16
 #endif
@@ -163,26 +167,45 @@ __device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, l
     }
 }
 // the consumer's side: window_mean (dpe_bcs.hip) from the words that blocks of the same launch publish; `first` = the word this
-// lane fetched when the block started
+// lane fetched when the block started.  Gives up after rideSpin polls and then sums the window's samples itself (see above).
 __device__ __forceinline__ void ride_window_mean(const unsigned long long *__restrict__ rideWord, unsigned long long first, unsigned epoch, int *__restrict__ status,
-                                                 int w, int nSumBlk, int S, float &mRe, float &mIm)
+                                                 int rideSpin, const int *__restrict__ x, int w, int nSumBlk, int S, float &mRe, float &mIm)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long *wd = rideWord + (size_t)w * kSumSlots + lane;
     unsigned long long v = first;
+    bool gaveUp = false;
     for (int it = 0;; ++it) {
-        if (__ballot(lane < nSumBlk && (unsigned)(v >> 62) != epoch) == 0ull) break;
-        if (it >= kRideSpinMax || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) {
-            if (lane == 0) atomicOr(status, 4);
+        if (rideSpin >= 0 && __ballot(lane < nSumBlk && (unsigned)(v >> 62) != epoch) == 0ull) break;   // (rideSpin < 0, tests: every block takes the fallback)
+        if (it >= rideSpin || (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) {
+            if (lane == 0) atomicOr(status, 4 | 16);
+            gaveUp = true;
             break;
         }
         __builtin_amdgcn_s_sleep(32);
         if (lane < nSumBlk) v = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     long long tI = 0, tQ = 0;
-    if (lane < nSumBlk) {   // 31-bit two's-complement fields
-        tI = (long long)((int)((unsigned)(v >> 31) << 1) >> 1);
-        tQ = (long long)((int)((unsigned)v << 1) >> 1);
+    if (!gaveUp) {
+        if (lane < nSumBlk) {   // 31-bit two's-complement fields
+            tI = (long long)((int)((unsigned)(v >> 31) << 1) >> 1);
+            tQ = (long long)((int)((unsigned)v << 1) >> 1);
+        }
+    } else {
+        // the window's sums by this wave alone (the riding form is only taken for 16-byte aligned windows)
+        const int4 *x4 = reinterpret_cast<const int4 *>(x);
+        const int n4 = S >> 2;
+        for (int n0 = 0; n0 < n4; n0 += 64 * 256) {   // partial sums of < 64 k samples per lane stay inside 32 bits
+            int sI = 0, sQ = 0;
+            const int hi = n0 + 64 * 256 < n4 ? n0 + 64 * 256 : n4;
+            for (int n = n0 + lane; n < hi; n += 64) {
+                const int4 q = x4[n];
+                sI += (short)(q.x & 0xFFFF) + (short)(q.y & 0xFFFF) + (short)(q.z & 0xFFFF) + (short)(q.w & 0xFFFF);
+                sQ += (q.x >> 16) + (q.y >> 16) + (q.z >> 16) + (q.w >> 16);
+            }
+            tI += sI; tQ += sQ;
+        }
+        for (int m = (n4 << 2) + lane; m < S; m += 64) { const int q = x[m]; tI += (short)(q & 0xFFFF); tQ += q >> 16; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
                                                                const uint32_t *__restrict__ chipBits,
                                                                float2 *__restrict__ part, float2 *__restrict__ mom,
                                                                unsigned long long *__restrict__ rideWord, unsigned epoch, int rideF, int rideSB, int rideGS,
-                                                               int *__restrict__ status)
+                                                               int rideSpin, int *__restrict__ status)
 {
     constexpr int NL = 65;   // partial layout shared with the other stage-1 kernels: entry j <-> lag j - 32 (j = 64 unused)
     __shared__ float2 sQ[k2QLen];
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
         thB = f2{readlane_f(t.x, 27), readlane_f(t.y, 27)};
     }
     float mRe, mIm;   // (behind the block's set-up: with RIDE the word fetched first thing has arrived by now)
-    if constexpr (RIDE) ride_window_mean(rideWord, rideFirst, epoch, status, w, nSumBlk, S, mRe, mIm);
+    if constexpr (RIDE) ride_window_mean(rideWord, rideFirst, epoch, status, rideSpin, x, w, nSumBlk, S, mRe, mIm);
     else window_mean(sums, w, nSumBlk, S, mRe, mIm);
     const f2 meanv = f2{mRe, mIm};
     float2 *momOut = mom + ((((size_t)w * K + k) * 2) * nBlk + blk) * kNMom;   // [side][nBlk][kNMom]

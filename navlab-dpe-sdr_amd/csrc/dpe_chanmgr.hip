@@ -259,9 +259,17 @@ int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans
     return 0;
 }
 
+// (the manager must be destroyed BEFORE the handles it is attached to: it detaches from them here)
 int dpe_chm_dev_destroy(dpe_chm_dev *h)
 {
     if (!h) return 0;
+    // a time update may still be parked in the BatchCorrScores handle (dpe_chm_dev_step hands it to the next stage-1 launch): it
+    // points into the buffers freed below -- run it now and let the stream drain; give the manifold handle its published results back
+    if (h->bcs) {
+        (void)dpe_bcs_cotask_flush(h->bcs, h->lastStream);
+        (void)hipStreamSynchronize(h->lastStream);
+    }
+    if (h->bcm) (void)dpe_bcm_hook_set_publish(h->bcm, 1);
     (void)hipFree(h->st_d);
     (void)hipFree(h->portBuf_d);
     if (h->ring_h) (void)hipHostFree(h->ring_h);
@@ -356,7 +364,7 @@ int dpe_chm_dev_fix(dpe_chm_dev *h, int64_t window, dpe_fix_record *out, int32_t
     const unsigned long long want = (unsigned long long)window + 1ull;
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (;;) {
+    for (unsigned spins = 0;; ++spins) {
         const unsigned long long seq = __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE);
         if (seq == want) break;
         DPE_REQUIRE(seq < want, "[cuChanMgr] fix: window %lld was overwritten (the ring holds %d fixes)", (long long)window, h->ringDepth);
@@ -366,6 +374,22 @@ int dpe_chm_dev_fix(dpe_chm_dev *h, int64_t window, dpe_fix_record *out, int32_t
             const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
             if (us > (double)timeoutMicros) return 1;   // not there yet
         }
+        // liveness: a kernel of the loop that faulted never sends the record -- report the stream's error instead of spinning for ever;
+        // a stream that has drained without the record having arrived (one more look: the write may just have landed) is an error too
+        if ((spins & 0x3ff) == 0x3ff) {
+            const hipError_t q = hipStreamQuery(h->lastStream);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                dpe::set_error("[cuChanMgr] fix: the loop's stream reports %s while window %lld is awaited", hipGetErrorString(q), (long long)window);
+                return -1;
+            }
+            if (q == hipSuccess && __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != want) {
+                dpe::set_error("[cuChanMgr] fix: the stream is idle and window %lld's record never arrived", (long long)window);
+                return -1;
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
     }
     memcpy(out, r, sizeof(dpe_fix_record));
     DPE_REQUIRE(__atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) == want, "[cuChanMgr] fix: window %lld was overwritten while it was read", (long long)window);

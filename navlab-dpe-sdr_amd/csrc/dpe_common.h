@@ -223,15 +223,17 @@ __device__ __forceinline__ const T *params_ptr(const T *global_ptr, int useKerna
 // Batch parameter blocks (a few KB to a few hundred KB per Update) go to the device with a small KERNEL that reads the pinned
 // staging block directly instead of a hipMemcpyAsync: an in-stream copy command costs ~5-8 us of stream time on this stack,
 // a kernel boundary 1.5-2 us (measured: config H step 0.320 -> 0.31x ms, two such copies per step).
-__global__ static void upload_params_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int n16)
+// (clearWord / clearMask: a status word whose per-launch bits the same kernel clears -- no memset command in the stream)
+__global__ static void upload_params_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int n16, int *__restrict__ clearWord, int clearMask)
 {
+    if (clearWord && blockIdx.x == 0 && threadIdx.x == 0) atomicAnd(clearWord, ~clearMask);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
-static inline void upload_params(void *dst_dev, const void *src_pinned_devptr, size_t bytes, hipStream_t st)
+static inline void upload_params(void *dst_dev, const void *src_pinned_devptr, size_t bytes, hipStream_t st, int *clearWord = nullptr, int clearMask = 0)
 {
     const int n16 = (int)((bytes + 15) / 16);
     const int blocks = n16 / 256 + 1 > 64 ? 64 : n16 / 256 + 1;
-    hipLaunchKernelGGL(upload_params_kernel, dim3(blocks), dim3(256), 0, st, (uint4 *)dst_dev, (const uint4 *)src_pinned_devptr, n16);
+    hipLaunchKernelGGL(upload_params_kernel, dim3(blocks), dim3(256), 0, st, (uint4 *)dst_dev, (const uint4 *)src_pinned_devptr, n16, clearWord, clearMask);
 }
 #endif
 

@@ -59,25 +59,44 @@ def test_acq_textbook_mode_vs_oracle(golden, oracle):
     acq.close()
 
 
-def test_acq_32_prns_full_search():
-    """BASELINE.json configs[4] shape: 32 PRNs x 125 bins x 2500 delays, 10 ms window."""
+@pytest.mark.parametrize("mode,nbins,step", [("coherent", 125, 100.0), ("noncoherent", 125, 100.0), ("textbook", 125, 100.0),
+                                             ("noncoherent", 25, 500.0)])
+def test_acq_32_prns_full_search(oracle, mode, nbins, step):
+    """BASELINE.json configs[4] shape, exactly as bench.py's acquisition line runs it: 32 PRNs x 125 bins (100 Hz) x 2500 delays, a
+    10 ms window, all PRNs in one chunk -- in the three modes -- and the reference's non-coherent mode on the raster the reference
+    pairs with it (25 x 500 Hz, correlator.py:13).  The |.| surface of the six simulated PRNs and of two absent ones against the
+    oracle's restatement of coarse_acquisition (correlator.py:53-103; the textbook form is the oracle's own, parity unpinned by the
+    reference), peak cell and decision for every one of the 32; the simulated PRNs found within one bin / half a chip."""
     import torch
     fs, S = 2.5e6, 25000
     ch = dpe.synth.random_channels(77, 6, prns=[3, 7, 11, 18, 22, 31])
     ch["cp_ref"] = ch["cp"].copy()
     iq = dpe.synth.gen_iq(78, fs, S, ch, amp=150.0, flip=np.zeros(6, dtype=bool))
-    bins = np.arange(-62, 63) * 100.0
-    acq = dpe.Acquisition(fs, S, list(range(1, 33)), bins, mode="coherent")
+    bins = (np.arange(nbins) - nbins // 2) * step
+    acq = dpe.Acquisition(fs, S, list(range(1, 33)), bins, mode=mode, prn_chunk=32)
     acq.search(torch.from_numpy(iq).to("cuda:0"))
     res = acq.results()
-    found = sorted(r["prn"] for r in res if r["found"])
-    assert found == [3, 7, 11, 18, 22, 31]
-    for r in res:
-        if r["found"]:
-            k = list(ch["prn"]).index(r["prn"])
-            d = (r["rc"] - ch["rc"][k] + 511.5) % 1023 - 511.5
-            assert abs(d) < 0.5 and abs(r["fi"] - ch["fi"][k]) < 100.0   # within one 100 Hz bin
+    surf = acq.read_surface()
     acq.close()
+    assert surf.shape == (32, nbins, 2500)
+    for prn in (3, 7, 11, 18, 22, 31, 1, 32):
+        kw = dict(mode="textbook") if mode == "textbook" else dict(coherent=(mode == "coherent"))
+        ref = oracle.coarse_acquisition(iq, fs, prn, bins, wrap_mask=True, **kw)
+        r = res[prn - 1]
+        assert r["prn"] == prn
+        assert np.abs(surf[prn - 1] - ref["surface"]).max() < 2e-5 * ref["surface"].max(), prn
+        assert r["max_code_idx"] == ref["max_code_idx"] and r["max_dopp_idx"] == ref["max_dopp_idx"] and r["found"] == ref["found"]
+        assert abs(r["cppm"] / ref["cppm"] - 1) < 1e-4 and abs(r["cppr"] / ref["cppr"] - 1) < 1e-4
+    if step == 100.0:
+        found = sorted(r["prn"] for r in res if r["found"])
+        assert set([3, 7, 11, 18, 22, 31]) <= set(found)
+        if mode == "coherent":
+            assert found == [3, 7, 11, 18, 22, 31]
+        for r in res:
+            if r["found"] and r["prn"] in (3, 7, 11, 18, 22, 31):
+                k = list(ch["prn"]).index(r["prn"])
+                d = (r["rc"] - ch["rc"][k] + 511.5) % 1023 - 511.5
+                assert abs(d) < 0.5 and abs(r["fi"] - ch["fi"][k]) < 100.0   # within one 100 Hz bin
 
 
 def test_fused_coherent_search_equals_the_rocfft_chain():

@@ -246,7 +246,11 @@ def test_sums_riding_in_the_chip2_launch_equal_the_sum_kernel():
     pad[:, :2 * case["S"]] = iq
     d = torch.from_numpy(pad).to("cuda:0")
     out = {}
-    for name, env in (("ride", {"DPE_BCS_SUMRIDE_MIN": "8"}), ("kernel", {"DPE_BCS_NO_SUMRIDE": "1"})):   # (default: batches of >= 48 windows ride)
+    # "forced": every correlator block behaves as if its wait had timed out and adds up its window's samples itself (DPE_BCS_RIDE_SPIN=-1;
+    # "impatient": it gives up after the first poll) -- the fallback that keeps a broken dispatch-order assumption from ever producing
+    # wrong means (batchcorrscores.cu:1065-1066: the mean is the exact sum over (float) S)
+    for name, env in (("ride", {"DPE_BCS_SUMRIDE_MIN": "8"}), ("kernel", {"DPE_BCS_NO_SUMRIDE": "1"}),
+                      ("forced", {"DPE_BCS_SUMRIDE_MIN": "8", "DPE_BCS_RIDE_SPIN": "-1"}), ("impatient", {"DPE_BCS_SUMRIDE_MIN": "8", "DPE_BCS_RIDE_SPIN": "0"})):   # (default: batches of >= 48 windows ride)
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -267,10 +271,13 @@ def test_sums_riding_in_the_chip2_launch_equal_the_sum_kernel():
         res.append((code.copy(), carr.copy(), bcs.read_info()[2].copy()))
         if name == "ride":
             assert bcs.dev_status() == 0          # no correlator block gave up waiting for its window's sums
+        if name == "forced":
+            assert bcs.dev_status() == 4 + 16     # this launch + sticky: the blocks summed their windows themselves
         bcs.Stop()
         out[name] = res
-    for a, b in zip(out["ride"], out["kernel"]):
-        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for form in ("ride", "forced", "impatient"):
+        for a, b in zip(out[form], out["kernel"]):
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), form
     for wi, w in enumerate(case["wins"]):
         s = w["start"]
         _, _, inf = o.bcs_sv(w["iq"], case["fs"], int(s["prn"][0]), s["rc"][0], s["ri"][0], s["fc"][0], s["fi"][0], int(s["cp"][0]),

@@ -959,23 +959,27 @@ def test_reference_maximum_grid_size():
         assert sc[best] >= want.max() * (1 - TOL)
 
 
-@pytest.mark.parametrize("name,W,probe", [("R", 256, (0, 100, 255)), ("H", 128, (0, 5, 127))])
+@pytest.mark.parametrize("name,W,probe", [("R", 256, (0, 100, 255)), ("H", 128, (0, 5, 127)), ("M", 256, (0, 100, 255))])
 def test_bench_configurations_against_the_oracle(oracle, name, W, probe):
     """The exact configurations bench.py times.  R: S = 50000, 8 SVs, two 390625-point rngrid3-format grids, 256 windows per
     call, banks L = 4 / B = 20 (the 16-samples-per-lane bank kernel, the fat finalize shape, the batch scan).  H (--config H):
     25 Msps, S = 500000, 12 SVs, 1e5-point grids, 128 windows per call -- 8 distinct ones repeated with their channel state, as
     bench.py builds them -- L = 31 (bcs_bank_chip2_kernel: its tile length follows from the batch size).  Banks and every 97th
     score of a few windows against the oracle, and for ALL windows the reported arg-max against the first maximum of the
-    scores the scan wrote."""
+    scores the scan wrote.  M (the extra line of the default bench): config R's windows against the 1e6-point global grids, 256
+    windows per call -- the scan's block split and the 2 GB of scores of the benched shape; every 997th score of the probe windows."""
     import torch
     o = oracle
-    cfg = dpe.workload.CONFIG_R if name == "R" else dpe.workload.CONFIG_H
+    cfg = {"R": dpe.workload.CONFIG_R, "H": dpe.workload.CONFIG_H, "M": dpe.workload.CONFIG_M}[name]
     fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
     distinct = W if name != "H" else 8
     iq, cs, ce, bw = dpe.workload.build_windows(distinct, fs, S, K, seed=0, amp=cfg["amp"])
     if distinct < W:
         iq, cs, ce, bw = (np.concatenate([a] * (W // distinct))[:W] for a in (iq, cs, ce, bw))
-    _, _, pos, vel, _ = dpe.workload.build_grids(G)
+    if name == "M":
+        pos, vel, _, _, _ = dpe.workload.build_grids_strong(G, 0, 1)      # the global grids bench.py's M line scans on one GPU
+    else:
+        _, _, pos, vel, _ = dpe.workload.build_grids(G)
     bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K)
     bcs.Start()
     bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B, max_windows=W,
@@ -988,13 +992,13 @@ def test_bench_configurations_against_the_oracle(oracle, name, W, probe):
     ps, vs = bcm.read_scores()
     kernel = bcs.stage1_kernel
     bcm.Stop(); bcs.Stop()
-    assert kernel == ("bcs_bank16_kernel" if name == "R" else "bcs_bank_chip2_kernel")
+    assert kernel == ("bcs_bank_chip2_kernel" if name == "H" else "bcs_bank16_kernel")
     C = dpe.engine.carr_fft_len(S)
     for w in range(W):
         assert res[w]["posOutOfWindow"] == 0 and res[w]["velOutOfWindow"] == 0
         assert res[w]["posIndex"] == int(np.argmax(ps[w])) and res[w]["velIndex"] == int(np.argmax(vs[w]))
         assert res[w]["posScore"] == ps[w].max() and res[w]["velScore"] == vs[w].max()
-    idx = np.arange(0, G, 97)
+    idx = np.arange(0, G, 997 if name == "M" else 97)
     for w in probe:
         rc, rf = [], []
         for k in range(K):
