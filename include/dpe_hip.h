@@ -384,6 +384,15 @@ int dpe_chm_dev_destroy(dpe_chm_dev *h);
 /* Before Start: bcs / bcm (either may be NULL) get their parameter blocks from this channel manager; with bcm a ring of
  * fixRingDepth fixes is set up and dpe_chm_dev_step becomes available. */
 int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRingDepth);
+/* Sharded manifold grid in the device-resident loop (the reference takes its arg-max at batchcorrmanifold.cu:
+ * 2589-2596): the attached BatchCorrManifold scans ITS shard of the grids (dpe_bcm_config posGridIndexOffset / velGridIndexOffset),
+ * and dpe_chm_dev_step puts the exchange between the scan and the measurement kernel --
+ *     dpe_bcs_update_prepared -> dpe_bcm_update_prepared -> [ all-reduce(MAX) of the device keys over `comm` ] -> measurement ...
+ * stream-ordered on the RCCL backend, nothing copied to the host; the measurement kernel decodes the REDUCED keys against the
+ * GLOBAL fp64 grids given here (copied to the device).  Every rank runs the same channel manager on the same reduced keys and
+ * ends every window with the same fix.  After dpe_chm_dev_attach, before Start; `comm` stays the caller's. */
+int dpe_chm_dev_set_shard(dpe_chm_dev *h, dpe_comm *comm, const double *posGridGlobal_host, int64_t posGridGlobalSize,
+                          const double *velGridGlobal_host, int64_t velGridGlobalSize);
 /* The device port arrays, in the structs dpe_bcs_update_dev / dpe_bcm_update_dev take, plus rxTime and the two state ports
  * (any pointer may be NULL): what dpeflow.cpp:169-191,212 connects. */
 int dpe_chm_dev_ports(dpe_chm_dev *h, dpe_bcs_ports_dev *bcs, dpe_bcm_ports_dev *bcm, const double **rxTime_dev,

@@ -154,6 +154,10 @@ struct dpe_chm_dev {
     int ringDepth = 0;
     long long enqueued = 0;          // Updates enqueued since Start
     hipStream_t lastStream = nullptr;
+    // sharded grid (dpe_chm_dev_set_shard): the keys are all-reduced before the measurement kernel, which decodes them against the global grids
+    dpe_comm *comm = nullptr;
+    double *gPos_d = nullptr, *gVel_d = nullptr;
+    long long gPosG = 0, gVelG = 0;
 };
 
 static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1, const double *xkk1, dpe::ChmKArgs &a)
@@ -173,6 +177,10 @@ static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1,
         a.keys = reinterpret_cast<const unsigned long long *>(keys);
         a.posGrid = h->hm.posGrid64_d; a.velGrid = h->hm.velGrid64_d;
         a.posG = h->hm.posG; a.velG = h->hm.velG; a.posOff = h->hm.posOffset; a.velOff = h->hm.velOffset;
+        if (h->comm) {   // the keys carry GLOBAL indices and have been reduced over the ranks: decode against the global grids
+            a.posGrid = h->gPos_d; a.velGrid = h->gVel_d;
+            a.posG = h->gPosG; a.velG = h->gVelG; a.posOff = 0; a.velOff = 0;
+        }
         a.ring = h->ring_hd;
         a.ringDepth = h->ringDepth;
         a.stage = h->stage_d;
@@ -272,6 +280,8 @@ int dpe_chm_dev_destroy(dpe_chm_dev *h)
     if (h->bcm) (void)dpe_bcm_hook_set_publish(h->bcm, 1);
     (void)hipFree(h->st_d);
     (void)hipFree(h->portBuf_d);
+    (void)hipFree(h->gPos_d);
+    (void)hipFree(h->gVel_d);
     if (h->ring_h) (void)hipHostFree(h->ring_h);
     (void)hipFree(h->stage_d);
     delete h;
@@ -302,6 +312,27 @@ int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRi
             DPE_REQUIRE(h->stage_d, "[cuChanMgr] attach: device allocation failed");
         }
     }
+    return 0;
+}
+
+int dpe_chm_dev_set_shard(dpe_chm_dev *h, dpe_comm *comm, const double *posGridGlobal, int64_t posG, const double *velGridGlobal, int64_t velG)
+{
+    DPE_REQUIRE(h && !h->started, "[cuChanMgr] set_shard: before Start");
+    DPE_REQUIRE(h->bcm && h->ring_h, "[cuChanMgr] set_shard: attach a BatchCorrManifold first (dpe_chm_dev_attach)");
+    DPE_REQUIRE(comm && posGridGlobal && velGridGlobal && posG >= 1 && velG >= 1, "[cuChanMgr] set_shard: bad arguments");
+    // the shard this rank's scan covers must lie inside the global grids (its keys then decode to rows of them)
+    DPE_REQUIRE(h->hm.posOffset >= 0 && h->hm.posOffset + h->hm.posG <= posG && h->hm.velOffset >= 0 && h->hm.velOffset + h->hm.velG <= velG,
+                "[cuChanMgr] set_shard: the attached BatchCorrManifold scans [%lld, %lld) / [%lld, %lld), outside the global grids (%lld, %lld)",
+                (long long)h->hm.posOffset, (long long)(h->hm.posOffset + h->hm.posG), (long long)h->hm.velOffset,
+                (long long)(h->hm.velOffset + h->hm.velG), (long long)posG, (long long)velG);
+    (void)hipFree(h->gPos_d); (void)hipFree(h->gVel_d);
+    h->gPos_d = dpe::dev_alloc<double>((size_t)posG * 4);
+    h->gVel_d = dpe::dev_alloc<double>((size_t)velG * 4);
+    DPE_REQUIRE(h->gPos_d && h->gVel_d, "[cuChanMgr] set_shard: device allocation failed");
+    DPE_CHECK_HIP(hipMemcpy(h->gPos_d, posGridGlobal, sizeof(double) * 4 * (size_t)posG, hipMemcpyHostToDevice));
+    DPE_CHECK_HIP(hipMemcpy(h->gVel_d, velGridGlobal, sizeof(double) * 4 * (size_t)velG, hipMemcpyHostToDevice));
+    h->gPosG = posG; h->gVelG = velG;
+    h->comm = comm;
     return 0;
 }
 
@@ -347,6 +378,9 @@ int dpe_chm_dev_step(dpe_chm_dev *h, dpe_stream_t stream)
     DPE_REQUIRE(h && h->started, "[cuChanMgr] Error: Update() Failed due to SatPos not initialized");
     DPE_REQUIRE(h->bcs && h->bcm && h->ring_h, "[cuChanMgr] step: no BatchCorrScores / BatchCorrManifold attached (dpe_chm_dev_attach)");
     if (dpe_bcs_cotask_flush(h->bcs, stream)) return -1;   // (a time update nobody picked up: no stage-1 launch since the last step)
+    // sharded grid: the arg-max keys of the scan just enqueued are reduced over the ranks, in place and in stream order, before the
+    // measurement kernel reads them (batchcorrmanifold.cu:2589-2596 is where the reference takes its arg-max)
+    if (h->comm && dpe_bcm_exchange_keys(h->bcm, h->comm, nullptr, stream)) return -1;
     if (chm_dev_launch(h, 1, 1, nullptr, nullptr, true, (hipStream_t)stream)) return -1;
     h->lastStream = (hipStream_t)stream;
     h->enqueued += 1;

@@ -32,6 +32,7 @@ EXPORTS = [
     "dpe_bcs_update_dev", "dpe_bcs_dev_status", "dpe_bcm_update_dev", "dpe_bcm_export_scores_f64",
     "dpe_chm_dev_create", "dpe_chm_dev_destroy", "dpe_chm_dev_attach", "dpe_chm_dev_ports", "dpe_chm_dev_start", "dpe_chm_dev_update",
     "dpe_chm_dev_step", "dpe_chm_dev_fix", "dpe_chm_dev_read", "dpe_bcs_update_prepared", "dpe_bcm_update_prepared", "dpe_bcs_set_dev_hint",
+    "dpe_chm_dev_set_shard",
 ]
 
 
@@ -624,6 +625,14 @@ class ChanMgrDev:
     def attach(self, bcs=None, bcm=None, ring_depth=64):
         _check(lib().dpe_chm_dev_attach(self._h, bcs._h if bcs is not None else None, bcm._h if bcm is not None else None,
                                         C.c_int32(ring_depth)))
+
+    def set_shard(self, comm, pos_grid_global, vel_grid_global):
+        """dpe_chm_dev_set_shard: the attached BatchCorrManifold scans a shard; step() all-reduces the keys over `comm` before the
+        measurement kernel, which decodes them against these GLOBAL grids ([G, 4] each)."""
+        p = np.ascontiguousarray(pos_grid_global, dtype=np.float64)
+        v = np.ascontiguousarray(vel_grid_global, dtype=np.float64)
+        _check(lib().dpe_chm_dev_set_shard(self._h, comm._h, p.ctypes.data_as(C.c_void_p), C.c_int64(p.shape[0]),
+                                           v.ctypes.data_as(C.c_void_p), C.c_int64(v.shape[0])))
 
     def ports(self):
         """-> (BcsPortsDev, BcmPortsDev, rxTime_dev, xk1k1_dev, xkk1_dev, zVal_dev): raw device pointers."""

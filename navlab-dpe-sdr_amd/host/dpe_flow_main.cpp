@@ -12,7 +12,9 @@
 //            [--ranks N --rank r --rendezvous DIR [--comm rccl|files] [--device d] [--shard-stage1]]
 //                                                one flow per GPU: grid shard r of N, arg-max exchanged through
 //                                                dpe_bcm_exchange_keys (RCCL, or host files for tests); --shard-stage1: each
-//                                                flow correlates K / N of the channels, dpe_bcs_allgather_banks completes the banks
+//                                                flow correlates K / N of the channels, dpe_bcs_allgather_banks completes the banks.
+//                                                With --device-loop the exchange is enqueued between the scan and the channel
+//                                                manager's measurement kernel (dpe_chm_dev_set_shard): still nothing read back
 //   dpe_flow --dump-grid <type> <dim> <spacing> <out.bin>        (grid builders only, no GPU)
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +34,8 @@
 // The flow of dpeflow.cpp:55-213 with cuEKF (pass-through), cuChanMgr and the X-file logger replaced by cuChanMgrDev.
 static int run_device_loop(const std::string &samples, const std::string &handoff, const std::string &out, const std::string &rinex,
                            const std::string &loadGrid, double fs, double T, int iters, int gridDim, int gridType, int lpower, float spacing,
-                           const float *delta, int L, int B, int fixLag, int device, bool timing)
+                           const float *delta, int L, int B, int fixLag, int device, bool timing, int ranks, int rank,
+                           const std::string &rendezvous, const std::string &commName)
 {
     dsp::Flow flow;
     auto *bcs = new dsp::BatchCorrScores;
@@ -70,6 +73,15 @@ static int run_device_loop(const std::string &samples, const std::string &handof
     if (!loadGrid.empty()) {
         CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGrid", true));
         CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGridFilename", loadGrid.c_str()));
+    }
+    if (ranks > 1 || !rendezvous.empty()) {
+        // one flow per GPU, each scanning grid shard `rank` of `ranks`; the device-resident channel manager puts the key exchange
+        // between the scan and its measurement kernel (dpe_chm_dev_set_shard) -- every rank ends every window with the same fix
+        if (commName != "rccl" && commName != "files") { std::fprintf(stderr, "--comm rccl|files\n"); return 2; }
+        CHECK(flow.SetModParam("BatchCorrManifold", "ShardRank", rank));
+        CHECK(flow.SetModParam("BatchCorrManifold", "ShardCount", ranks));
+        CHECK(flow.SetModParam("BatchCorrManifold", "CommBackend", commName == "files" ? DPE_COMM_HOSTFILES : DPE_COMM_RCCL));
+        CHECK(flow.SetModParam("BatchCorrManifold", "CommRendezvous", rendezvous.c_str()));
     }
     static const char *wires[][4] = {
         {"DPInit", "StartByte", "SampleBlock", "StartByte"},
@@ -214,12 +226,12 @@ int main(int argc, char **argv)
         }
     }
 
-    if (deviceLoop && (enableEkf || ranks > 1 || !rendezvous.empty() || useGraph)) {
-        std::fprintf(stderr, "[DPEFlow] --device-loop runs the shipped pass-through filter on one GPU (not with --ekf / --ranks / --graph)\n");
+    if (deviceLoop && (enableEkf || useGraph || shardStage1)) {
+        std::fprintf(stderr, "[DPEFlow] --device-loop runs the shipped pass-through filter (not with --ekf / --graph / --shard-stage1)\n");
         return 2;
     }
     if (deviceLoop) return run_device_loop(samples, handoff, out, rinex, loadGrid, fs, T, iters, gridDim, gridType, lpower, spacing, delta, L, B,
-                                           fixLag, device, timing);
+                                           fixLag, device, timing, ranks, rank, rendezvous, commName);
     dsp::Flow flow;                                             // dpeflow.cpp:55-62
     flow.Add(new dsp::DPInit);
     flow.Add(new dsp::SampleBlock);

@@ -579,6 +579,7 @@ class BatchCorrManifold : public Module {
     }
     const dpe_bcm_result &LastResult() const { return last; }
     dpe_bcm *Handle() const { return h; }
+    dpe_comm *Comm() const { return comm; }      // the communicator of a sharded grid (nullptr: one GPU scans the whole grid)
     const std::vector<double> &TimeGrid() const { return timeGrid; }
     const std::vector<double> &PosGrid() const { return posGrid; }
     const std::vector<double> &VelGrid() const { return velGrid; }
@@ -814,6 +815,12 @@ class cuChanMgrDev : public Module {
         dpe_chm_config cfg = {K, dopplerSign, *(double *)inputs[11]->Data, *(double *)inputs[9]->Data};
         if (dpe_chm_dev_create(&cfg, init.data(), tg.data(), (int32_t)tg.size(), &h)) DPE_MOD_FAIL("Start: " << dpe_last_error());
         if (dpe_chm_dev_attach(h, bcs->Handle(), bcm->Handle(), fixLag + 8)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+        // sharded grid (BatchCorrManifold's ShardRank / ShardCount / Comm* parameters): the exchange of the arg-max keys sits between
+        // the scan and this module's measurement kernel, which decodes the reduced keys against the global grids
+        if (bcm->Comm() &&
+            dpe_chm_dev_set_shard(h, bcm->Comm(), bcm->PosGrid().data(), (int64_t)bcm->PosGrid().size() / 4, bcm->VelGrid().data(),
+                                  (int64_t)bcm->VelGrid().size() / 4))
+            DPE_MOD_FAIL("Start: " << dpe_last_error());
         if (xFilename[0]) {
             fp = std::fopen(xFilename, "w");
             if (!fp) DPE_MOD_FAIL("Unable to open file: " << xFilename);

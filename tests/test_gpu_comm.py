@@ -89,6 +89,41 @@ def test_flow_with_one_rccl_rank(tmp_path):
     assert np.array_equal(np.loadtxt(one, delimiter=","), np.loadtxt(full, delimiter=","))
 
 
+def test_sharded_device_loop_equals_the_unsharded_device_loop(tmp_path):
+    """dpe_flow --device-loop --ranks N: the device-resident channel manager with the grid sharded (dpe_chm_dev_set_shard) -- per window
+    update_prepared -> update_prepared -> all-reduce(MAX) of the device keys -> measurement kernel on the reduced keys against the
+    global grids (the reference takes its arg-max at batchcorrmanifold.cu:2589-2596).  Two ranks on one GPU through the host-file
+    transport and one rank through RCCL (stream-ordered ncclAllReduce on the device keys, nothing read back) write the X-file rows
+    of the unsharded device loop, and every rank ends with the same fix.  No scaling number is claimed."""
+    W = 12
+    dat, ho = _inputs(tmp_path, W)
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
+    base = [exe, "--samples", dat, "--handoff", ho, "--iters", str(W), "--grid-dim", "9", "--spacing", "1.0", "--init-delta", "2", "-1", "1", "3",
+            "--device-loop", "--fix-lag", "3"]
+    full = str(tmp_path / "X_dev.csv")
+    subprocess.check_call(base + ["--out", full], timeout=200)
+    ref = np.loadtxt(full, delimiter=",")
+    assert ref.shape == (W, 8)
+    rdv = str(tmp_path / "rdv")
+    os.makedirs(rdv)
+    outs = [str(tmp_path / ("X_dev_rank%d.csv" % r)) for r in range(2)]
+    procs = [subprocess.Popen(base + ["--out", outs[r], "--ranks", "2", "--rank", str(r), "--rendezvous", rdv, "--comm", "files"],
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-2000:]
+    for o in outs:
+        assert np.array_equal(np.loadtxt(o, delimiter=","), ref)
+    rdv1 = str(tmp_path / "rdv1")
+    os.makedirs(rdv1)
+    one = str(tmp_path / "X_dev_rccl.csv")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(base + ["--out", one, "--ranks", "1", "--rank", "0", "--rendezvous", rdv1, "--comm", "rccl"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.loadtxt(one, delimiter=","), ref)
+
+
 def test_comm_allreduce_max_through_python(tmp_path):
     """dpe_comm_allreduce_max_u64 on a device buffer: one RCCL rank (identity), and the packed-key semantics of the
     host-file transport with two communicator objects driven from two threads."""
