@@ -393,6 +393,13 @@ int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRi
  * ends every window with the same fix.  After dpe_chm_dev_attach, before Start; `comm` stays the caller's. */
 int dpe_chm_dev_set_shard(dpe_chm_dev *h, dpe_comm *comm, const double *posGridGlobal_host, int64_t posGridGlobalSize,
                           const double *velGridGlobal_host, int64_t velGridGlobalSize);
+/* EnableEKF = true in the device-resident loop: dsp::cuEKF::StepUpdate / StepPredict (cuekf.cu:626-742; the host form is dpe_ekf_*
+ * below) run inside the measurement kernel -- 8 x 8 fp64, one lane per matrix element, the same operations in the same order as the
+ * host form -- on the measurement just formed (R = I, as BatchCorrManifold emits it): the state ports carry x_k|k and x_k+1|k
+ * instead of the passed-through measurement, the fix record's zVal is x_k|k (what the X-file logs).  Bit 5 (32) of the record's
+ * status: S was singular in some window (state held).  After dpe_chm_dev_attach, before Start.  (dpe_ekf_config is declared below.) */
+struct dpe_ekf_config;
+int dpe_chm_dev_set_ekf(dpe_chm_dev *h, const struct dpe_ekf_config *cfg);
 /* The device port arrays, in the structs dpe_bcs_update_dev / dpe_bcm_update_dev take, plus rxTime and the two state ports
  * (any pointer may be NULL): what dpeflow.cpp:169-191,212 connects. */
 int dpe_chm_dev_ports(dpe_chm_dev *h, dpe_bcs_ports_dev *bcs, dpe_bcm_ports_dev *bcm, const double **rxTime_dev,

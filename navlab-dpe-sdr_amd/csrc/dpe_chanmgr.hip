@@ -158,6 +158,7 @@ struct dpe_chm_dev {
     dpe_comm *comm = nullptr;
     double *gPos_d = nullptr, *gVel_d = nullptr;
     long long gPosG = 0, gVelG = 0;
+    dpe::EkfDev *ekf_d = nullptr;    // cuEKF's filter inside the measurement kernel (dpe_chm_dev_set_ekf); nullptr: pass-through
 };
 
 static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1, const double *xkk1, dpe::ChmKArgs &a)
@@ -184,6 +185,7 @@ static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1,
         a.ring = h->ring_hd;
         a.ringDepth = h->ringDepth;
         a.stage = h->stage_d;
+        a.ekf = h->ekf_d;
     }
     if (h->bcs) { a.bcsChan = h->hb.chan_d; a.bcsStatus = h->hb.status_d; a.fs = h->hb.fs; a.S = h->hb.S; }
     if (h->bcm) {
@@ -282,6 +284,7 @@ int dpe_chm_dev_destroy(dpe_chm_dev *h)
     (void)hipFree(h->portBuf_d);
     (void)hipFree(h->gPos_d);
     (void)hipFree(h->gVel_d);
+    (void)hipFree(h->ekf_d);
     if (h->ring_h) (void)hipHostFree(h->ring_h);
     (void)hipFree(h->stage_d);
     delete h;
@@ -333,6 +336,29 @@ int dpe_chm_dev_set_shard(dpe_chm_dev *h, dpe_comm *comm, const double *posGridG
     DPE_CHECK_HIP(hipMemcpy(h->gVel_d, velGridGlobal, sizeof(double) * 4 * (size_t)velG, hipMemcpyHostToDevice));
     h->gPosG = posG; h->gVelG = velG;
     h->comm = comm;
+    return 0;
+}
+
+int dpe_chm_dev_set_ekf(dpe_chm_dev *h, const dpe_ekf_config *cfg)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h && cfg && !h->started, "[cuChanMgr] set_ekf: before Start");
+    DPE_REQUIRE(h->bcm && h->ring_h, "[cuChanMgr] set_ekf: attach a BatchCorrManifold first (dpe_chm_dev_attach)");
+    DPE_REQUIRE(cfg->sampleLength > 0, "[cuEKF] create: SampleLength must be positive");
+    std::vector<EkfDev> e(1);
+    memset(&e[0], 0, sizeof(EkfDev));
+    const auto eye = [](double *m) { for (int i = 0; i < 64; ++i) m[i] = (i % 9 == 0) ? 1.0 : 0.0; };
+    eye(e[0].F);                                                              // the host form's create, dpe_ekf.hip (cuekf.cu:338-352,460-477)
+    if (cfg->coupleVelocity)
+        for (int j = 0; j < 4; ++j) e[0].F[j * 8 + j + 4] = cfg->sampleLength;
+    eye(e[0].H); eye(e[0].Q); eye(e[0].K); eye(e[0].Pkk1);
+    memcpy(e[0].Pk1k1, cfg->P0, sizeof(e[0].Pk1k1));
+    memcpy(e[0].xk1k1, cfg->x0, sizeof(e[0].xk1k1));
+    memcpy(e[0].xkk1, cfg->x0, sizeof(e[0].xkk1));
+    (void)hipFree(h->ekf_d);
+    h->ekf_d = dev_alloc<EkfDev>(1);
+    DPE_REQUIRE(h->ekf_d, "[cuChanMgr] set_ekf: device allocation failed");
+    DPE_CHECK_HIP(hipMemcpy(h->ekf_d, &e[0], sizeof(EkfDev), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -256,6 +256,14 @@ struct ChmPorts {
     int *dopplerSign, *cpRef, *cpElaStart, *cpElaEnd, *cpRefTOW;
     unsigned char *prn;
 };
+// cuEKF's filter (EnableEKF = true) as device state: dsp::cuEKF::StepUpdate / StepPredict (cuekf.cu:626-742) run inside the
+// measurement kernel, one lane per matrix element.  Same fields, same row-major layout as the host form (dpe_ekf.hip).
+struct EkfDev {
+    double F[64], H[64], Q[64], K[64], Pk1k1[64], Pkk1[64], xk1k1[8], xkk1[8];
+    double lpfVals[20];
+    double lpfAvg;
+    int lpfIdx, failed;   // failed: S was singular in some window (the state is then held for that window, bit 32 of the status)
+};
 struct ChmKArgs {
     ChmDevState *st;
     ChmPorts p;
@@ -270,6 +278,7 @@ struct ChmKArgs {
     dpe_fix_record *ring;           // pinned, device address
     int ringDepth;
     dpe_fix_record *stage;          // device memory: chm_k1 leaves the window's record here, the chm_k2 that follows it sends it over the host link
+    EkfDev *ekf;                    // nullptr: EKF_PassMeas (the shipped flow); else the filter runs on the measurement (dpe_chm_dev_set_ekf)
     // parameter blocks of the attached handles for the NEXT window (nullptr: not attached)
     BcsChanDev *bcsChan;
     int *bcsStatus;
@@ -369,9 +378,132 @@ __device__ static inline int sat_state_warm(const Eph &p, double tx, double out[
 //       Then all threads: the K x dimT batch states.
 constexpr double kChmH = 0.0009765625;
 
+// ---- cuEKF on the device: the 8 x 8 fp64 steps of dpe_ekf.hip with one lane per matrix element (a block of 64 threads).
+// Every element is formed by the same operations in the same order as the host form (sums over k = 0 .. 7 ascending, no fused
+// multiply-add), so the two give the same doubles.  sm: 6 x 64 doubles of LDS scratch.
+__device__ static inline void ekf_dev_mul(const double *a, const double *b, bool bT, double *c)
+{
+#pragma clang fp contract(off)
+    const int l = threadIdx.x, i = l >> 3, j = l & 7;
+    double s = 0.0;
+    for (int k = 0; k < 8; ++k) s += a[i * 8 + k] * (bT ? b[j * 8 + k] : b[k * 8 + j]);
+    __syncthreads();   // (c may alias a or b)
+    c[l] = s;
+    __syncthreads();
+}
+// inverse through LU with partial pivoting (getrf + getri, cuekf.cu:681-694); false: singular
+__device__ static inline bool ekf_dev_invert(const double *a, double *lu, double *inv, int *piv)
+{
+#pragma clang fp contract(off)
+    const int l = threadIdx.x, r = l >> 3, kk = l & 7;
+    lu[l] = a[l];
+    if (l < 8) piv[l] = l;
+    __syncthreads();
+    for (int c = 0; c < 8; ++c) {
+        int p = c;   // (every lane finds the same pivot row)
+        for (int q = c + 1; q < 8; ++q)
+            if (fabs(lu[q * 8 + c]) > fabs(lu[p * 8 + c])) p = q;
+        if (lu[p * 8 + c] == 0.0) return false;
+        __syncthreads();
+        if (p != c) {
+            if (r == 0) { const double t = lu[p * 8 + kk]; lu[p * 8 + kk] = lu[c * 8 + kk]; lu[c * 8 + kk] = t; }
+            if (l == 0) { const int t = piv[p]; piv[p] = piv[c]; piv[c] = t; }
+        }
+        __syncthreads();
+        const double f = (r > c) ? lu[r * 8 + c] / lu[c * 8 + c] : 0.0;
+        __syncthreads();
+        if (r > c && kk == c) lu[r * 8 + c] = f;
+        if (r > c && kk > c) lu[r * 8 + kk] -= f * lu[c * 8 + kk];
+        __syncthreads();
+    }
+    if (l < 8) {   // one column of the inverse per lane
+        const int col = l;
+        double y[8];
+        for (int i = 0; i < 8; ++i) {
+            double s = (piv[i] == col) ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= lu[i * 8 + k] * y[k];
+            y[i] = s;
+        }
+        for (int i = 7; i >= 0; --i) {
+            double s = y[i];
+            for (int k = i + 1; k < 8; ++k) s -= lu[i * 8 + k] * inv[k * 8 + col];
+            inv[i * 8 + col] = s / lu[i * 8 + i];
+        }
+    }
+    __syncthreads();
+    return true;
+}
+// StepUpdate (:660-721) with the measurement z and R = I as BatchCorrManifold emits it (:2003-2011), then StepPredict (:626-656).
+// Leaves x_k|k in xOut1 and x_k+1|k in xOutK (LDS or global), returns false when S is singular (state untouched).
+__device__ static inline bool ekf_dev_step(EkfDev *e, const double *z, double *sm, int *piv)
+{
+#pragma clang fp contract(off)
+    const int l = threadIdx.x;
+    double *T = sm, *S = sm + 64, *Sinv = sm + 128, *lu = sm + 192, *y = sm + 256, *tmp = sm + 320;
+    if (l < 8) {                                                   // y = z - H x_k|k-1
+        double s = z[l];
+        for (int k = 0; k < 8; ++k) s -= e->H[l * 8 + k] * e->xkk1[k];
+        y[l] = s;
+    }
+    ekf_dev_mul(e->H, e->Pkk1, false, T);                          // S = H P H^T + R
+    ekf_dev_mul(T, e->H, true, S);
+    S[l] += (l % 9 == 0) ? 1.0 : 0.0;
+    __syncthreads();
+    if (!ekf_dev_invert(S, lu, Sinv, piv)) return false;
+    ekf_dev_mul(e->Pkk1, e->H, true, T);                           // K = P H^T S^-1
+    ekf_dev_mul(T, Sinv, false, tmp);
+    e->K[l] = tmp[l];
+    __syncthreads();
+    if (l < 8) {                                                   // x_k|k = x_k|k-1 + K y
+        double s = e->xkk1[l];
+        for (int k = 0; k < 8; ++k) s += tmp[l * 8 + k] * y[k];
+        e->xk1k1[l] = s;
+    }
+    ekf_dev_mul(tmp, e->H, false, T);                              // P_k|k = (I - K H) P_k|k-1
+    T[l] = -T[l];
+    if (l % 9 == 0) T[l] += 1.0;
+    __syncthreads();
+    ekf_dev_mul(T, e->Pkk1, false, tmp);
+    e->Pk1k1[l] = tmp[l];
+    __syncthreads();
+    // ---- StepPredict with GetQVal (:733-742) and EKF_Update_Q (:42-78)
+    if (l == 0) {
+        const double *x = e->xk1k1;
+        const double v = sqrt(x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
+        e->lpfAvg = e->lpfAvg - e->lpfVals[e->lpfIdx] + (v / 20.0);
+        e->lpfVals[e->lpfIdx] = v / 20.0;
+        if (++e->lpfIdx >= 20) e->lpfIdx = 0;
+    }
+    __syncthreads();
+    {
+        const double q = 1.0 + 250.0 / fmin(fmax(e->lpfAvg * e->lpfAvg, 50.0), 125.0);
+        double q0 = 0.0;
+        if (l == 4 * 8 + 4 || l == 5 * 8 + 5 || l == 6 * 8 + 6) q0 = q;
+        if (l == 7 * 8 + 7) q0 = (2.5e-10) * (2.5e-10) * kC * kC;   // Q_CLOCK_DRIFT, cuekf.h:28
+        S[l] = q0;                                                 // (S is free again: Q0)
+    }
+    __syncthreads();
+    ekf_dev_mul(e->F, S, false, T);                                // Q = F Q0 F^T
+    ekf_dev_mul(T, e->F, true, tmp);
+    e->Q[l] = tmp[l];
+    __syncthreads();
+    if (l < 8) {                                                   // x_k+1|k = F x_k|k
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) s += e->F[l * 8 + k] * e->xk1k1[k];
+        e->xkk1[l] = s;
+    }
+    ekf_dev_mul(e->F, e->Pk1k1, false, T);                         // P_k+1|k = F P F^T + Q
+    ekf_dev_mul(T, e->F, true, S);
+    e->Pkk1[l] = S[l] + e->Q[l];
+    __syncthreads();
+    return true;
+}
+
 __device__ static inline void chm_k1(const ChmKArgs &a)
 {
-    __shared__ double sX1[8];
+    __shared__ double sX1[8], sXk[8], sZ[8];   // x_k|k, x_k+1|k, the measurement
+    __shared__ double sEkf[6 * 64];
+    __shared__ int sPiv[8];
     __shared__ int sFlags;
     ChmDevState *st = a.st;
     const int k = threadIdx.x, K = st->K;
@@ -406,7 +538,23 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
                 for (int i = 0; i < 8; ++i) z[i] = cc[i];
                 atomicOr(&sFlags, measBad);
             }
-            for (int i = 0; i < 8; ++i) { sX1[i] = z[i]; a.p.zVal[i] = z[i]; a.p.xk1k1[i] = z[i]; a.p.xkk1[i] = z[i]; }   // EKF_PassMeas: both state ports
+            for (int i = 0; i < 8; ++i) { sX1[i] = z[i]; sXk[i] = z[i]; sZ[i] = z[i]; a.p.zVal[i] = z[i]; }   // EKF_PassMeas: z to both state ports (below)
+        }
+    }
+    if (a.meas && a.ekf) {   // EnableEKF = true: StepUpdate + StepPredict on the measurement (block-uniform branch; all 64 lanes work)
+        __syncthreads();
+        const bool ok = sFlags == 0 && ekf_dev_step(a.ekf, sZ, sEkf, sPiv);
+        __syncthreads();
+        if (k < 8) {
+            if (ok) { sX1[k] = a.ekf->xk1k1[k]; sXk[k] = a.ekf->xkk1[k]; }
+            else { sX1[k] = a.p.xkk1[k]; sXk[k] = a.p.xkk1[k]; }   // (no measurement, or S singular: hold the predicted state)
+        }
+        if (!ok && k == 0 && sFlags == 0) { atomicOr(&sFlags, 32); a.ekf->failed = 1; }
+        __syncthreads();
+    }
+    if (k == 63) {
+        if (a.meas) {
+            for (int i = 0; i < 8; ++i) { z[i] = sX1[i]; a.p.xk1k1[i] = sX1[i]; a.p.xkk1[i] = sXk[i]; }   // the state ports (cuekf.cu:277-279)
             // the fix for the host: staged in device memory; the chm_k2 behind this kernel (which has time to spare) sends it over
             // the host link -- stores to the pinned ring and the wait for them cost this kernel, which the next window's
             // correlator waits for, ~2 us
@@ -419,7 +567,7 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
             r->velOutOfWindow = (long long)a.keys[3];
             r->posScore = __uint_as_float((unsigned)(kp >> 32));
             r->velScore = __uint_as_float((unsigned)(kv >> 32));
-            r->status = st->status | measBad;
+            r->status = st->status | measBad | (sFlags & 32);
             r->seq = (unsigned long long)(st->window + 1);
         } else {
             for (int i = 0; i < 8; ++i) {

@@ -32,7 +32,7 @@ EXPORTS = [
     "dpe_bcs_update_dev", "dpe_bcs_dev_status", "dpe_bcm_update_dev", "dpe_bcm_export_scores_f64",
     "dpe_chm_dev_create", "dpe_chm_dev_destroy", "dpe_chm_dev_attach", "dpe_chm_dev_ports", "dpe_chm_dev_start", "dpe_chm_dev_update",
     "dpe_chm_dev_step", "dpe_chm_dev_fix", "dpe_chm_dev_read", "dpe_bcs_update_prepared", "dpe_bcm_update_prepared", "dpe_bcs_set_dev_hint",
-    "dpe_chm_dev_set_shard",
+    "dpe_chm_dev_set_shard", "dpe_chm_dev_set_ekf",
 ]
 
 
@@ -633,6 +633,13 @@ class ChanMgrDev:
         v = np.ascontiguousarray(vel_grid_global, dtype=np.float64)
         _check(lib().dpe_chm_dev_set_shard(self._h, comm._h, p.ctypes.data_as(C.c_void_p), C.c_int64(p.shape[0]),
                                            v.ctypes.data_as(C.c_void_p), C.c_int64(v.shape[0])))
+
+    def set_ekf(self, T, x0, P0=None, couple_velocity=True):
+        """dpe_chm_dev_set_ekf: cuEKF's filter (EnableEKF = true) inside the measurement kernel instead of the pass-through."""
+        cfg = EkfConfig(float(T), 1 if couple_velocity else 0, 0)
+        cfg.x0[:] = [float(v) for v in np.asarray(x0, dtype=np.float64)]
+        cfg.P0[:] = [float(v) for v in (np.eye(8) if P0 is None else np.asarray(P0, dtype=np.float64)).reshape(64)]
+        _check(lib().dpe_chm_dev_set_ekf(self._h, C.byref(cfg)))
 
     def ports(self):
         """-> (BcsPortsDev, BcmPortsDev, rxTime_dev, xk1k1_dev, xkk1_dev, zVal_dev): raw device pointers."""

@@ -35,7 +35,7 @@
 static int run_device_loop(const std::string &samples, const std::string &handoff, const std::string &out, const std::string &rinex,
                            const std::string &loadGrid, double fs, double T, int iters, int gridDim, int gridType, int lpower, float spacing,
                            const float *delta, int L, int B, int fixLag, int device, bool timing, int ranks, int rank,
-                           const std::string &rendezvous, const std::string &commName)
+                           const std::string &rendezvous, const std::string &commName, bool enableEkf)
 {
     dsp::Flow flow;
     auto *bcs = new dsp::BatchCorrScores;
@@ -69,6 +69,7 @@ static int run_device_loop(const std::string &samples, const std::string &handof
     CHECK(flow.SetModParam("BatchCorrScores", "BinHalfWidth", B));
     CHECK(flow.SetModParam("cuChanMgr", "DopplerSign", 1));
     CHECK(flow.SetModParam("cuChanMgr", "FixLag", fixLag));
+    CHECK(flow.SetModParam("cuChanMgr", "EnableEKF", enableEkf));   // cuEKF's filter inside the measurement kernel (dpe_chm_dev_set_ekf)
     CHECK(flow.SetModParam("cuChanMgr", "XFilename", out.c_str()));
     if (!loadGrid.empty()) {
         CHECK(flow.SetModParam("BatchCorrManifold", "LoadPosGrid", true));
@@ -86,6 +87,7 @@ static int run_device_loop(const std::string &samples, const std::string &handof
     static const char *wires[][4] = {
         {"DPInit", "StartByte", "SampleBlock", "StartByte"},
         {"DPInit", "InitX", "cuChanMgr", "InitX"},
+        {"DPInit", "InitP", "cuChanMgr", "InitP"},
         {"DPInit", "InitEph", "cuChanMgr", "InitEph"},
         {"DPInit", "InitPRN", "cuChanMgr", "InitPRN"},
         {"DPInit", "InitCodePhase", "cuChanMgr", "InitCodePhase"},
@@ -226,12 +228,12 @@ int main(int argc, char **argv)
         }
     }
 
-    if (deviceLoop && (enableEkf || useGraph || shardStage1)) {
-        std::fprintf(stderr, "[DPEFlow] --device-loop runs the shipped pass-through filter (not with --ekf / --graph / --shard-stage1)\n");
+    if (deviceLoop && (useGraph || shardStage1)) {
+        std::fprintf(stderr, "[DPEFlow] --device-loop launches eagerly and correlates every channel on every rank (not with --graph / --shard-stage1)\n");
         return 2;
     }
     if (deviceLoop) return run_device_loop(samples, handoff, out, rinex, loadGrid, fs, T, iters, gridDim, gridType, lpower, spacing, delta, L, B,
-                                           fixLag, device, timing, ranks, rank, rendezvous, commName);
+                                           fixLag, device, timing, ranks, rank, rendezvous, commName, enableEkf);
     dsp::Flow flow;                                             // dpeflow.cpp:55-62
     flow.Add(new dsp::DPInit);
     flow.Add(new dsp::SampleBlock);

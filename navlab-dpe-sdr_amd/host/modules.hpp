@@ -771,14 +771,16 @@ class cuChanMgrDev : public Module {
     cuChanMgrDev(BatchCorrScores *bcs_, BatchCorrManifold *bcm_) : bcs(bcs_), bcm(bcm_)
     {
         ModuleName = "cuChanMgr";
-        AllocateInputs(12);
+        AllocateInputs(13);
         AllocateOutputs(18);
-        const char *in[12] = {"InitEph", "InitPRN", "InitCodePhase", "InitCarrierPhase", "InitCodeFrequency", "InitCarrierFrequency",
-                              "InitElapsedCodePeriods", "InitReferenceCodePeriods", "InitCPRefTOW", "InitRXTime", "InitX", "SampleLength"};
-        const DataType_t idt[12] = {UNDEFINED_t, CHAR_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, INT_t, INT_t, INT_t, DOUBLE_t, DOUBLE_t, DOUBLE_t};
-        const ValueType_t ivt[12] = {EPHEMS, VALUE, VALUE, VALUE, FREQUENCY_HZ, FREQUENCY_HZ, VALUE, VALUE, VALUE, VALUE, STATE, VALUE};
-        for (int i = 0; i < 12; ++i) ConfigExpectedInput(i, in[i], idt[i], ivt[i], i == 11 ? 1 : VECTORLENGTH_ANY);
+        const char *in[13] = {"InitEph", "InitPRN", "InitCodePhase", "InitCarrierPhase", "InitCodeFrequency", "InitCarrierFrequency",
+                              "InitElapsedCodePeriods", "InitReferenceCodePeriods", "InitCPRefTOW", "InitRXTime", "InitX", "SampleLength",
+                              "InitP"};   // InitP: cuEKF's input (cuekf.cu:352), optional, read with EnableEKF
+        const DataType_t idt[13] = {UNDEFINED_t, CHAR_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, INT_t, INT_t, INT_t, DOUBLE_t, DOUBLE_t, DOUBLE_t, DOUBLE_t};
+        const ValueType_t ivt[13] = {EPHEMS, VALUE, VALUE, VALUE, FREQUENCY_HZ, FREQUENCY_HZ, VALUE, VALUE, VALUE, VALUE, STATE, VALUE, COVARIANCE};
+        for (int i = 0; i < 13; ++i) ConfigExpectedInput(i, in[i], idt[i], ivt[i], i == 11 ? 1 : VECTORLENGTH_ANY);
         InsertParam("DopplerSign", &dopplerSign, INT_t, sizeof(int), sizeof(int));
+        InsertParam("EnableEKF", &enableEkf, BOOL_t, sizeof(bool), sizeof(bool));   // cuEKF's parameter: the filter runs in this module's measurement kernel
         InsertParam("FixLag", &fixLag, INT_t, sizeof(int), sizeof(int));
         InsertParam("XFilename", xFilename, CHAR_t, sizeof(xFilename), 0);
         const char *out[18] = {"rxTime", "txTime", "CodePhaseStart", "CarrierPhaseStart", "CodePhaseEnd", "CarrierPhaseEnd",
@@ -817,6 +819,15 @@ class cuChanMgrDev : public Module {
         if (dpe_chm_dev_attach(h, bcs->Handle(), bcm->Handle(), fixLag + 8)) DPE_MOD_FAIL("Start: " << dpe_last_error());
         // sharded grid (BatchCorrManifold's ShardRank / ShardCount / Comm* parameters): the exchange of the arg-max keys sits between
         // the scan and this module's measurement kernel, which decodes the reduced keys against the global grids
+        if (enableEkf) {   // dsp::cuEKF with EnableEKF = true (cuekf.cu:338-352,460): F couples the velocities over one window
+            dpe_ekf_config ec = {};
+            ec.sampleLength = *(double *)inputs[11]->Data;
+            ec.coupleVelocity = 1;
+            std::memcpy(ec.x0, inputs[10]->Data, sizeof(ec.x0));
+            if (inputs[12]) std::memcpy(ec.P0, inputs[12]->Data, sizeof(ec.P0));
+            else for (int i = 0; i < 64; ++i) ec.P0[i] = (i % 9 == 0) ? 1.0 : 0.0;
+            if (dpe_chm_dev_set_ekf(h, &ec)) DPE_MOD_FAIL("Start: " << dpe_last_error());
+        }
         if (bcm->Comm() &&
             dpe_chm_dev_set_shard(h, bcm->Comm(), bcm->PosGrid().data(), (int64_t)bcm->PosGrid().size() / 4, bcm->VelGrid().data(),
                                   (int64_t)bcm->VelGrid().size() / 4))
@@ -892,6 +903,7 @@ class cuChanMgrDev : public Module {
     BatchCorrManifold *bcm;
     dpe_chm_dev *h = nullptr;
     int K = 0, dopplerSign = 1, fixLag = 8;
+    bool enableEkf = false;
     long long enq = 0, got = 0;
     bool warned = false;
     char xFilename[512] = "";

@@ -161,3 +161,30 @@ def test_cpp_flow_device_loop_matches_the_host_driven_flow(tmp_path):
         rows[name] = np.loadtxt(out, delimiter=",")
         assert rows[name].shape == (W, 8)
     assert np.array_equal(rows["dev"], rows["host"]) and np.array_equal(rows["dev1"], rows["host"])     # "%f" rows
+
+
+def test_cpp_flow_device_loop_with_the_filter_matches_the_host_driven_filter(tmp_path):
+    """EnableEKF = true: host/dpe_flow --ekf runs dsp::cuEKF's StepUpdate / StepPredict (cuekf.cu:626-742) on the host in fp64
+    (dpe_ekf_*, pinned by fixture O10); --device-loop --ekf runs the same 8 x 8 steps inside the channel manager's measurement
+    kernel, one lane per matrix element, the same operations in the same order (dpe_chm_dev_set_ekf).  The logged state x_k|k and,
+    through the predicted state that centres the next window's grids, every later fix: identical X-file rows."""
+    import os
+    import subprocess
+    W, fs, S, K = 30, 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=5, amp=200.0, velocity=np.array([4.0, -2.0, 1.0]))
+    dat = str(tmp_path / "synthetic_2500kHz.dat")
+    iq.tofile(dat)
+    ho_path = str(tmp_path / "handoff.csv")
+    with open(dpe.workload.HANDOFF_CSV) as f, open(ho_path, "w") as g:
+        for line in f:
+            g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
+    rows = {}
+    for name, extra in (("host", ["--ekf"]), ("dev", ["--device-loop", "--ekf", "--fix-lag", "3"]), ("pass", ["--device-loop"])):
+        out = str(tmp_path / ("X_%s.csv" % name))
+        subprocess.check_call([exe, "--samples", dat, "--handoff", ho_path, "--out", out, "--iters", str(W), "--grid-dim", "9",
+                               "--spacing", "1.0", "--init-delta", "2", "-1", "1", "3"] + extra)
+        rows[name] = np.loadtxt(out, delimiter=",")
+        assert rows[name].shape == (W, 8)
+    assert np.array_equal(rows["dev"], rows["host"])               # "%f" rows
+    assert not np.array_equal(rows["dev"], rows["pass"])           # ... and the filter really ran (the pass-through rows differ)
