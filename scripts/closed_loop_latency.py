@@ -15,13 +15,14 @@ with open(dpe.workload.HANDOFF_CSV) as f, open(ho_path, "w") as g:
         g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
 exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "dpe_flow")
 base = {}
-for dim, extra in ((9, []), (9, ["--device-loop"]), (9, ["--graph"]), (25, []), (25, ["--device-loop"]), (25, ["--device-loop", "--fix-lag", "2"]), (25, ["--graph"])):
+for dim, extra in ((9, []), (9, ["--device-loop"]), (9, ["--graph"]), (25, []), (25, ["--device-loop"]), (25, ["--device-loop", "--fix-lag", "2"]), (25, ["--graph"]),
+                   (25, ["--ekf"]), (25, ["--device-loop", "--ekf"])):      # EnableEKF = true: the filter on the host / inside the measurement kernel
     r = subprocess.run([exe, "--samples", dat, "--handoff", ho_path, "--out", os.path.join(d, "X.csv"), "--iters", str(W), "--grid-dim", str(dim), "--spacing", "1.0"] + extra, capture_output=True, text=True, timeout=120)
     print(dim, extra, [l for l in r.stderr.splitlines() if "iterations" in l or "LoadFlow" in l or "second half" in l])
     rows = np.loadtxt(os.path.join(d, "X.csv"), delimiter=",")
     ho = dpe.handoff.read_handoff(ho_path)
     print("  max |fix - truth| m:", np.abs(rows[:, :3] - ho["X_ECEF"][:3]).max(), "rows", rows.shape)
-    if not extra:
-        base[dim] = rows
+    if not extra or extra == ["--ekf"]:
+        base[(dim, "--ekf" in extra)] = rows
     elif extra[0] == "--device-loop":
-        print("  max |fix - host-driven loop| m:", np.abs(rows - base[dim]).max())
+        print("  max |fix - host-driven loop| m:", np.abs(rows - base[(dim, "--ekf" in extra)]).max())
