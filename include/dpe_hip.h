@@ -145,7 +145,11 @@ int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream);
  * back and does not wait for the stream; the prep kernel checks the promise (and that the nav-bit boundary falls on a chip boundary
  * of the replica, which it does unless fp64 rounding separates the two expressions -- about once in 1e10 windows): bit 3 of
  * dpe_bcs_dev_status = it did not hold for that window (banks then within the chip kernel's error for such input, not within the
- * stated tolerance; re-run the window without the hint).  0 clears the promise. */
+ * stated tolerance; re-run the window without the hint).  A broken promise also withdraws the hint: the device-side check raises a
+ * pinned word, and from the next call that finds it raised the handle reads the derived block back and chooses the kernel from the
+ * real values again, for the rest of its life (the flagged window -- at most the few the host had already enqueued -- keeps its bit 3).
+ * The same check runs in the device-resident channel manager's kernel for dpe_bcs_update_prepared, which launches no prep kernel
+ * (bit 6 = 64 of the fix record's status).  0 clears the promise. */
 #define DPE_DEV_HINT_CHIP 1
 int dpe_bcs_set_dev_hint(dpe_bcs *h, int32_t flags);
 /* Output ports CodeScores / CarrScores / NumFFTPoints (batchcorrscores.cu:696-698,869-874).
@@ -195,8 +199,12 @@ typedef struct dpe_bcm_config {
                                  * the Update then finds the affected grid points with one device pass, re-evaluates them in fp64
                                  * on the host, patches their scores with one scatter launch and re-derives the arg-max
                                  * (synchronous: a few stream waits per Update, cost proportional to the number of affected points
-                                 * -- a handful; no fixed limit; needs writeScores and the host form of the inputs).  0 (default):
-                                 * the continuous interpolation everywhere.  No effect when S / 2 is not a power of two. */
+                                 * -- a handful; no fixed limit; needs writeScores).  With the device ports (dpe_bcm_update_dev) the
+                                 * whole fix-up stays on the device -- candidates, the reference's expression in fp64 from the port
+                                 * arrays, scores patched in place, arg-max re-derived -- with nothing read back; there it needs
+                                 * weightedMean = 0 and holds at most 65 536 candidate points per window (more: an error from the
+                                 * results call).  Not with dpe_bcm_update_prepared (its blocks hold expansion coefficients only).
+                                 * 0 (default): the continuous interpolation everywhere.  No effect when S / 2 is not a power of two. */
     int32_t reserved;
 } dpe_bcm_config;
 
@@ -251,7 +259,7 @@ int dpe_bcm_update(dpe_bcm *h, const float *codeBank_dev, const float *carrBank_
  * captured once at batchcorrmanifold.cu:2512-2533, xCurrkk1 re-read per Update :2540); rxTime is a host scalar in the
  * reference too (:2536-2537).  A one-block kernel forms the per-SV expansion coefficients in fp64 on the device (the centre
  * index as a compensated sum where the host form uses long double); the scan runs with its range clamps on, since the host
- * cannot prove the indices inside the banks.  Not with referencePair. */
+ * cannot prove the indices inside the banks.  referencePair: see dpe_bcm_config. */
 typedef struct dpe_bcm_ports_dev {
     const double *xCurrkk1;            /* [8]  (input 2) */
     const double *enu2ecef;            /* [9]  row-major (input 12) */
@@ -375,7 +383,8 @@ typedef struct dpe_fix_record {
     int64_t posOutOfWindow, velOutOfWindow;
     float posScore, velScore;
     int32_t status;             /* sticky bits: 1 Kepler iteration failed, 4 an arg-max key was 0 / outside the grid (state held for
-                                 * that window), 8 / 16 the BatchCorrScores input flags of dpe_bcs_dev_status */
+                                 * that window), 8 / 16 the BatchCorrScores input flags of dpe_bcs_dev_status, 32 the filter's S was singular
+                                 * (dpe_chm_dev_set_ekf; state held), 64 a dpe_bcs_set_dev_hint promise did not hold */
     int32_t reserved;
 } dpe_fix_record;
 int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans, const double *timeGrid_host, int32_t dimT,

@@ -488,6 +488,70 @@ __global__ __launch_bounds__(256) void bcm_rekey_kernel(const float *__restrict_
     if ((threadIdx.x & 63) == 0 && best) atomicMax(&keys[2 * (size_t)w], best);
 }
 
+// referencePair for the device-parameter form (dpe_bcm_update_dev), step 2 on the device: one thread per candidate re-evaluates its
+// point with the reference's own expression in fp64 (batchcorrmanifold.cu:1760-1816, the host form's ref_pair_index / ref_pair_fixup
+// operation for operation) from the port arrays, and where the neighbour pair is two apart writes the score in place.  A candidate
+// list that overflowed its capacity cannot be grown without the host: bit 1 of the window frame's `bad` (the results call reports it).
+#pragma clang fp contract(off)
+__device__ static inline bool ref_pair_index_dev(const double *R, const double *c, const double *s, double rxTime, double rcEnd, double fc,
+                                                 int cpRefTOW, int cpElaEnd, int cpRef, const double *g, double fs, int S, int k,
+                                                 double *idxOut, double *fiOut, double *ciOut)
+{
+    const double px = R[0] * g[0] + R[1] * g[1] + R[2] * g[2] + c[0];        // :1760-1763
+    const double py = R[3] * g[0] + R[4] * g[1] + R[5] * g[2] + c[1];
+    const double pz = R[6] * g[0] + R[7] * g[1] + R[8] * g[2] + c[2];
+    const double pdt = g[3] + c[3];
+    const double lx = s[0] - px, ly = s[1] - py, lz = s[2] - pz;            // :1779-1781
+    const double range = sqrt(lx * lx + ly * ly + lz * lz);                 // :1782
+    const double pr = range - kC * s[3] + pdt;                              // :1783
+    const double txT = rxTime - pr / kC;                                    // :1784
+    const double cfd = txT - cpRefTOW - ((cpElaEnd - cpRef) * kTCA);
+    const double rcbc = cfd * kFCA;                                         // :1786
+    const double rc0 = rcbc - rcEnd;                                        // :1790
+    const double base = (fs / fc) * (-rc0) + S / 2.0;                       // :1791
+    if (!(base < S && base > 0)) return false;                              // :1795
+    const double idx = base + ((double)S * k);                              // :1797
+    *idxOut = idx;
+    *fiOut = floor(idx);                                                    // :1798
+    *ciOut = floor(idx + 1);                                                // :1799
+    return true;
+}
+__global__ __launch_bounds__(64) void bcm_refpair_eval_kernel(BcmPortsDev p, int K, double rxTime, double fs, int S, int L, int lPower,
+                                                               const double *__restrict__ grid64, const float2 *__restrict__ bank, int maxK,
+                                                               const unsigned long long *__restrict__ cand, unsigned long long capacity,
+                                                               float *__restrict__ scores, long long pitch, BcmDevWin *__restrict__ hostWin,
+                                                               unsigned long long *__restrict__ patched)
+{
+    const unsigned long long nAll = cand[0], n = nAll < capacity ? nAll : capacity;
+    if (nAll > capacity && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&hostWin->bad, 2);
+    const int nLag = 2 * L + 1;
+    for (unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 64) {
+        const unsigned long long wi = cand[1 + j];
+        const long long i = (long long)(wi & ((1ull << 40) - 1));   // (one window in this form)
+        const double *g = grid64 + 4 * i;
+        double idx, fi_, ci_;
+        const double *s0 = p.sat + ((size_t)0 * p.dimT + p.dimT / 2) * 8;
+        if (!ref_pair_index_dev(p.R, p.x, s0, rxTime, p.rcEnd[0], p.fc[0], p.cpRefTOW[0], p.cpElaEnd[0], p.cpRef[0], g, fs, S, 0, &idx, &fi_, &ci_)) continue;
+        if (ci_ - fi_ != 2.0) continue;                                   // the ordinary pair: the scan's value stands
+        double score = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double *s = p.sat + ((size_t)k * p.dimT + p.dimT / 2) * 8;
+            if (!ref_pair_index_dev(p.R, p.x, s, rxTime, p.rcEnd[k], p.fc[k], p.cpRefTOW[k], p.cpElaEnd[k], p.cpRef[k], g, fs, S, k, &idx, &fi_, &ci_)) continue;
+            const long long fin = (long long)fi_ - (long long)S * k - (S / 2 - L);
+            const long long cin = (long long)ci_ - (long long)S * k - (S / 2 - L);
+            if (fin < 0 || cin < 0 || fin >= nLag || cin >= nLag) continue;
+            const float2 *row = bank + (size_t)k * nLag;
+            const double wc = idx - fi_, wf = ci_ - idx;                 // :1810-1811
+            const double vr = (double)row[cin].x * wc + (double)row[fin].x * wf;
+            const double vi = (double)row[cin].y * wc + (double)row[fin].y * wf;
+            score += pow(hypot(vr, vi), (double)lPower);                  // :1816
+        }
+        scores[(size_t)i] = (float)score;
+        atomicAdd(patched, 1ull);
+        (void)maxK; (void)pitch;
+    }
+}
+
 }  // namespace dpe
 
 // ============================================================================================
@@ -527,6 +591,9 @@ struct dpe_bcm {
     size_t refPatchCap = 0;
     std::vector<double> refWsum;            // [W][5] corrections of the weighted sums (patched - scanned score at offset x,y,z,t)
     long long refPatched = 0;               // points patched by the last Update (diagnostic)
+    dpe::BcmPortsDev refPorts{};            // the device ports of the dpe_bcm_update_dev in progress (referencePair on the device)
+    double refRxTime = 0.0;
+    unsigned long long *refPatched_d = nullptr;
     std::vector<dpe_bcm_window> win_h;
     dpe::BcmDevWin *devWin_h = nullptr, *devWin_hd = nullptr;   // pinned [2]: window frame of a device-parameter Update (written by bcm_prep_kernel),
                                                                 // one per alternating key set, so that the results of Update n can still be
@@ -903,7 +970,7 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
 int dpe_bcm_destroy(dpe_bcm *h)
 {
     if (!h) return 0;
-    void *bufs[] = {h->posGrid64_d, h->velGrid64_d, h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d, h->done_d};
+    void *bufs[] = {h->posGrid64_d, h->velGrid64_d, h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d, h->done_d, h->refPatched_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->svBase_h) (void)hipHostFree(h->svBase_h);
     if (h->keys_h) (void)hipHostFree(h->keys_h);
@@ -1058,9 +1125,34 @@ static int bcm_update_impl(dpe_bcm *h, const float *codeBank_dev, const float *c
         }
     }
     h->cur = use;
-    if (h->refPair) {
+    if (h->refPair && !dev) {
         h->pollable = false;
         if (ref_pair_fixup(h, codeBank_dev, nWindows, nChan, chan_host, keys, stream)) return -1;
+    } else if (h->refPair) {
+        // device-parameter form (dpe_bcm_update_dev): candidates, re-evaluation, patch and arg-max all on the device, nothing read back
+        h->pollable = false;
+        const long long G = h->cfg.posGridSize;
+        if (!h->refCand_d) {
+            if (h->refCap == 0) h->refCap = 1 << 16;
+            h->refCand_d = dev_alloc<unsigned long long>(1 + h->refCap);
+        }
+        if (!h->refPatched_d) h->refPatched_d = dev_alloc<unsigned long long>(1);
+        DPE_REQUIRE(h->refCand_d && h->refPatched_d, "[BatchCorrManifold] Update: referencePair: candidate list allocation failed");
+        if (!h->posGrid64_d) { dpe_bcm_hook hk; if (dpe_bcm_hook_get(h, &hk)) return -1; }   // (makes the fp64 copies of the grids)
+        DPE_CHECK_HIP(hipMemsetAsync(h->refCand_d, 0, sizeof(unsigned long long), stream));
+        DPE_CHECK_HIP(hipMemsetAsync(h->refPatched_d, 0, sizeof(unsigned long long), stream));
+        const unsigned gx = (unsigned)((G + 256 * 8 - 1) / (256 * 8));
+        hipLaunchKernelGGL(bcm_refpair_candidates_kernel, dim3(gx > 1024 ? 1024 : gx, 1), dim3(256), 0, stream, h->posGrid_d, G, h->sv_d,
+                           h->cfg.maxChannels, h->cfg.lagHalfWidth, 5e-4, h->refCand_d, h->refCap);
+        hipLaunchKernelGGL(bcm_refpair_eval_kernel, dim3(64), dim3(64), 0, stream, h->refPorts, (int)nChan, h->refRxTime, h->cfg.samplingFrequency,
+                           h->cfg.samplesPerWindow, h->cfg.lagHalfWidth, h->cfg.lPower, h->posGrid64_d, reinterpret_cast<const float2 *>(codeBank_dev),
+                           h->cfg.maxChannels, h->refCand_d, h->refCap, h->posScores_d, h->posPitch, h->devWin_hd + use, h->refPatched_d);
+        hipLaunchKernelGGL(bcm_zero_pos_keys_kernel, dim3(1), dim3(64), 0, stream, keys, 1);
+        const unsigned gr = (unsigned)((G + 256 * 16 - 1) / (256 * 16));
+        hipLaunchKernelGGL(bcm_rekey_kernel, dim3(gr > 512 ? 512 : gr, 1), dim3(256), 0, stream, h->posScores_d, G, h->posPitch,
+                           (long long)h->cfg.posGridIndexOffset, keys);
+        DPE_CHECK_HIP(hipGetLastError());
+        h->lastPublished = false;   // (the pinned mirror holds the scan's keys from before the patch: the results call fetches the re-derived ones)
     }
     return 0;
 }
@@ -1078,13 +1170,17 @@ int dpe_bcm_update_dev(dpe_bcm *h, const float *codeBank_dev, const float *carrB
     using namespace dpe;
     DPE_REQUIRE(h && ports, "[BatchCorrManifold] Update: null argument");
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrManifold] Update: nChan %d out of range", nChan);
-    DPE_REQUIRE(!h->refPair, "[BatchCorrManifold] Update: referencePair re-evaluates points on the host and needs the host form of the inputs");
+    DPE_REQUIRE(!h->refPair || (h->cfg.writeScores && !h->cfg.weightedMean),
+                "[BatchCorrManifold] Update: referencePair with the device ports patches the scores on the device: it needs writeScores and no weightedMean "
+                "(the weighted sums are corrected on the host in the host form only)");
     DPE_REQUIRE(ports->xCurrkk1 && ports->enu2ecef && ports->satStates && ports->codePhaseEnd && ports->codeFrequency &&
                 ports->carrierFrequency && ports->cpRefTOW && ports->cpElapsedEnd && ports->cpRef && ports->dopplerSign && ports->dimT >= 1,
                 "[BatchCorrManifold] Update: a device port pointer is null / dimT < 1");
     const BcmPortsDev p = {ports->xCurrkk1, ports->enu2ecef, ports->satStates, ports->codePhaseEnd, ports->codeFrequency, ports->carrierFrequency,
                            ports->cpRefTOW, ports->cpElapsedEnd, ports->cpRef, ports->dopplerSign, ports->dimT};
     const size_t W = h->cfg.maxWindows, maxK = h->cfg.maxChannels;
+    h->refPorts = p;
+    h->refRxTime = rxTime;
     hipLaunchKernelGGL(bcm_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, rxTime, (const double *)nullptr, h->cfg.samplingFrequency,
                        (double)h->cfg.numFFTPoints, h->cfg.samplesPerWindow, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, (long long)h->cfg.numFFTPoints,
                        h->sv_d, h->sv_d + W * maxK, h->devWin_hd + (h->cur ^ 1));   // (the frame of the key set this Update reduces into)
@@ -1095,7 +1191,8 @@ int dpe_bcm_update_prepared(dpe_bcm *h, const float *codeBank_dev, const float *
 {
     DPE_REQUIRE(h, "[BatchCorrManifold] Update: null argument");
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrManifold] Update: nChan %d out of range", nChan);
-    DPE_REQUIRE(!h->refPair, "[BatchCorrManifold] Update: referencePair re-evaluates points on the host and needs the host form of the inputs");
+    DPE_REQUIRE(!h->refPair, "[BatchCorrManifold] Update: referencePair needs the port arrays (dpe_bcm_update_dev) or the host form of the inputs: "
+                             "the prepared blocks hold the expansion coefficients only");
     return bcm_update_impl(h, codeBank_dev, carrBank_dev, 1, nChan, nullptr, nullptr, stream);
 }
 
@@ -1168,7 +1265,9 @@ static int fetch_device_frame(dpe_bcm *h)
 {
     if (!h->lastDev) return 0;
     const dpe::BcmDevWin &fw = h->devWin_h[h->cur];
-    DPE_REQUIRE(!fw.bad, "[BatchCorrManifold] results: DopplerSign on the device is not +/-1");
+    DPE_REQUIRE(!(fw.bad & 1), "[BatchCorrManifold] results: DopplerSign on the device is not +/-1");
+    DPE_REQUIRE(!(fw.bad & 2), "[BatchCorrManifold] results: referencePair: more candidate points than the device list holds (%llu): scores partly unpatched",
+                (unsigned long long)h->refCap);
     memcpy(h->win_h[0].xCurrkk1, fw.xCurrkk1, sizeof(double) * 8);
     memcpy(h->win_h[0].enu2ecef, fw.enu2ecef, sizeof(double) * 9);
     h->win_h[0].dopplerSign = fw.dopplerSign;

@@ -1079,7 +1079,7 @@ struct BcsPortsDev {
 // the conditions it could not check are checked here, bit 3 of the status = one of them does not hold (chips of hintL1 or hintL1 + 1
 // samples, code step within the assumed bound, 2 pi |fi| <= 0.25 fc, the nav-bit boundary on a chip boundary of the replica).
 __global__ void bcs_prep_kernel(BcsPortsDev p, int K, double fs, int S, BcsChanDev *__restrict__ out, int *__restrict__ status, int hintL1,
-                                double hintStepMax)
+                                double hintStepMax, int *__restrict__ hintViol)
 {
     const int k = threadIdx.x;
     if (k == 0) atomicAnd(status, ~15);   // (bits 0 .. 3 are this kernel's; bits 2 and 4 belong to the batches whose DC sums ride in the stage-1 launch)
@@ -1088,9 +1088,9 @@ __global__ void bcs_prep_kernel(BcsPortsDev p, int K, double fs, int S, BcsChanD
     int bad;
     const BcsChanDev d = bcs_prep_one(p.rc[k], p.ri[k], p.fc[k], p.fi[k], p.cpEla[k], p.cpRef[k], (int)p.prn[k], fs, S, bad);
     out[k] = d;
-    if (hintL1 > 0) {
-        const bool offBoundary = d.hasFlip && (int)fma((double)d.idxNext, d.codeStep, d.rc) == (int)fma((double)(d.idxNext - 1), d.codeStep, d.rc);
-        if ((int)d.invStep != hintL1 || d.codeStep > hintStepMax || 6.283185307179586 * fabs(d.fi) > 0.25 * d.fc || offBoundary) bad |= 8;
+    if (hintL1 > 0 && hint_broken(d, hintL1, hintStepMax)) {
+        bad |= 8;
+        __hip_atomic_store(hintViol, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (pinned: the host drops the hint at its next call)
     }
     if (bad) atomicOr(status, bad);
 }
@@ -1170,6 +1170,7 @@ struct dpe_bcs {
     dpe::ChmKArgs co{};            // a task of the device-resident channel manager for the next stage-1 launch (dpe_bcs_cotask_set)
     bool coPending = false;
     int devHint = 0;               // dpe_bcs_set_dev_hint: bit 0 = the caller promises the chip kernels' conditions for the device-parameter form
+    int *hintViol_h = nullptr, *hintViol_hd = nullptr;   // pinned word a device-side check raises when the promise did not hold: the hint is then dropped
     std::vector<int32_t> idxNext_h;
     dpe::KernelProfiler prof;  // slots: 0 sum, 1 bank, 2 finalize
     dpe::GraphCache graphs;
@@ -1309,7 +1310,11 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     h->info_d = dev_alloc<int>(W * K);
     h->status_d = dev_alloc<int>(1);
     if (h->status_d) (void)hipMemset(h->status_d, 0, sizeof(int));
-    if (!h->status_d || !h->rideWord_d || !h->tTable_d || !h->chipTable_d || !h->chipBits_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
+    if (hipHostMalloc((void **)&h->hintViol_h, sizeof(int), hipHostMallocDefault) == hipSuccess) {
+        *h->hintViol_h = 0;
+        (void)hipHostGetDevicePointer((void **)&h->hintViol_hd, h->hintViol_h, 0);
+    }
+    if (!h->status_d || !h->hintViol_hd || !h->rideWord_d || !h->tTable_d || !h->chipTable_d || !h->chipBits_d || !h->sums_d || !h->chan_d || !h->part_d || !h->mom_d || !h->momRep_d || !h->codeBank_d || !h->carrBank_d ||
         !h->info_d || hipHostMalloc((void **)&h->chanBase_h, dpe_bcs::kStaging * W * K * sizeof(BcsChanDev), hipHostMallocDefault) != hipSuccess) {
         set_error("[BatchCorrScores] create: device allocation failed");
         dpe_bcs_destroy(h);
@@ -1370,6 +1375,7 @@ int dpe_bcs_destroy(dpe_bcs *h)
     void *bufs[] = {h->tTable_d, h->chipTable_d, h->chipBits_d, h->sums_d, h->rideWord_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
+    if (h->hintViol_h) (void)hipHostFree(h->hintViol_h);
     h->planS3.destroy(); h->planS2.destroy(); h->planC.destroy();
     (void)hipFree(h->fftWork_d);
     for (hipEvent_t e : h->stagingFree)
@@ -1428,6 +1434,11 @@ static int bcs_update_impl(dpe_bcs *h, const int16_t *samples_dev, int64_t windo
     // block bcs_prep_kernel has just derived -- <= 3 KB and one stream wait per window, against a 4-5 x slower stage 1;
     // at lower rates nothing is fetched and nothing the host decides depends on the values.
     bool chip = h->chipOK && h->chipAllowed;
+    if (dev && (h->devHint & 1) && __atomic_load_n(h->hintViol_h, __ATOMIC_RELAXED)) {
+        // a device-side check found the promise broken in an earlier window (flagged there: status bit 3): the hint is withdrawn for the
+        // life of the handle -- from here on the call reads the derived block back and chooses the kernel from the real values
+        h->devHint &= ~1;
+    }
     if (chip && dev && (h->devHint & 1)) {
         // the caller's promise (dpe_bcs_set_dev_hint): decide from nominal values -- code frequency F_CA within 1e-5 (ten times the
         // largest code Doppler), carrier offset inside the closed-form DC term's range -- and let bcs_prep_kernel check what was
@@ -1879,10 +1890,11 @@ int dpe_bcs_update_dev(dpe_bcs *h, const int16_t *samples_dev, int32_t nChan, co
                 ports->cpElapsedStart && ports->cpReference && ports->validPRNs, "[BatchCorrScores] Update: a device port pointer is null");
     const BcsPortsDev p = {ports->codePhaseStart, ports->carrierPhaseStart, ports->codeFrequency, ports->carrierFrequency,
                            ports->cpElapsedStart, ports->cpReference, ports->validPRNs};
+    if ((h->devHint & 1) && __atomic_load_n(h->hintViol_h, __ATOMIC_RELAXED)) h->devHint &= ~1;   // a broken promise withdraws the hint (see bcs_update_impl)
     const bool hinted = (h->devHint & 1) && h->chipOK && h->chipAllowed;
     const double nomStep = kFCA / h->cfg.samplingFrequency;
     hipLaunchKernelGGL(bcs_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, h->cfg.samplingFrequency,
-                       h->cfg.samplesPerWindow, h->chan_d, h->status_d, hinted ? (int)(1.0 / nomStep) : 0, nomStep * (1.0 + 1e-5));
+                       h->cfg.samplesPerWindow, h->chan_d, h->status_d, hinted ? (int)(1.0 / nomStep) : 0, nomStep * (1.0 + 1e-5), h->hintViol_hd);
     return bcs_update_impl(h, samples_dev, h->cfg.samplesPerWindow, 1, nChan, nullptr, stream);
 }
 
@@ -1927,6 +1939,11 @@ int dpe_bcs_hook_get(dpe_bcs *h, dpe_bcs_hook *out)
     out->fs = h->cfg.samplingFrequency;
     out->S = h->cfg.samplesPerWindow;
     out->maxChannels = h->cfg.maxChannels;
+    const bool hinted = (h->devHint & 1) && h->chipOK && h->chipAllowed && !__atomic_load_n(h->hintViol_h, __ATOMIC_RELAXED);
+    const double nomStep = dpe::kFCA / h->cfg.samplingFrequency;
+    out->hintL1 = hinted ? (int)(1.0 / nomStep) : 0;
+    out->hintStepMax = nomStep * (1.0 + 1e-5);
+    out->hintViol = h->hintViol_hd;
     return 0;
 }
 

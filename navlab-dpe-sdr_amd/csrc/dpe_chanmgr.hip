@@ -187,7 +187,11 @@ static int chm_dev_args(dpe_chm_dev *h, int mode, int meas, const double *xk1k1,
         a.stage = h->stage_d;
         a.ekf = h->ekf_d;
     }
-    if (h->bcs) { a.bcsChan = h->hb.chan_d; a.bcsStatus = h->hb.status_d; a.fs = h->hb.fs; a.S = h->hb.S; }
+    if (h->bcs) {
+        if (dpe_bcs_hook_get(h->bcs, &h->hb)) return -1;   // (the hint may have been set, or withdrawn, since the last window)
+        a.bcsChan = h->hb.chan_d; a.bcsStatus = h->hb.status_d; a.fs = h->hb.fs; a.S = h->hb.S;
+        a.hintL1 = h->hb.hintL1; a.hintStepMax = h->hb.hintStepMax; a.hintViol = h->hb.hintViol;
+    }
     if (h->bcm) {
         if (dpe_bcm_hook_get(h->bcm, &h->hm)) return -1;   // (the window frame alternates with the key sets)
         a.svPos = h->hm.svPos_d; a.svVel = h->hm.svVel_d; a.devWin = h->hm.devWin_hd;

@@ -282,6 +282,9 @@ struct ChmKArgs {
     // parameter blocks of the attached handles for the NEXT window (nullptr: not attached)
     BcsChanDev *bcsChan;
     int *bcsStatus;
+    int hintL1;                     // > 0: the attached BatchCorrScores chooses its kernel from nominal values (dpe_bcs_set_dev_hint): check the promise here
+    double hintStepMax;
+    int *hintViol;
     double fs;
     int S;
     BcmSvDev *svPos, *svVel;
@@ -598,13 +601,18 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
     }
     if (k < K && a.bcsChan) {   // the next window starts where this one ended: rcEnd, riEnd, cpElaEnd with the new frequencies
         int bad;
-        a.bcsChan[k] = bcs_prep_one(c.rcEnd, c.riEnd, c.fc, c.fi, c.cpElaEnd, c.cpRef, c.prn, a.fs, a.S, bad);
+        const BcsChanDev d = bcs_prep_one(c.rcEnd, c.riEnd, c.fc, c.fi, c.cpElaEnd, c.cpRef, c.prn, a.fs, a.S, bad);
+        a.bcsChan[k] = d;
+        if (a.hintL1 > 0 && hint_broken(d, a.hintL1, a.hintStepMax)) {   // (the prepared form launches no prep kernel: the promise is checked here)
+            bad |= 8;
+            __hip_atomic_store(a.hintViol, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (bad) atomicOr(&sFlags, bad << 3);
     }
     __syncthreads();
     if (k == 0) {
         if (sFlags) st->status |= sFlags;
-        if (a.bcsStatus) *a.bcsStatus = (sFlags >> 3) & 3;
+        if (a.bcsStatus) *a.bcsStatus = (sFlags >> 3) & 11;   // BatchCorrScores' input flags: bits 0, 1 and 3 (bit 2 is the batch kernels' own)
     }
 }
 

@@ -131,7 +131,19 @@ struct dpe_bcs_hook {
     int *status_d;
     double fs;
     int S, maxChannels;
+    // dpe_bcs_set_dev_hint in force (hintL1 > 0): whoever writes the parameter block checks the promise (hint_broken below), flags it
+    // in the status word (bit 3) and raises *hintViol (pinned, device address): the handle drops the hint at its next call
+    int hintL1;
+    double hintStepMax;
+    int *hintViol;
 };
+// the conditions behind DPE_DEV_HINT_CHIP for one channel: chips of hintL1 or hintL1 + 1 samples, code step within the assumed bound,
+// carrier offset inside the chip kernels' closed-form DC term, nav-bit boundary on a chip boundary of the replica
+__host__ __device__ inline bool hint_broken(const dpe::BcsChanDev &d, int hintL1, double hintStepMax)
+{
+    const bool offBoundary = d.hasFlip && (int)fma((double)d.idxNext, d.codeStep, d.rc) == (int)fma((double)(d.idxNext - 1), d.codeStep, d.rc);
+    return (int)d.invStep != hintL1 || d.codeStep > hintStepMax || 6.283185307179586 * fabs(d.fi) > 0.25 * d.fc || offBoundary;
+}
 int dpe_bcs_hook_get(dpe_bcs *h, dpe_bcs_hook *out);
 // The device-resident channel manager's time update (chm_k2, dpe_chm_dev.h) as a task for this handle's next stage-1 launch:
 // `args` = a dpe::ChmKArgs; the launch carries it as an extra block when its kernel form can (single-window bcs_bank_kernel),

@@ -213,8 +213,17 @@ def test_device_ports_at_a_high_sampling_rate_take_the_chip_kernel():
             bad["carrierFrequency"] = dv(np.asarray(s["fi"]) + 60e3, np.float64)
             bcs.UpdateDev(d, K, bad)
             assert bcs.dev_status() == 8
+            # ... and withdraws the hint: from the next call on the handle reads the derived block back again and chooses from the real
+            # values -- the same out-of-promise input now takes a per-sample kernel, unflagged, and its banks are the oracle's
+            bcs.UpdateDev(d, K, bad)
+            assert bcs.dev_status() == 0 and bcs.stage1_kernel not in ("bcs_bank_chip2_kernel", "bcs_bank_chip_kernel")
+            codeb, carrb = bcs.read_banks()
+            for k in range(K):
+                c, f, _ = o.bcs_sv(case["wins"][0]["iq"], fs, int(s["prn"][k]), s["rc"][k], s["ri"][k], s["fc"][k], s["fi"][k] + 60e3,
+                                   int(s["cp"][k]), int(s["cp_ref"][k]), -L, L, -B, B, case["C"])
+                assert np.abs(codeb[0][k] - c).max() < TOL * np.abs(c).max() and np.abs(carrb[0][k] - f).max() < TOL * np.abs(f).max()
             bcs.UpdateDev(d, K, ports)
-            assert bcs.dev_status() == 0
+            assert bcs.dev_status() == 0 and bcs.stage1_kernel == "bcs_bank_chip2_kernel"      # (chosen from the values read back)
         bcs.Stop()
     assert out["host"][2] == out["dev"][2] == out["hint"][2] == "bcs_bank_chip2_kernel"
     for a, b in zip(out["hint"][0], out["dev"][0]):       # nominal tile length: the banks of the two device forms agree to rounding

@@ -1099,3 +1099,53 @@ def test_reference_pair_mode_reproduces_the_double_counting_branch(S, W):
     a, b = helpers.run_gpu(case2, 4, 20, reference_pair=True), helpers.run_gpu(case2, 4, 20)
     for w in range(2):
         assert np.array_equal(a["pos"][w], b["pos"][w]) and a["res"][w]["posIndex"] == b["res"][w]["posIndex"]
+
+
+def test_reference_pair_mode_with_the_device_ports(oracle):
+    """referencePair through dpe_bcm_update_dev: candidates, the reference's fp64 expression (batchcorrmanifold.cu:1760-1816) from the
+    port arrays, the patch and the re-derived arg-max all on the device, nothing read back -- the scores of the host form of the
+    mode (which the test above holds against the faithful oracle), the same arg-max and fix; S / 2 = 4096."""
+    import torch
+    S, K, L, B = 8192, 6, 4, 12
+    case = helpers.make_case(seed=1, S=S, K=K, G=625, amp=200.0, W=3, grid="uniform")
+    ref = helpers.run_oracle(case, L, B)
+    fs = case["fs"]
+    iq, cs, ce, bw = helpers.pack_gpu_inputs(case)
+    dev = torch.device("cuda:0")
+    tg = np.zeros(1)
+    checked = 0
+    for w in range(3):
+        q = ref["pos_quirk"][w]
+        win = case["wins"][w]
+        out = {}
+        for form in ("host", "dev"):
+            bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=1, max_channels=K)
+            bcs.Start()
+            bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, case["pos"], case["vel"], lag_half_width=L, bin_half_width=B, max_channels=K,
+                                        weighted_mean=False, reference_pair=True)
+            bcm.Start()
+            bcs.Update(torch.from_numpy(iq[w]).to(dev), cs[w:w + 1])
+            if form == "host":
+                bcm.Update(bcs.CodeScores, bcs.CarrScores, bw[w:w + 1], ce[w:w + 1])
+            else:
+                def d(a, dt):
+                    return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dt)).to(dev)
+                keep = dict(x=d(win["centre"], np.float64), R=d(np.asarray(win["R"]).ravel(), np.float64), sat=d(win["sat"][:, None, :], np.float64),
+                            rcE=d(win["rcEnd"], np.float64), fc=d(win["fc"], np.float64), fi=d(win["fi"], np.float64),
+                            tow=d(win["cpRefTOW"], np.int32), elaE=d(win["cpElaEnd"], np.int32), ref=d(win["cpRef"], np.int32), ds=d([1], np.int32))
+                bcm.UpdateDev(bcs.CodeScores, bcs.CarrScores, K,
+                              dict(xCurrkk1=keep["x"], enu2ecef=keep["R"], satStates=keep["sat"], codePhaseEnd=keep["rcE"], codeFrequency=keep["fc"],
+                                   carrierFrequency=keep["fi"], cpRefTOW=keep["tow"], cpElapsedEnd=keep["elaE"], cpRef=keep["ref"], dopplerSign=keep["ds"]),
+                              1, float(win["rxTime"]))
+            r = bcm.results()[0]
+            ps, _ = bcm.read_scores()
+            out[form] = (r, ps[0].copy())
+            bcm.Stop(); bcs.Stop()
+        (rh, ph), (rd, pd) = out["host"], out["dev"]
+        assert np.abs(pd - ph).max() < 2e-6 * ph.max()
+        assert rd["posIndex"] == rh["posIndex"] == ref["res"][w]["posIndex"] and rd["posScore"] == pd.max()
+        assert np.abs(rd["zVal"] - rh["zVal"]).max() < 1e-9
+        if len(q):
+            assert np.abs(pd[q] - ref["pos"][w][q]).max() < 5e-6 * ref["pos"][w].max()     # the patched points follow the reference's expression
+            checked += 1
+    assert checked, "the case must exercise the branch"
