@@ -516,7 +516,9 @@ int dpe_bcs_profile(dpe_bcs *h, int32_t enable, float *ms, int32_t *count);
 const char *dpe_bcs_stage1_kernel(dpe_bcs *h);
 int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count);
 
-/* Closed-loop latency: with enable != 0 an Update whose shape and device pointers repeat (the per-window
+/* Graph replay (an option, NOT the low-latency path on this ROCm: measured on MI355X / ROCm 7.2 a replayed single-window step
+ * takes 78 us against 48 us for the eager launches, profiles/r4_closed_loop_device.txt -- hipGraphLaunch costs more than the 2 + 1
+ * launches it replaces; leave it off unless a later runtime changes that).  With enable != 0 an Update whose shape and device pointers repeat (the per-window
  * call of a running receiver, one entry per SampleBlock ring slot) is captured once as a hipGraph and
  * replayed with a single launch afterwards; the pinned parameter blocks are re-read on every replay, so
  * results are identical to the eager path.  Needs a created stream (not the null stream, which cannot be
