@@ -194,14 +194,25 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
                                                               const float2 *__restrict__ tw, int B, int nSeg, int binsPerBlock, int pOffset,
                                                               float *__restrict__ surf, unsigned int *__restrict__ mpBits,
                                                               const float2 *__restrict__ tw25k = nullptr, float2 *__restrict__ r10Scratch = nullptr,
-                                                              unsigned int *__restrict__ r10Busy = nullptr, int r10Slots = 0)
+                                                              unsigned int *__restrict__ r10Busy = nullptr, int r10Slots = 0, int xcdMap = 0)
 {
     static_assert(ALIAS || !R10, "the in-block radix-10 stage belongs to the 25 000-point form");
     constexpr int N = kAcqFusedLen, SS = kAcqSubStride;
     __shared__ float2 sA[10 * SS], sB[10 * SS];
     __shared__ float2 sW250[256], sW25[32];   // W250^n = tw[10 n], W25^n = tw[100 n]: the twiddles of passes 2 and 3
     __shared__ int sSlot;
-    const int t = threadIdx.x, p = blockIdx.y;
+    const int t = threadIdx.x;
+    int p = blockIdx.y, bx = blockIdx.x;
+    if constexpr (R10) {
+        // XCD-aware (PRN, bin) order: the block's linear id mod 8 is its XCD.  XCD x takes the PRNs p = x (mod 8) and walks the bins with them
+        // together, so that a PRN's spectrum stays in that XCD's L2 for the whole launch and a bin's spectrum is fetched once per XCD
+        // instead of once per block (400 KB per block through the fabric otherwise: 1.6 GB per 32 x 125 search).
+        if (xcdMap) {
+            const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, x = L & 7u, s = L >> 3, ppx = gridDim.y >> 3;
+            p = (int)(x + 8u * (s % ppx));
+            bx = (int)(s / ppx);
+        }
+    }
     const bool act = t < 250;
     const int tt = act ? t : 0;
     if constexpr (R10) {
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     float mx[10], macc[2][5];
 #pragma unroll
     for (int q = 0; q < 10; ++q) mx[q] = 0.f;
-    const int b0 = blockIdx.x * binsPerBlock;
+    const int b0 = bx * binsPerBlock;
     const int nb = (B - b0) < binsPerBlock ? (B - b0) : binsPerBlock;
     const int nTr = nb * nSeg;   // transforms of this block: rows b0 nSeg .. of X (ALIAS: of this PRN's Z), consecutive
     const float2 *x0 = X + ((ALIAS ? (size_t)p * B : (size_t)0) + (size_t)b0) * nSeg * N;
@@ -1083,7 +1094,8 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         const int pc = std::min(h->chunk, P - p0);
         if (h->fusedAlias && h->r10InBlock) {
             hipLaunchKernelGGL((acq_corr2500_kernel<true, true>), dim3(B, pc), dim3(256), 0, st, h->X_d, h->Rc_d + (size_t)p0 * h->len, h->tw_d, B, h->N, 1, p0,
-                               h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), h->tw25k_d, h->Y_d, h->r10Busy_d, h->r10Slots);
+                               h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), h->tw25k_d, h->Y_d, h->r10Busy_d, h->r10Slots,
+                               (pc % 8 == 0 && (size_t)pc * B % 8 == 0 && !(getenv("DPE_ACQ_NO_XCD_MAP") && atoi(getenv("DPE_ACQ_NO_XCD_MAP")))) ? 1 : 0);
             continue;
         }
         if (h->fusedAlias) {
