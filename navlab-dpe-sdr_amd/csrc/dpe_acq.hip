@@ -173,6 +173,9 @@ __device__ __forceinline__ void acq_idft10(af2 (&v)[10])
     v[0] = e0; v[6] = e1; v[2] = e2; v[8] = e3; v[4] = e4;
     v[5] = o0; v[1] = o1; v[7] = o2; v[3] = o3; v[9] = o4;
 }
+}  // namespace dpe
+#include "dpe_acq_wave.h"
+namespace dpe {
 constexpr int kAcqFusedLen = 2500;
 constexpr int kAcqFusedBins = 6;     // bins per block: 21 x 32 blocks are resident at once (three per CU) on 256 CUs
 constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequences: = 25 (mod 32), so that the 25-lane groups of
@@ -919,6 +922,9 @@ struct dpe_acq {
     float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused searches (acq_corr2500_kernel), else null
     float2 *tw25k_d = nullptr;  // exp(+j 2 pi n / 25000): the radix-10 stage of the fused non-coherent search
     bool fused = false, fusedAlias = false;
+    int cus = 256;              // compute units of the device (the wave form launches one persistent block per CU)
+    bool waveForm = false;      // fusedAlias through acq_corr25k_wave_kernel (dpe_acq_wave.h); DPE_ACQ_NO_WAVE=1 keeps the radix-10 + four-pass form
+    float2 *Rcq_d = nullptr, *tw2_d = nullptr;   // wave form: the replicas' spectra decimated by ten, W2500^(a c) as [c][a]
     bool fusedFwd = true;   // fused modes: wipe-off and forward transform in one kernel (DPE_ACQ_NO_FUSED_FWD=1: wipe kernel + rocFFT, A/B runs)
     dpe::AcqStats *stats_hd = nullptr, *stats_h = nullptr;  // per-PRN peak statistics: pinned host memory the statistics kernel writes itself (_hd: its device address)
     bool searched = false;
@@ -941,7 +947,7 @@ int dpe_acq_destroy(dpe_acq *h)
     h->planFwd.destroy();
     h->planInv.destroy();
     h->planFine.destroy();
-    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->r10Busy_d};
+    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->r10Busy_d, h->Rcq_d, h->tw2_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->stats_h) (void)hipHostFree(h->stats_h);
     delete h;
@@ -977,7 +983,8 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     const bool wantAlias = cfg->mode == 1 && h->M == kAcqFusedLen && h->N == 10 && !getenv("DPE_ACQ_NO_FUSED");
     h->X_d = dev_alloc<float2>(B * S);
     h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
-    h->Y_d = dev_alloc<float2>(wantFused ? 1 : (size_t)h->chunk * B * S);
+    const bool wantWave = wantAlias && !(getenv("DPE_ACQ_NO_WAVE") && atoi(getenv("DPE_ACQ_NO_WAVE")) != 0);
+    h->Y_d = dev_alloc<float2>(wantFused ? 1 : wantWave ? B * S : (size_t)h->chunk * B * S);   // (wave form: the bins' decimated spectra)
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
     h->peakIdx_d = dev_alloc<int>(2 * P);
@@ -1045,6 +1052,28 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             }
         }
     }
+    if (!rc && h->fusedAlias && wantWave) {
+        std::vector<float2> t2(2500);
+        for (int c = 0; c < 50; ++c)
+            for (int a = 0; a < 50; ++a) {
+                const double ang = 6.283185307179586476925286766559 * (double)(a * c) / 2500.0;
+                t2[c * 50 + a] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+            }
+        h->tw2_d = dev_alloc<float2>(t2.size());
+        h->Rcq_d = dev_alloc<float2>(P * (size_t)h->len);
+        if (!h->tw2_d || !h->Rcq_d || hipMemcpy(h->tw2_d, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess) {
+            set_error("[Acquisition] create: wave-form tables");
+            rc = -1;
+        } else {
+            hipLaunchKernelGGL(acq_decimate10_kernel, dim3(40, (unsigned)P), dim3(640), 0, 0, h->Rc_d, h->Rcq_d);
+            if (hipDeviceSynchronize() != hipSuccess) { set_error("[Acquisition] create: decimating the replica spectra"); rc = -1; }
+            else { h->waveForm = true; h->r10InBlock = false; }
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) h->cus = prop.multiProcessorCount / 8 * 8;
+        }
+    }
     h->fusedFwd = !(getenv("DPE_ACQ_NO_FUSED_FWD") && atoi(getenv("DPE_ACQ_NO_FUSED_FWD")) != 0);
     if (!rc && (wantFused || wantAlias)) {
         std::vector<float2> tw(kAcqFusedLen);
@@ -1092,6 +1121,13 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                            B, h->cfg.mode == 0 ? 1 : h->N, kAcqFusedBins, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
+        if (h->waveForm) {
+            if (p0 == 0) hipLaunchKernelGGL(acq_decimate10_kernel, dim3(40, (unsigned)B), dim3(640), 0, st, h->X_d, h->Y_d);
+            const int items = pc * B, nBlk = std::min(h->cus, pc % 8 == 0 ? (items + 7) / 8 * 8 : items);
+            hipLaunchKernelGGL(acq_corr25k_wave_kernel, dim3(nBlk), dim3(640), kWvLdsBytes, st, h->Y_d, h->Rcq_d + (size_t)p0 * h->len, h->tw2_d, h->tw25k_d,
+                               B, pc, p0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (pc % 8 == 0 && nBlk % 8 == 0) ? 1 : 0);
+            continue;
+        }
         if (h->fusedAlias && h->r10InBlock) {
             hipLaunchKernelGGL((acq_corr2500_kernel<true, true>), dim3(B, pc), dim3(256), 0, st, h->X_d, h->Rc_d + (size_t)p0 * h->len, h->tw_d, B, h->N, 1, p0,
                                h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), h->tw25k_d, h->Y_d, h->r10Busy_d, h->r10Slots,
