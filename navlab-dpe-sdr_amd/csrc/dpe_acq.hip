@@ -922,6 +922,8 @@ struct dpe_acq {
     float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused searches (acq_corr2500_kernel), else null
     float2 *tw25k_d = nullptr;  // exp(+j 2 pi n / 25000): the radix-10 stage of the fused non-coherent search
     bool fused = false, fusedAlias = false;
+    bool fwdPack = true;        // packed form: wipe-off + forward transform in acq_fwd25k_pack_kernel (DPE_ACQ_NO_FWD_PACK=1: wipe kernel + rocFFT + decimation)
+    bool packForm = true;       // wave form with the ten transforms' 500 lanes packed into eight waves (DPE_ACQ_NO_PACK=1: ten waves of 50 lanes)
     int cus = 256;              // compute units of the device (the wave form launches one persistent block per CU)
     bool waveForm = false;      // fusedAlias through acq_corr25k_wave_kernel (dpe_acq_wave.h); DPE_ACQ_NO_WAVE=1 keeps the radix-10 + four-pass form
     float2 *Rcq_d = nullptr, *tw2_d = nullptr;   // wave form: the replicas' spectra decimated by ten, W2500^(a c) as [c][a]
@@ -1062,13 +1064,16 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         h->tw2_d = dev_alloc<float2>(t2.size());
         h->Rcq_d = dev_alloc<float2>(P * (size_t)h->len);
         if (!h->tw2_d || !h->Rcq_d || hipMemcpy(h->tw2_d, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_fwd25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess) {
             set_error("[Acquisition] create: wave-form tables");
             rc = -1;
         } else {
             hipLaunchKernelGGL(acq_decimate10_kernel, dim3(40, (unsigned)P), dim3(640), 0, 0, h->Rc_d, h->Rcq_d);
             if (hipDeviceSynchronize() != hipSuccess) { set_error("[Acquisition] create: decimating the replica spectra"); rc = -1; }
-            else { h->waveForm = true; h->r10InBlock = false; }
+            else { h->waveForm = true; h->r10InBlock = false; h->packForm = !(getenv("DPE_ACQ_NO_PACK") && atoi(getenv("DPE_ACQ_NO_PACK")) != 0);
+                   h->fwdPack = h->packForm && !(getenv("DPE_ACQ_NO_FWD_PACK") && atoi(getenv("DPE_ACQ_NO_FWD_PACK")) != 0); }
             int dev = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) h->cus = prop.multiProcessorCount / 8 * 8;
@@ -1101,7 +1106,10 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     DPE_REQUIRE(h && samples_dev, "[Acquisition] search: null argument");
     hipStream_t st = (hipStream_t)stream_;
     const int S = h->SX, B = h->B, P = h->P, M = h->M;
-    if (h->fused && h->fusedFwd && h->cfg.mode != 0) {
+    if (h->waveForm && h->fwdPack) {
+        hipLaunchKernelGGL(acq_fwd25k_pack_kernel, dim3(B), dim3(512), kWvLdsBytes, st, samples_dev, h->cfg.binStartHz, h->cfg.binStepHz,
+                           1.0 / h->cfg.samplingFrequency, h->tw2_d, h->tw25k_d, h->Y_d, h->mp_d, (long long)P * M);
+    } else if (h->fused && h->fusedFwd && h->cfg.mode != 0) {
         // textbook mode (N rows of 2 500 per bin): wipe-off and the forward transform in one launch, 0.271 -> 0.260 ms per 32-PRN window.
         // (Coherent mode keeps the two launches: one block per bin would have to fold ten periods -- a hundred sin / cos pairs per
         // thread on 125 blocks -- and measured 0.066 against 0.060 ms.)
@@ -1122,10 +1130,14 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
         if (h->waveForm) {
-            if (p0 == 0) hipLaunchKernelGGL(acq_decimate10_kernel, dim3(40, (unsigned)B), dim3(640), 0, st, h->X_d, h->Y_d);
+            if (p0 == 0 && !h->fwdPack) hipLaunchKernelGGL(acq_decimate10_kernel, dim3(40, (unsigned)B), dim3(640), 0, st, h->X_d, h->Y_d);
             const int items = pc * B, nBlk = std::min(h->cus, pc % 8 == 0 ? (items + 7) / 8 * 8 : items);
-            hipLaunchKernelGGL(acq_corr25k_wave_kernel, dim3(nBlk), dim3(640), kWvLdsBytes, st, h->Y_d, h->Rcq_d + (size_t)p0 * h->len, h->tw2_d, h->tw25k_d,
-                               B, pc, p0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (pc % 8 == 0 && nBlk % 8 == 0) ? 1 : 0);
+            if (h->packForm)
+                hipLaunchKernelGGL(acq_corr25k_pack_kernel, dim3(nBlk), dim3(512), kWvLdsBytes, st, h->Y_d, h->Rcq_d + (size_t)p0 * h->len, h->tw2_d, h->tw25k_d,
+                                   B, pc, p0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (pc % 8 == 0 && nBlk % 8 == 0) ? 1 : 0);
+            else
+                hipLaunchKernelGGL(acq_corr25k_wave_kernel, dim3(nBlk), dim3(640), kWvLdsBytes, st, h->Y_d, h->Rcq_d + (size_t)p0 * h->len, h->tw2_d, h->tw25k_d,
+                                   B, pc, p0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (pc % 8 == 0 && nBlk % 8 == 0) ? 1 : 0);
             continue;
         }
         if (h->fusedAlias && h->r10InBlock) {
