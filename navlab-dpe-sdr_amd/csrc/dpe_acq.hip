@@ -174,7 +174,7 @@ __device__ __forceinline__ void acq_idft10(af2 (&v)[10])
     v[5] = o0; v[1] = o1; v[7] = o2; v[3] = o3; v[9] = o4;
 }
 }  // namespace dpe
-#include "dpe_acq_wave.h"
+#include "dpe_acq_pack.h"
 namespace dpe {
 constexpr int kAcqFusedLen = 2500;
 constexpr int kAcqFusedBins = 6;     // bins per block: 21 x 32 blocks are resident at once (three per CU) on 256 CUs
@@ -188,46 +188,17 @@ constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequ
 // decimation-in-frequency stage already applied -- so y[10 m' + k0] = IFFT2500(Z[..][k0])[m'] and the ten lag aliases of delay
 // j = 10 r + k0 are the outputs r + 250 n of transform k0: exactly the ten values thread r holds.  nSeg = 10 transforms per
 // (PRN, bin), no multiply, each transform's ten-fold sums written at stride 10.
-// R10 (with ALIAS): the radix-10 stage of acq_radix10_kernel runs INSIDE this block -- spectrum product, 10-point butterflies and twiddles for
-// the block's (PRN, bin), written to a scratch slot of 25 000 complex values that the block then transforms from.  The slots are a small pool
-// (r10Slots x 200 KB, claimed with a compare-and-swap, released at the end) that is rewritten all the time: it lives in L2 / the Infinity Cache
-// instead of travelling to HBM and back as the 800 MB of Z of a 32 x 125 search did (X = the bins' spectra, Rc = the PRNs' spectra here).
-template <bool ALIAS, bool R10 = false>
+template <bool ALIAS>
 __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc,
                                                               const float2 *__restrict__ tw, int B, int nSeg, int binsPerBlock, int pOffset,
-                                                              float *__restrict__ surf, unsigned int *__restrict__ mpBits,
-                                                              const float2 *__restrict__ tw25k = nullptr, float2 *__restrict__ r10Scratch = nullptr,
-                                                              unsigned int *__restrict__ r10Busy = nullptr, int r10Slots = 0, int xcdMap = 0)
+                                                              float *__restrict__ surf, unsigned int *__restrict__ mpBits)
 {
-    static_assert(ALIAS || !R10, "the in-block radix-10 stage belongs to the 25 000-point form");
     constexpr int N = kAcqFusedLen, SS = kAcqSubStride;
     __shared__ float2 sA[10 * SS], sB[10 * SS];
     __shared__ float2 sW250[256], sW25[32];   // W250^n = tw[10 n], W25^n = tw[100 n]: the twiddles of passes 2 and 3
-    __shared__ int sSlot;
-    const int t = threadIdx.x;
-    int p = blockIdx.y, bx = blockIdx.x;
-    if constexpr (R10) {
-        // XCD-aware (PRN, bin) order: the block's linear id mod 8 is its XCD.  XCD x takes the PRNs p = x (mod 8) and walks the bins with them
-        // together, so that a PRN's spectrum stays in that XCD's L2 for the whole launch and a bin's spectrum is fetched once per XCD
-        // instead of once per block (400 KB per block through the fabric otherwise: 1.6 GB per 32 x 125 search).
-        if (xcdMap) {
-            const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, x = L & 7u, s = L >> 3, ppx = gridDim.y >> 3;
-            p = (int)(x + 8u * (s % ppx));
-            bx = (int)(s / ppx);
-        }
-    }
+    const int t = threadIdx.x, p = blockIdx.y, bx = blockIdx.x;
     const bool act = t < 250;
     const int tt = act ? t : 0;
-    if constexpr (R10) {
-        if (t == 0) {   // a free scratch slot: there are more slots than blocks resident at once, so the search ends
-            // A slot stays with ONE XCD: the block's linear id mod 8 is its XCD, the slot count is a multiple of 8 and the probe steps
-            // by 8.  The per-XCD L2s are write-back and not coherent with each other inside a kernel -- a slot handed from one XCD to
-            // another could be hit by a late write-back of its previous owner's lines after the new owner's were evicted.
-            int sl = (int)((blockIdx.y * gridDim.x + blockIdx.x) % (unsigned)r10Slots);
-            while (atomicCAS(&r10Busy[sl], 0u, 1u) != 0u) sl = sl + 8 >= r10Slots ? (sl & 7) : sl + 8;
-            sSlot = sl;
-        }
-    }
     if (act) sW250[t] = tw[10 * t];
     if (t < 25) sW25[t] = tw[100 * t];
     // the PRN's spectrum and the pass-1 twiddles W^(t k1) of this thread's ten elements stay in registers across the bins
@@ -249,40 +220,6 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     const int nb = (B - b0) < binsPerBlock ? (B - b0) : binsPerBlock;
     const int nTr = nb * nSeg;   // transforms of this block: rows b0 nSeg .. of X (ALIAS: of this PRN's Z), consecutive
     const float2 *x0 = X + ((ALIAS ? (size_t)p * B : (size_t)0) + (size_t)b0) * nSeg * N;
-    if constexpr (R10) {
-        __syncthreads();
-        float2 *z = r10Scratch + (size_t)sSlot * (10 * N);
-        if (act) {
-            const float2 *xb = X + (size_t)b0 * (10 * N), *rp = Rc + (size_t)p * (10 * N);
-            // the block's 2 500 values of m, ten per thread: Z[k0][m] = W^(m k0) sum_q P[m + 2500 q] W10^(q k0).  The next m's twenty
-            // spectrum values are fetched under this m's butterfly (rolled loop: one m at a time the phase was ten memory latencies long)
-            float2 na[10], nc[10];
-#pragma unroll
-            for (int q = 0; q < 10; ++q) { na[q] = xb[t + N * q]; nc[q] = rp[t + N * q]; }
-#pragma unroll 1
-            for (int j = 0; j < 10; ++j) {
-                const int m = t + 250 * j;
-                af2 v[10];
-                float2 w[10];
-#pragma unroll
-                for (int k0 = 1; k0 < 10; ++k0) w[k0] = tw25k[m * k0];
-#pragma unroll
-                for (int q = 0; q < 10; ++q) v[q] = acq_cmul(af2{na[q].x, na[q].y}, af2{nc[q].x, nc[q].y});
-                if (j < 9) {
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) { na[q] = xb[m + 250 + N * q]; nc[q] = rp[m + 250 + N * q]; }
-                }
-                acq_idft10(v);
-#pragma unroll
-                for (int k0 = 0; k0 < 10; ++k0) {
-                    const af2 y = k0 ? acq_cmul(v[k0], af2{w[k0].x, w[k0].y}) : v[k0];
-                    z[(size_t)k0 * N + m] = make_float2(y.x, y.y);
-                }
-            }
-        }
-        __syncthreads();   // (the block's own stores, written through to L2: visible to all of its waves behind the barrier)
-        x0 = z;
-    }
     float2 xn[10];   // the next transform's spectrum, fetched under this one
 #pragma unroll
     for (int q = 0; q < 10; ++q) xn[q] = x0[tt + 250 * q];
@@ -395,10 +332,6 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     if (!ALIAS && act) {
 #pragma unroll
         for (int q = 0; q < 10; ++q) atomicMax(&mpBits[(size_t)p * N + t + 250 * q], __float_as_uint(mx[q]));
-    }
-    if constexpr (R10) {
-        __syncthreads();
-        if (t == 0) atomicExch(&r10Busy[sSlot], 0u);
     }
 }
 
@@ -914,19 +847,15 @@ struct dpe_acq {
     int SX;                          // samples per Doppler row after the wipe-off (M in mode 0: time-folded)
     dpe::FftPlan planFwd, planInv;
     float2 *X_d = nullptr, *Rc_d = nullptr, *Y_d = nullptr;
-    unsigned int *r10Busy_d = nullptr;   // claim words of the scratch slots of the in-block radix-10 stage
-    int r10Slots = 0;
-    bool r10InBlock = true;              // DPE_ACQ_NO_R10_INBLOCK=1: acq_radix10_kernel + Z through memory, as before (A/B runs)
     float *surf_d = nullptr, *mp_d = nullptr;
     int *peakIdx_d = nullptr;   // [2][P]: max_code_idx, max_dopp_idx
     float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused searches (acq_corr2500_kernel), else null
     float2 *tw25k_d = nullptr;  // exp(+j 2 pi n / 25000): the radix-10 stage of the fused non-coherent search
     bool fused = false, fusedAlias = false;
     bool fwdPack = true;        // packed form: wipe-off + forward transform in acq_fwd25k_pack_kernel (DPE_ACQ_NO_FWD_PACK=1: wipe kernel + rocFFT + decimation)
-    bool packForm = true;       // wave form with the ten transforms' 500 lanes packed into eight waves (DPE_ACQ_NO_PACK=1: ten waves of 50 lanes)
-    int cus = 256;              // compute units of the device (the wave form launches one persistent block per CU)
-    bool waveForm = false;      // fusedAlias through acq_corr25k_wave_kernel (dpe_acq_wave.h); DPE_ACQ_NO_WAVE=1 keeps the radix-10 + four-pass form
-    float2 *Rcq_d = nullptr, *tw2_d = nullptr;   // wave form: the replicas' spectra decimated by ten, W2500^(a c) as [c][a]
+    int cus = 256;              // compute units of the device (the packed form launches one persistent block per CU)
+    bool packForm = false;      // fusedAlias through acq_corr25k_pack_kernel (dpe_acq_pack.h); DPE_ACQ_NO_PACK=1 keeps acq_radix10_kernel + the four-pass transform (A/B runs)
+    float2 *Rcq_d = nullptr, *tw2_d = nullptr;   // packed form: the replicas' spectra decimated by ten, W2500^(a c) as [c][a]
     bool fusedFwd = true;   // fused modes: wipe-off and forward transform in one kernel (DPE_ACQ_NO_FUSED_FWD=1: wipe kernel + rocFFT, A/B runs)
     dpe::AcqStats *stats_hd = nullptr, *stats_h = nullptr;  // per-PRN peak statistics: pinned host memory the statistics kernel writes itself (_hd: its device address)
     bool searched = false;
@@ -949,7 +878,7 @@ int dpe_acq_destroy(dpe_acq *h)
     h->planFwd.destroy();
     h->planInv.destroy();
     h->planFine.destroy();
-    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->r10Busy_d, h->Rcq_d, h->tw2_d};
+    void *bufs[] = {h->tw25k_d, h->tw_d, h->X_d, h->Rc_d, h->Y_d, h->surf_d, h->mp_d, h->peakIdx_d, h->F_d, h->fineVal_d, h->fineIdx_d, h->fineSums_d, h->fineChan_d, h->chips_d, h->Rcq_d, h->tw2_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->stats_h) (void)hipHostFree(h->stats_h);
     delete h;
@@ -985,8 +914,8 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     const bool wantAlias = cfg->mode == 1 && h->M == kAcqFusedLen && h->N == 10 && !getenv("DPE_ACQ_NO_FUSED");
     h->X_d = dev_alloc<float2>(B * S);
     h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
-    const bool wantWave = wantAlias && !(getenv("DPE_ACQ_NO_WAVE") && atoi(getenv("DPE_ACQ_NO_WAVE")) != 0);
-    h->Y_d = dev_alloc<float2>(wantFused ? 1 : wantWave ? B * S : (size_t)h->chunk * B * S);   // (wave form: the bins' decimated spectra)
+    const bool wantPack = wantAlias && !(getenv("DPE_ACQ_NO_PACK") && atoi(getenv("DPE_ACQ_NO_PACK")) != 0);
+    h->Y_d = dev_alloc<float2>(wantFused ? 1 : wantPack ? B * S : (size_t)h->chunk * B * S);   // (packed form: the bins' decimated spectra)
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
     h->peakIdx_d = dev_alloc<int>(2 * P);
@@ -1040,21 +969,8 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             set_error("[Acquisition] create: twiddle table");
             rc = -1;
         } else h->fusedAlias = true;
-        if (h->fusedAlias) {
-            h->r10InBlock = !(getenv("DPE_ACQ_NO_R10_INBLOCK") && atoi(getenv("DPE_ACQ_NO_R10_INBLOCK")) != 0);
-            const long long pairs = (long long)h->chunk * B;        // Y_d holds chunk x B rows of S: the pool is a part of it
-            // a multiple of 8 (one class of slots per XCD): 128 per XCD > the 96 blocks an XCD holds at once (3 per CU); a small search
-            // gets fewer slots than blocks (a block then waits for one of its XCD's to come free), fewer than 8 pairs keep the separate stage
-            h->r10Slots = (int)(pairs < 1024 ? pairs / 8 * 8 : 1024);
-            if (h->r10Slots < 8) { h->r10Slots = 8; h->r10InBlock = false; }
-            h->r10Busy_d = dev_alloc<unsigned int>((size_t)h->r10Slots);
-            if (!h->r10Busy_d || hipMemset(h->r10Busy_d, 0, sizeof(unsigned int) * h->r10Slots) != hipSuccess) {
-                set_error("[Acquisition] create: scratch claim words");
-                rc = -1;
-            }
-        }
     }
-    if (!rc && h->fusedAlias && wantWave) {
+    if (!rc && h->fusedAlias && wantPack) {
         std::vector<float2> t2(2500);
         for (int c = 0; c < 50; ++c)
             for (int a = 0; a < 50; ++a) {
@@ -1064,16 +980,14 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
         h->tw2_d = dev_alloc<float2>(t2.size());
         h->Rcq_d = dev_alloc<float2>(P * (size_t)h->len);
         if (!h->tw2_d || !h->Rcq_d || hipMemcpy(h->tw2_d, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_fwd25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWvLdsBytes) != hipSuccess) {
-            set_error("[Acquisition] create: wave-form tables");
+            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPkLdsBytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_fwd25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPkLdsBytes) != hipSuccess) {
+            set_error("[Acquisition] create: packed-form tables");
             rc = -1;
         } else {
             hipLaunchKernelGGL(acq_decimate10_kernel, dim3(40, (unsigned)P), dim3(640), 0, 0, h->Rc_d, h->Rcq_d);
             if (hipDeviceSynchronize() != hipSuccess) { set_error("[Acquisition] create: decimating the replica spectra"); rc = -1; }
-            else { h->waveForm = true; h->r10InBlock = false; h->packForm = !(getenv("DPE_ACQ_NO_PACK") && atoi(getenv("DPE_ACQ_NO_PACK")) != 0);
-                   h->fwdPack = h->packForm && !(getenv("DPE_ACQ_NO_FWD_PACK") && atoi(getenv("DPE_ACQ_NO_FWD_PACK")) != 0); }
+            else { h->packForm = true; h->fwdPack = !(getenv("DPE_ACQ_NO_FWD_PACK") && atoi(getenv("DPE_ACQ_NO_FWD_PACK")) != 0); }
             int dev = 0;
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) h->cus = prop.multiProcessorCount / 8 * 8;
@@ -1106,8 +1020,8 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     DPE_REQUIRE(h && samples_dev, "[Acquisition] search: null argument");
     hipStream_t st = (hipStream_t)stream_;
     const int S = h->SX, B = h->B, P = h->P, M = h->M;
-    if (h->waveForm && h->fwdPack) {
-        hipLaunchKernelGGL(acq_fwd25k_pack_kernel, dim3(B), dim3(512), kWvLdsBytes, st, samples_dev, h->cfg.binStartHz, h->cfg.binStepHz,
+    if (h->packForm && h->fwdPack) {
+        hipLaunchKernelGGL(acq_fwd25k_pack_kernel, dim3(B), dim3(512), kPkLdsBytes, st, samples_dev, h->cfg.binStartHz, h->cfg.binStepHz,
                            1.0 / h->cfg.samplingFrequency, h->tw2_d, h->tw25k_d, h->Y_d, h->mp_d, (long long)P * M);
     } else if (h->fused && h->fusedFwd && h->cfg.mode != 0) {
         // textbook mode (N rows of 2 500 per bin): wipe-off and the forward transform in one launch, 0.271 -> 0.260 ms per 32-PRN window.
@@ -1129,21 +1043,11 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                            B, h->cfg.mode == 0 ? 1 : h->N, kAcqFusedBins, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
-        if (h->waveForm) {
+        if (h->packForm) {
             if (p0 == 0 && !h->fwdPack) hipLaunchKernelGGL(acq_decimate10_kernel, dim3(40, (unsigned)B), dim3(640), 0, st, h->X_d, h->Y_d);
             const int items = pc * B, nBlk = std::min(h->cus, pc % 8 == 0 ? (items + 7) / 8 * 8 : items);
-            if (h->packForm)
-                hipLaunchKernelGGL(acq_corr25k_pack_kernel, dim3(nBlk), dim3(512), kWvLdsBytes, st, h->Y_d, h->Rcq_d + (size_t)p0 * h->len, h->tw2_d, h->tw25k_d,
-                                   B, pc, p0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (pc % 8 == 0 && nBlk % 8 == 0) ? 1 : 0);
-            else
-                hipLaunchKernelGGL(acq_corr25k_wave_kernel, dim3(nBlk), dim3(640), kWvLdsBytes, st, h->Y_d, h->Rcq_d + (size_t)p0 * h->len, h->tw2_d, h->tw25k_d,
-                                   B, pc, p0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (pc % 8 == 0 && nBlk % 8 == 0) ? 1 : 0);
-            continue;
-        }
-        if (h->fusedAlias && h->r10InBlock) {
-            hipLaunchKernelGGL((acq_corr2500_kernel<true, true>), dim3(B, pc), dim3(256), 0, st, h->X_d, h->Rc_d + (size_t)p0 * h->len, h->tw_d, B, h->N, 1, p0,
-                               h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), h->tw25k_d, h->Y_d, h->r10Busy_d, h->r10Slots,
-                               (pc % 8 == 0 && (size_t)pc * B % 8 == 0 && !(getenv("DPE_ACQ_NO_XCD_MAP") && atoi(getenv("DPE_ACQ_NO_XCD_MAP")))) ? 1 : 0);
+            hipLaunchKernelGGL(acq_corr25k_pack_kernel, dim3(nBlk), dim3(512), kPkLdsBytes, st, h->Y_d, h->Rcq_d + (size_t)p0 * h->len, h->tw2_d, h->tw25k_d,
+                               B, pc, p0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (pc % 8 == 0 && nBlk % 8 == 0) ? 1 : 0);
             continue;
         }
         if (h->fusedAlias) {

@@ -1,5 +1,6 @@
-// dpe_acq_wave.h -- the reference's non-coherent search (coarse_acquisition(coherent=False), correlator.py:77-82) at 10 x 2 500
-// samples with ONE WAVE PER 2 500-POINT TRANSFORM: included by dpe_acq.hip (namespace dpe, after acq_cmul / acq_idft5 / acq_idft10).
+// dpe_acq_pack.h -- the reference's non-coherent search (coarse_acquisition(coherent=False), correlator.py:77-82) at 10 x 2 500
+// samples: the forward and the inverse 25 000-point transforms as ten PACKED 2 500-point transforms per block.  Included by dpe_acq.hip
+// (namespace dpe, after acq_cmul / acq_idft5 / acq_idft10).
 //
 //   surface[p][b][j] = sum_{n<10} | y[j + 2500 n] |,   y = IFFT_25000( X_b .* Rc_p )            (N = 25 000, M = 2 500)
 //
@@ -8,27 +9,31 @@
 // so a (PRN, bin) is ten independent 2 500-point transforms of the ten residue classes of the product spectrum, a twiddle, and a
 // ten-point transform ACROSS them at every delay j -- whose ten outputs are exactly the ten lag aliases of j, summed in magnitude
 // on the spot.  (The form this replaces decimated in frequency: its radix-10 stage came FIRST and its 200 KB of output per (PRN,
-// bin) had to pass through a scratch slot in L2.  Here nothing but the surface leaves the block.)  The spectra arrive decimated --
-// Xq[b][q][k'] = X_b[10 k' + q] (acq_decimate10_kernel), the replicas' the same at create -- so every load is contiguous.
+// bin) had to pass through memory.  Here nothing but the surface leaves the block.)  The spectra arrive decimated --
+// Xq[b][q][k'] = X_b[10 k' + q], written in that order by acq_fwd25k_pack_kernel; the replicas' the same at create -- so every load is
+// contiguous.
 //
-// One 2 500-point transform = one wave, 50 x 50: lane a < 50 holds P[a + 50 b'] (b' < 50) in registers, runs a 50-point transform
-// over b' (prime-factor 2 x 25, the 25 as 5 x 5: every index is a compile-time constant, the data never leaves the registers),
-// multiplies by W2500^(a c) (table in LDS, [c][a]), transposes through LDS (by halves: the even output columns c first, then
-// the odd ones, 10 KB per wave; a wave's LDS operations execute in order, so the transposes need no barrier at all) and runs the
-// second 50-point transform over a: lane c then holds U[c + 50 d], d < 50.  Ten waves = the ten q of one (PRN, bin); they meet
-// in the exchange buffer (laid over the transposes: E[q][1250] for the even d, then the odd d), after which each lane takes
-// delays from the flat range and does twiddle, ten-point transform, magnitudes, sum, store, atomic maximum over the bins.
-// Five barriers per (PRN, bin) in all (the four-pass 250-thread transform needed five per TRANSFORM).
+// One 2 500-point transform = 50 lanes x 50 registers: lane a < 50 holds P[a + 50 b'] (b' < 50), runs a 50-point transform over b'
+// (prime-factor 2 x 25, the 25 as 5 x 5: every index is a compile-time constant, the data never leaves the registers), multiplies by
+// W2500^(a c) (table in LDS, [c][a]), transposes through LDS (by halves: the even output columns c first, then the odd ones, 10 KB per
+// transform) and runs the second 50-point transform over a: lane c then holds U[c + 50 d], d < 50.  The 500 lanes of an item's ten
+// transforms are threads 0 .. 499 of a 512-thread block (eight waves, two per SIMD, up to 256 registers each).  The ten transforms meet
+// in the exchange buffer (laid over the transposes: E[q][1250] for the even d, then the odd d), after which each thread takes delays
+// from the flat range and does twiddle, ten-point transform, magnitudes, sum, store, atomic maximum over the bins.  Eight barriers per
+// (PRN, bin) in all (the four-pass 250-thread transform of acq_corr2500_kernel needs five per TRANSFORM).
+// Measured on MI355X, 32 PRNs x 125 bins (profiles/r5_ab_acq_noncoherent.txt): radix-10 stage + four-pass transforms 0.62 ms per search
+// (0.57 with an XCD-aware block order); this decomposition with one WAVE per transform (ten waves of 50 lanes, 3 + 3 + 2 + 2 on the
+// SIMDs, 168 registers: the transposes' 150 live values spill) 0.43; packed 0.36; with the forward kernel below 0.31.
 #pragma once
 
 namespace dpe {
 
-constexpr int kWvRow = 51;                 // row stride (float2) of a half transpose: rows r, r' of a read fall on distinct banks (102 r mod 64)
-constexpr int kWvBuf = 25 * kWvRow;        // float2 per wave
-constexpr int kWvWaves = 10;
-constexpr int kWvHalf = 1250;              // delays per exchange round
-constexpr size_t kWvLdsBytes = ((size_t)kWvWaves * kWvBuf + 2500 + 1000) * sizeof(float2);   // 130 000 B: one block per CU
-static_assert(kWvWaves * kWvBuf >= kWvWaves * kWvHalf, "the exchange buffer lies over the transposes");
+constexpr int kPkRow = 51;                 // row stride (float2) of a half transpose: rows r, r' of a read fall on distinct banks (102 r mod 64)
+constexpr int kPkBuf = 25 * kPkRow;        // float2 per transform
+constexpr int kPkTransforms = 10;
+constexpr int kPkHalf = 1250;              // delays per exchange round
+constexpr size_t kPkLdsBytes = ((size_t)kPkTransforms * kPkBuf + 2500 + 1000) * sizeof(float2);   // 130 000 B: one block per CU
+static_assert(kPkTransforms * kPkBuf >= kPkTransforms * kPkHalf, "the exchange buffer lies over the transposes");
 
 // complex product with the second factor in scalar registers (compile-time twiddles: two literals, no vector register)
 __device__ __forceinline__ af2 acq_cmul_s(af2 a, af2 w)
@@ -82,204 +87,10 @@ __global__ __launch_bounds__(640) void acq_decimate10_kernel(const float2 *__res
     if (k0 + kk < 2500) Xq[row + (size_t)q * 2500 + k0 + kk] = s[kk * 10 + q];
 }
 
-constexpr int kWvNA = 8;    // radix-2 pairs of the NEXT item whose spectra are requested before the last reader phase of the current one
-__global__ __launch_bounds__(640) void acq_corr25k_wave_kernel(const float2 *__restrict__ Xq, const float2 *__restrict__ Rcq,
-                                                               const float2 *__restrict__ tw2, const float2 *__restrict__ tw25k, int B, int nP, int pOffset,
-                                                               float *__restrict__ surf, unsigned int *__restrict__ mpBits, int xcdMap)
-{
-    extern __shared__ float2 acqWvLds[];
-    float2 *sTw = acqWvLds + kWvWaves * kWvBuf;   // [c][a] = W2500^(a c)
-    float2 *sT1 = sTw + 2500, *sT2 = sT1 + 500;   // W25000^(q c) as [q][c] and W500^(q d) as [q][d]: the twiddle of delay j = c + 50 d in front of the ten-point transform
-    const int tid = threadIdx.x;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Lane-dependent indices and addresses are re-derived inside each phase from an opaque copy of tid: hoisted out of the item loop (as
-    // the compiler does with anything loop-invariant) they occupy ~20 registers around a loop whose transposes already need 150 of the
-    // 168 a wave gets at ten waves per CU -- and the spills that follow are reloads with a memory latency each.
-#define DPE_WV_LANE(lane, act, a)                   \
-    int lane = tid;                                 \
-    asm volatile("" : "+v"(lane));                  \
-    lane &= 63;                                     \
-    const bool act = lane < 50;                     \
-    const int a = act ? lane : 49;                  \
-    (void)a; (void)act
-    float2 *sT = acqWvLds + q * kWvBuf;
-    // PERSISTENT blocks, one per CU (the 130 KB of LDS see to that), each walking its share of the (PRN, bin) items.  xcdMap: the block's
-    // index mod 8 is its XCD; XCD x takes the PRNs p = x (mod 8) and walks the bins with all of them together -- a PRN's spectrum stays
-    // in that XCD's L2 for the whole launch, a bin's is fetched once per XCD.
-    unsigned s, sStep, sEnd, ppx, pBase, pMul;
-    if (xcdMap) { s = blockIdx.x >> 3; sStep = gridDim.x >> 3; ppx = (unsigned)nP >> 3; pBase = blockIdx.x & 7u; pMul = 8; }
-    else { s = blockIdx.x; sStep = gridDim.x; ppx = (unsigned)nP; pBase = 0; pMul = 1; }
-    sEnd = ppx * (unsigned)B;
-    if (s >= sEnd) return;
-    for (int i = tid; i < 2500; i += 640) sTw[i] = tw2[i];
-    if (tid < 500) {
-        const int tq = tid / 50, tc = tid - 50 * tq;
-        sT1[tid] = tw25k[tq * tc];
-        sT2[tid] = tw25k[50 * tq * tc];
-    }
-    const int a0 = (tid & 63) < 50 ? (tid & 63) : 49;
-    int p = (int)(pBase + pMul * (s % ppx)), b = (int)(s / ppx);
-    const float2 *xq = Xq + ((size_t)b * 10 + q) * 2500 + a0;
-    const float2 *rq = Rcq + ((size_t)p * 10 + q) * 2500 + a0;
-    float2 ax0[kWvNA], ar0[kWvNA], ax1[kWvNA], ar1[kWvNA];
-#pragma unroll
-    for (int n2 = 0; n2 < kWvNA; ++n2) {
-        ax0[n2] = xq[50 * acq_in50(0, n2)]; ar0[n2] = rq[50 * acq_in50(0, n2)];
-        ax1[n2] = xq[50 * acq_in50(1, n2)]; ar1[n2] = rq[50 * acq_in50(1, n2)];
-    }
-    __syncthreads();   // (the tables)
-    for (;;) {
-        af2 S[25], D[25];
-        // product spectrum of this wave's residue class, and the radix-2 stage of the first 50-point transform on the way in.  The first
-        // kWvNA pairs were requested during the previous item; the rest comes in three groups, each requested before the group before it is
-        // consumed (the scheduling fences keep the compiler from requesting all sixty at once, which does not fit the registers)
-        {
-            constexpr int G1 = kWvNA + (25 - kWvNA + 2) / 3, G2 = G1 + (25 - kWvNA + 1) / 3;
-            float2 bx0[25], br0[25], bx1[25], br1[25];   // (indexed by n2; only [kWvNA, 25) is used)
-            const auto request = [&](int lo, int hi) {
-#pragma unroll
-                for (int n2 = lo; n2 < hi; ++n2) {
-                    bx0[n2] = xq[50 * acq_in50(0, n2)]; br0[n2] = rq[50 * acq_in50(0, n2)];
-                    bx1[n2] = xq[50 * acq_in50(1, n2)]; br1[n2] = rq[50 * acq_in50(1, n2)];
-                }
-            };
-            const auto consume = [&](int lo, int hi) {
-#pragma unroll
-                for (int n2 = lo; n2 < hi; ++n2) {
-                    const af2 p0 = acq_cmul(af2{bx0[n2].x, bx0[n2].y}, af2{br0[n2].x, br0[n2].y}), p1 = acq_cmul(af2{bx1[n2].x, bx1[n2].y}, af2{br1[n2].x, br1[n2].y});
-                    S[n2] = p0 + p1;
-                    D[n2] = p0 - p1;
-                }
-            };
-#pragma unroll
-            for (int n2 = 0; n2 < kWvNA; ++n2) { bx0[n2] = ax0[n2]; br0[n2] = ar0[n2]; bx1[n2] = ax1[n2]; br1[n2] = ar1[n2]; }
-            request(kWvNA, G1);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(0, kWvNA);
-            request(G1, G2);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(kWvNA, G1);
-            request(G2, 25);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(G1, G2);
-            consume(G2, 25);
-        }
-        acq_idft25(S);
-        acq_idft25(D);
-        __syncthreads();   // the readers of the previous item are through with the exchange buffer, which lies over the transposes
-        // even columns out, twiddled; every lane reads back the row of its (even) column -- the odd lanes read again below.  (All the twiddles
-        // of a half are fetched BEFORE its first store: the table and the transposes are one LDS array to the compiler, and a load behind a
-        // store that may alias it waits for nothing but is not moved up either -- 25 exposed LDS round trips per half otherwise.)
-        af2 Bv[50];
-        {
-            DPE_WV_LANE(lane, act, a);
-            float2 w[25];
-#pragma unroll
-            for (int k2 = 0; k2 < 25; ++k2) w[k2] = sTw[acq_out50(0, k2) * 50 + a];
-#pragma unroll
-            for (int k2 = 0; k2 < 25; ++k2) S[acq_pos25(k2)] = acq_cmul(S[acq_pos25(k2)], af2{w[k2].x, w[k2].y});
-#pragma unroll
-            for (int k2 = 0; k2 < 25; ++k2) w[k2] = sTw[acq_out50(1, k2) * 50 + a];
-            if (act) {
-#pragma unroll
-                for (int k2 = 0; k2 < 25; ++k2) sT[(acq_out50(0, k2) >> 1) * kWvRow + lane] = make_float2(S[acq_pos25(k2)].x, S[acq_pos25(k2)].y);
-            }
-#pragma unroll
-            for (int k2 = 0; k2 < 25; ++k2) D[acq_pos25(k2)] = acq_cmul(D[acq_pos25(k2)], af2{w[k2].x, w[k2].y});
-            const float2 *row = sT + (a >> 1) * kWvRow;
-#pragma unroll
-            for (int i = 0; i < 50; ++i) {
-                const float2 v = row[i];
-                Bv[i] = af2{v.x, v.y};
-            }
-            if (act) {
-#pragma unroll
-                for (int k2 = 0; k2 < 25; ++k2) sT[(acq_out50(1, k2) >> 1) * kWvRow + lane] = make_float2(D[acq_pos25(k2)].x, D[acq_pos25(k2)].y);
-            }
-            if (lane & 1) {
-#pragma unroll
-                for (int i = 0; i < 50; ++i) {
-                    const float2 v = row[i];
-                    Bv[i] = af2{v.x, v.y};
-                }
-            }
-        }
-        // second 50-point transform, over a: S -> U[c + 50 d] for the even d, D -> the odd d
-#pragma unroll
-        for (int n2 = 0; n2 < 25; ++n2) {
-            S[n2] = Bv[acq_in50(0, n2)] + Bv[acq_in50(1, n2)];
-            D[n2] = Bv[acq_in50(0, n2)] - Bv[acq_in50(1, n2)];
-        }
-        acq_idft25(S);
-        acq_idft25(D);
-        float2 *sE = acqWvLds + q * kWvHalf;
-        const size_t rowOut = ((size_t)(pOffset + p) * B + b) * 2500;
-        unsigned int *mpRow = mpBits + (size_t)(pOffset + p) * 2500;
-        const unsigned sNext = s + sStep;
-        const bool more = sNext < sEnd;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            __syncthreads();   // r = 0: every wave is through with its transposes; r = 1: every reader is through with the even half
-            DPE_WV_LANE(lane, act, a);
-            if (act) {
-#pragma unroll
-                for (int k2 = 0; k2 < 25; ++k2) {
-                    const int e = acq_out50(r, k2) >> 1;   // d = 2 e + r
-                    const af2 y = r ? D[acq_pos25(k2)] : S[acq_pos25(k2)];
-                    sE[e * 50 + lane] = make_float2(y.x, y.y);
-                }
-            }
-            if (r == 1) {
-                // the transform's registers are free: the first spectra of the next item travel under the last reader phase.  (Unconditional --
-                // the last item requests its own again: a conditional request would keep the OLD values alive around the whole loop.)
-                const unsigned sn = more ? sNext : s;
-                p = (int)(pBase + pMul * (sn % ppx)); b = (int)(sn / ppx);
-                xq = Xq + ((size_t)b * 10 + q) * 2500 + a;
-                rq = Rcq + ((size_t)p * 10 + q) * 2500 + a;
-#pragma unroll
-                for (int n2 = 0; n2 < kWvNA; ++n2) {
-                    ax0[n2] = xq[50 * acq_in50(0, n2)]; ar0[n2] = rq[50 * acq_in50(0, n2)];
-                    ax1[n2] = xq[50 * acq_in50(1, n2)]; ar1[n2] = rq[50 * acq_in50(1, n2)];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                int i = tid;
-                asm volatile("" : "+v"(i));
-                i += it * 640;
-                if (i < kWvHalf) {
-                    const int e = i / 50, c = i - 50 * e, d = 2 * e + r, j = c + 50 * d;   // i = 50 e + c
-                    af2 v[10];
-                    float2 f1[10], f2[10];
-#pragma unroll
-                    for (int qq = 0; qq < 10; ++qq) {
-                        const float2 u = acqWvLds[qq * kWvHalf + i];
-                        v[qq] = af2{u.x, u.y};
-                    }
-#pragma unroll
-                    for (int qq = 1; qq < 10; ++qq) { f1[qq] = sT1[qq * 50 + c]; f2[qq] = sT2[qq * 50 + d]; }
-#pragma unroll
-                    for (int qq = 1; qq < 10; ++qq) v[qq] = acq_cmul(v[qq], acq_cmul(af2{f1[qq].x, f1[qq].y}, af2{f2[qq].x, f2[qq].y}));   // W25000^(q j)
-                    acq_idft10(v);
-                    float sv = 0.f;
-#pragma unroll
-                    for (int n = 0; n < 10; ++n) sv += __builtin_amdgcn_sqrtf(v[n].x * v[n].x + v[n].y * v[n].y);   // the ten lag aliases of delay j (correlator.py:80-82)
-                    surf[rowOut + j] = sv;
-                    atomicMax(&mpRow[j], __float_as_uint(sv));   // max over the bins (:87)
-                }
-            }
-        }
-        if (!more) break;
-        s = sNext;
-    }
-#undef DPE_WV_LANE
-}
-
 // The packed 2 500-point inverse transforms of a block (unnormalised; thread L < 500 = lane a = L mod 50 of transform q = L / 50; 512 threads).
 // In: S[n2] / D[n2] = sum / difference of the inputs P[a + 50 acq_in50(0 / 1, n2)] of this lane (the radix-2 stage of the first 50-point
 // transform).  Out: lane c of transform q holds U_q[c + 50 d]: S[acq_pos25(k2)] for the even d = acq_out50(0, k2), D[...] for the odd d =
-// acq_out50(1, k2).  lds = the block's transposes (kWvWaves x kWvBuf), sTw = W2500^(a c) as [c][a].  Four barriers; the first one
+// acq_out50(1, k2).  lds = the block's transposes (kPkTransforms x kPkBuf), sTw = W2500^(a c) as [c][a].  Four barriers; the first one
 // separates whatever the caller last did with the transposes' LDS from the first store here.
 #define DPE_PK_LANE_(q, a, act)                     \
     int L_ = tid;                                   \
@@ -288,7 +99,7 @@ __global__ __launch_bounds__(640) void acq_corr25k_wave_kernel(const float2 *__r
     L_ = act ? L_ : 499;                            \
     const int q = L_ / 50, a = L_ - 50 * q;         \
     (void)a; (void)act; (void)q
-__device__ __forceinline__ void acq_pack_transform2500(af2 (&S)[25], af2 (&D)[25], const int tid, float2 *acqWvLds, const float2 *sTw)
+__device__ __forceinline__ void acq_pack_transform2500(af2 (&S)[25], af2 (&D)[25], const int tid, float2 *acqPkLds, const float2 *sTw)
 {
     acq_idft25(S);
     acq_idft25(D);
@@ -299,7 +110,7 @@ __device__ __forceinline__ void acq_pack_transform2500(af2 (&S)[25], af2 (&D)[25
     af2 Bv[50];
     {
         DPE_PK_LANE_(q, a, act);
-        float2 *sT = acqWvLds + q * kWvBuf;
+        float2 *sT = acqPkLds + q * kPkBuf;
         float2 w[25];
 #pragma unroll
         for (int k2 = 0; k2 < 25; ++k2) w[k2] = sTw[acq_out50(0, k2) * 50 + a];
@@ -309,12 +120,12 @@ __device__ __forceinline__ void acq_pack_transform2500(af2 (&S)[25], af2 (&D)[25
         for (int k2 = 0; k2 < 25; ++k2) w[k2] = sTw[acq_out50(1, k2) * 50 + a];
         if (act) {
 #pragma unroll
-            for (int k2 = 0; k2 < 25; ++k2) sT[(acq_out50(0, k2) >> 1) * kWvRow + a] = make_float2(S[acq_pos25(k2)].x, S[acq_pos25(k2)].y);
+            for (int k2 = 0; k2 < 25; ++k2) sT[(acq_out50(0, k2) >> 1) * kPkRow + a] = make_float2(S[acq_pos25(k2)].x, S[acq_pos25(k2)].y);
         }
 #pragma unroll
         for (int k2 = 0; k2 < 25; ++k2) D[acq_pos25(k2)] = acq_cmul(D[acq_pos25(k2)], af2{w[k2].x, w[k2].y});
         __syncthreads();   // the even columns of every transform are in place
-        const float2 *row = sT + (a >> 1) * kWvRow;
+        const float2 *row = sT + (a >> 1) * kPkRow;
 #pragma unroll
         for (int i = 0; i < 50; ++i) {
             const float2 v = row[i];
@@ -323,7 +134,7 @@ __device__ __forceinline__ void acq_pack_transform2500(af2 (&S)[25], af2 (&D)[25
         __syncthreads();   // ... and read
         if (act) {
 #pragma unroll
-            for (int k2 = 0; k2 < 25; ++k2) sT[(acq_out50(1, k2) >> 1) * kWvRow + a] = make_float2(D[acq_pos25(k2)].x, D[acq_pos25(k2)].y);
+            for (int k2 = 0; k2 < 25; ++k2) sT[(acq_out50(1, k2) >> 1) * kPkRow + a] = make_float2(D[acq_pos25(k2)].x, D[acq_pos25(k2)].y);
         }
         __syncthreads();
         if (a & 1) {
@@ -357,8 +168,8 @@ __global__ __launch_bounds__(512) void acq_fwd25k_pack_kernel(const int16_t *__r
                                                               const float2 *__restrict__ tw2, const float2 *__restrict__ tw25k, float2 *__restrict__ Xq,
                                                               float *__restrict__ mp, long long mpLen)
 {
-    extern __shared__ float2 acqWvLds[];
-    float2 *sTw = acqWvLds + kWvWaves * kWvBuf;
+    extern __shared__ float2 acqPkLds[];
+    float2 *sTw = acqPkLds + kPkTransforms * kPkBuf;
     float2 *sT1 = sTw + 2500, *sT2 = sT1 + 500;
     acq_clear(mp, mpLen);
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -376,7 +187,7 @@ __global__ __launch_bounds__(512) void acq_fwd25k_pack_kernel(const int16_t *__r
     __syncthreads();   // (the tables)
 #pragma unroll
     for (int ch = 0; ch < 5; ++ch) {
-        float2 *E = acqWvLds + (ch & 1) * 5000;   // [q][500]
+        float2 *E = acqPkLds + (ch & 1) * 5000;   // [q][500]
         if (act) {
             const int n1 = 500 * ch + tid;
             af2 v[10];
@@ -414,7 +225,7 @@ __global__ __launch_bounds__(512) void acq_fwd25k_pack_kernel(const int16_t *__r
         S[n2] = Z[acq_in50(0, n2)] + Z[acq_in50(1, n2)];
         D[n2] = Z[acq_in50(0, n2)] - Z[acq_in50(1, n2)];
     }
-    acq_pack_transform2500(S, D, tid, acqWvLds, sTw);
+    acq_pack_transform2500(S, D, tid, acqPkLds, sTw);
     if (act) {
         float2 *xo = Xq + ((size_t)b * 10 + q) * 2500 + a;
 #pragma unroll
@@ -430,15 +241,16 @@ __global__ __launch_bounds__(512) void acq_corr25k_pack_kernel(const float2 *__r
                                                                const float2 *__restrict__ tw2, const float2 *__restrict__ tw25k, int B, int nP, int pOffset,
                                                                float *__restrict__ surf, unsigned int *__restrict__ mpBits, int xcdMap)
 {
-    extern __shared__ float2 acqWvLds[];
-    float2 *sTw = acqWvLds + kWvWaves * kWvBuf;   // [c][a] = W2500^(a c)
+    extern __shared__ float2 acqPkLds[];
+    float2 *sTw = acqPkLds + kPkTransforms * kPkBuf;   // [c][a] = W2500^(a c)
     float2 *sT1 = sTw + 2500, *sT2 = sT1 + 500;   // W25000^(q c) as [q][c] and W500^(q d) as [q][d]: the twiddle of delay j = c + 50 d in front of the ten-point transform
     const int tid = threadIdx.x;
     // THE FIVE HUNDRED LANES OF AN ITEM'S TEN TRANSFORMS PACKED INTO EIGHT WAVES: thread L < 500 is lane a = L mod 50 of transform q = L / 50
-    // (the one-wave-per-transform form uses 50 of 64 lanes and puts ten waves on four SIMDs, 3 + 3 + 2 + 2).  A transform now straddles
-    // two waves, so the transposes are ordered by block barriers instead of by a wave's in-order LDS queue; with two waves per SIMD a
-    // wave may use 256 registers, which the transposes (150 live) and the prefetch of the next item's spectra want.
-    // Lane-dependent indices and addresses are re-derived inside each phase from an opaque copy of tid (see the wave form).
+    // (one wave per transform would use 50 of 64 lanes and put ten waves on four SIMDs, 3 + 3 + 2 + 2).  A transform straddles two
+    // waves, so the transposes are ordered by block barriers; with two waves per SIMD a wave may use 256 registers, which the transposes
+    // (150 live) and the prefetch of the next item's spectra want.
+    // Lane-dependent indices and addresses are re-derived inside each phase from an opaque copy of tid: hoisted out of the item loop (as
+    // the compiler does with anything loop-invariant) they would occupy ~20 registers around the whole loop.
 #define DPE_PK_LANE(q, a, act)                      \
     int L_ = tid;                                   \
     asm volatile("" : "+v"(L_));                    \
@@ -473,7 +285,7 @@ __global__ __launch_bounds__(512) void acq_corr25k_pack_kernel(const float2 *__r
     __syncthreads();   // (the tables)
     for (;;) {
         af2 S[25], D[25];
-        // product spectrum of this wave's residue class, and the radix-2 stage of the first 50-point transform on the way in.  The first
+        // product spectrum of this lane's residue class, and the radix-2 stage of the first 50-point transform on the way in.  The first
         // kPkNA pairs were requested during the previous item; the rest comes in three groups, each requested before the group before it is
         // consumed (the scheduling fences keep the compiler from requesting all sixty at once, which does not fit the registers)
         {
@@ -507,17 +319,17 @@ __global__ __launch_bounds__(512) void acq_corr25k_pack_kernel(const float2 *__r
             consume(G1, G2);
             consume(G2, 25);
         }
-        acq_pack_transform2500(S, D, tid, acqWvLds, sTw);   // (its first barrier: the readers of the previous item are through with the exchange buffer)
+        acq_pack_transform2500(S, D, tid, acqPkLds, sTw);   // (its first barrier: the readers of the previous item are through with the exchange buffer)
         const size_t rowOut = ((size_t)(pOffset + p) * B + b) * 2500;
         unsigned int *mpRow = mpBits + (size_t)(pOffset + p) * 2500;
         const unsigned sNext = s + sStep;
         const bool more = sNext < sEnd;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            __syncthreads();   // r = 0: every wave is through with its transposes; r = 1: every reader is through with the even half
+            __syncthreads();   // r = 0: every transform is through with its transposes; r = 1: every reader is through with the even half
             DPE_PK_LANE(q, a, act);
             if (act) {
-                float2 *sE = acqWvLds + q * kWvHalf;
+                float2 *sE = acqPkLds + q * kPkHalf;
 #pragma unroll
                 for (int k2 = 0; k2 < 25; ++k2) {
                     const int e = acq_out50(r, k2) >> 1;   // d = 2 e + r
@@ -544,13 +356,13 @@ __global__ __launch_bounds__(512) void acq_corr25k_pack_kernel(const float2 *__r
                 int i = tid;
                 asm volatile("" : "+v"(i));
                 i += it * 512;
-                if (i < kWvHalf) {
+                if (i < kPkHalf) {
                     const int e = i / 50, c = i - 50 * e, d = 2 * e + r, j = c + 50 * d;   // i = 50 e + c
                     af2 v[10];
                     float2 f1[10], f2[10];
 #pragma unroll
                     for (int qq = 0; qq < 10; ++qq) {
-                        const float2 u = acqWvLds[qq * kWvHalf + i];
+                        const float2 u = acqPkLds[qq * kPkHalf + i];
                         v[qq] = af2{u.x, u.y};
                     }
 #pragma unroll

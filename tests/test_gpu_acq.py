@@ -138,9 +138,12 @@ def test_fused_coherent_search_equals_the_rocfft_chain():
 
 def test_fused_noncoherent_search_equals_the_rocfft_chain():
     """The reference's non-coherent mode (coherent = False: one 25 000-point correlation per bin, |.| summed over the ten lag
-    aliases, correlator.py:77-82) at 10 x 2 500 samples runs as a radix-10 stage + ten fused 2 500-point transforms per (PRN,
-    bin); DPE_ACQ_NO_FUSED=1 keeps multiply kernel, 25 000-point rocFFT and fold kernel.  Same surface to fp32 rounding, same
-    peak cells and statistics -- 32 PRNs x the reference's 25 x 500 Hz raster, PRNs in chunks of 8 and of 5 (a short last chunk)."""
+    aliases, correlator.py:77-82) at 10 x 2 500 samples runs as ten packed 2 500-point transforms per (PRN, bin) with the ten-point
+    stage across them at the output, fed by a forward kernel that writes the decimated spectra (csrc/dpe_acq_pack.h);
+    DPE_ACQ_NO_FUSED=1 keeps wipe kernel, multiply kernel, 25 000-point rocFFTs and fold kernel.  Same surface to fp32 rounding,
+    same peak cells and statistics -- 32 PRNs x the reference's 25 x 500 Hz raster; PRNs in one launch (XCD-aware item order), in
+    chunks of 8, of 5 (a short last chunk, plain item order) and of 1; with the forward transform left to rocFFT
+    (DPE_ACQ_NO_FWD_PACK=1) and with the radix-10 kernel + four-pass transforms of round 4 (DPE_ACQ_NO_PACK=1)."""
     import os
     import torch
     fs, S = 2.5e6, 25000
@@ -149,28 +152,35 @@ def test_fused_noncoherent_search_equals_the_rocfft_chain():
     iq = torch.from_numpy(dpe.synth.gen_iq(94, fs, S, ch, amp=120.0, flip=np.zeros(5, dtype=bool))).to("cuda:0")
     bins = np.arange(-12, 13) * 500.0
     out = {}
-    for form, chunk in (("fused", 8), ("fused5", 5), ("rocfft", 8)):
-        old = os.environ.get("DPE_ACQ_NO_FUSED")
-        if form == "rocfft":
-            os.environ["DPE_ACQ_NO_FUSED"] = "1"
+    forms = (("fused", 32, None), ("fused8", 8, None), ("fused5", 5, None), ("fused1", 1, None), ("rocfft_fwd", 32, "DPE_ACQ_NO_FWD_PACK"),
+             ("round4", 8, "DPE_ACQ_NO_PACK"), ("rocfft", 8, "DPE_ACQ_NO_FUSED"))
+    for form, chunk, env in forms:
+        old = os.environ.get(env) if env else None
+        if env:
+            os.environ[env] = "1"
         try:
             acq = dpe.Acquisition(fs, S, list(range(1, 33)), bins, mode="noncoherent", prn_chunk=chunk)
         finally:
-            if form == "rocfft":
+            if env:
                 if old is None:
-                    os.environ.pop("DPE_ACQ_NO_FUSED", None)
+                    os.environ.pop(env, None)
                 else:
-                    os.environ["DPE_ACQ_NO_FUSED"] = old
+                    os.environ[env] = old
         acq.search(iq)
+        acq.search(iq)   # (a second search on the same handle: the per-delay maxima are cleared by the first kernel of a search)
         out[form] = (acq.results(), acq.read_surface().copy())
         acq.close()
-    (r0, s0), (r5, s5), (r1, s1) = out["fused"], out["fused5"], out["rocfft"]
+    (r0, s0), (r1, s1) = out["fused"], out["rocfft"]
     assert s0.shape == s1.shape == (32, 25, 2500)
-    assert np.array_equal(s0, s5)
+    for form in ("fused8", "fused5", "fused1"):
+        assert np.array_equal(s0, out[form][1]), form
     assert np.abs(s0 - s1).max() < 3e-6 * s1.max()
-    for a, b in zip(r0, r1):
-        assert a["max_code_idx"] == b["max_code_idx"] and a["max_dopp_idx"] == b["max_dopp_idx"] and a["found"] == b["found"]
-        assert abs(a["cppm"] / b["cppm"] - 1) < 1e-5 and abs(a["cppr"] / b["cppr"] - 1) < 1e-5
+    assert np.abs(out["rocfft_fwd"][1] - s1).max() < 3e-6 * s1.max()
+    assert np.abs(out["round4"][1] - s1).max() < 3e-6 * s1.max()
+    for form in ("fused", "rocfft_fwd", "round4"):
+        for a, b in zip(out[form][0], r1):
+            assert a["max_code_idx"] == b["max_code_idx"] and a["max_dopp_idx"] == b["max_dopp_idx"] and a["found"] == b["found"], form
+            assert abs(a["cppm"] / b["cppm"] - 1) < 1e-5 and abs(a["cppr"] / b["cppr"] - 1) < 1e-5, form
     assert {4, 9, 23, 29} <= {r["prn"] for r in r0 if r["found"]}   # (PRN 16, the weakest, stays below cppm = 2 on this raster in both forms)
 
 
