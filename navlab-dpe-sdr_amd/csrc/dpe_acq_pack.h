@@ -282,6 +282,7 @@ __global__ __launch_bounds__(512) void acq_corr25k_pack_kernel(const float2 *__r
         ax0[n2] = xq[50 * acq_in50(0, n2)]; ar0[n2] = rq[50 * acq_in50(0, n2)];
         ax1[n2] = xq[50 * acq_in50(1, n2)]; ar1[n2] = rq[50 * acq_in50(1, n2)];
     }
+    float mx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // running maxima over the bins of this thread's six delays (the same six for every item)
     __syncthreads();   // (the tables)
     for (;;) {
         af2 S[25], D[25];
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(512) void acq_corr25k_pack_kernel(const float2 *__r
         unsigned int *mpRow = mpBits + (size_t)(pOffset + p) * 2500;
         const unsigned sNext = s + sStep;
         const bool more = sNext < sEnd;
+        const int pCur = p;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             __syncthreads();   // r = 0: every transform is through with its transposes; r = 1: every reader is through with the even half
@@ -374,9 +376,26 @@ __global__ __launch_bounds__(512) void acq_corr25k_pack_kernel(const float2 *__r
 #pragma unroll
                     for (int n = 0; n < 10; ++n) sv += __builtin_amdgcn_sqrtf(v[n].x * v[n].x + v[n].y * v[n].y);   // the ten lag aliases of delay j (correlator.py:80-82)
                     surf[rowOut + j] = sv;
-                    atomicMax(&mpRow[j], __float_as_uint(sv));   // max over the bins (:87)
+                    mx[r][it] = fmaxf(mx[r][it], sv);   // max over the bins (:87)
                 }
             }
+        }
+        // the maxima go out when the block leaves the PRN (with the XCD-aware order a block keeps ONE PRN for all its bins: 2 500 atomics
+        // per block instead of 2 500 per item -- ten million per 32 x 125 search)
+        if (!more || p != pCur) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    int i = tid;
+                    asm volatile("" : "+v"(i));
+                    i += it * 512;
+                    if (i < kPkHalf) {
+                        const int e = i / 50;
+                        atomicMax(&mpRow[i + 50 * e + 50 * r], __float_as_uint(mx[r][it]));
+                    }
+                    mx[r][it] = 0.f;
+                }
         }
         if (!more) break;
         s = sNext;
