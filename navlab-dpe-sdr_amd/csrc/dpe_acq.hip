@@ -839,6 +839,287 @@ __global__ __launch_bounds__(256) void acq_stats_kernel(const float *__restrict_
     }
 }
 
+// ---- the statistics of rows of up to 2 560 delays (the reference's 2.5 Msps) with the row in REGISTERS: same selections, same results
+// as acq_stats_kernel, whose chain of six LDS passes over the row and ~80 ds_bpermute shuffle steps was 10 of its 14.6 us.  Each of the
+// 256 threads owns ten delays; the masked values are formed once; every pass is ten register operations and a reduction on the vector
+// ALU (DPP row operations: ~8 cycles a step where a shuffle through the LDS crossbar takes ~100), waves meet through LDS eight times.
+#define DPE_RED63(T, v, ident, OPEXPR)                                                                                                          \
+    {                                                                                                                                           \
+        const int id_ = __builtin_bit_cast(int, (T)(ident));                                                                                    \
+        T o_;                                                                                                                                   \
+        o_ = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(id_, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); v = OPEXPR;           \
+        o_ = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(id_, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)); v = OPEXPR;           \
+        o_ = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(id_, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)); v = OPEXPR;          \
+        o_ = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(id_, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)); v = OPEXPR;          \
+        o_ = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(id_, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)); v = OPEXPR;          \
+        o_ = __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(id_, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)); v = OPEXPR;          \
+        v = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));                                                   \
+    }
+__device__ __forceinline__ float wave_max63(float v) { DPE_RED63(float, v, 0.f, fmaxf(v, o_)); return v; }               // (values >= 0)
+__device__ __forceinline__ float wave_min63(float v) { DPE_RED63(float, v, 3.0e38f, fminf(v, o_)); return v; }
+__device__ __forceinline__ float wave_sum63(float v) { DPE_RED63(float, v, 0.f, v + o_); return v; }
+__device__ __forceinline__ unsigned int wave_minu63(unsigned int v) { DPE_RED63(unsigned int, v, 0xFFFFFFFFu, (v < o_ ? v : o_)); return v; }
+__device__ __forceinline__ unsigned int wave_addu63(unsigned int v) { DPE_RED63(unsigned int, v, 0u, v + o_); return v; }
+#undef DPE_RED63
+__device__ __forceinline__ double wave_sumd63(double v)
+{
+#define DPE_STEP(CTRL, RM)                                                                                                                      \
+    {                                                                                                                                           \
+        const long long b_ = __builtin_bit_cast(long long, v);                                                                                  \
+        const unsigned int lo_ = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)b_, CTRL, RM, 0xf, false);                     \
+        const unsigned int hi_ = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b_ >> 32), CTRL, RM, 0xf, false);             \
+        v += __builtin_bit_cast(double, ((unsigned long long)hi_ << 32) | lo_);                                                                 \
+    }
+    DPE_STEP(0xB1, 0xf) DPE_STEP(0x4E, 0xf) DPE_STEP(0x141, 0xf) DPE_STEP(0x140, 0xf) DPE_STEP(0x142, 0xa) DPE_STEP(0x143, 0xc)
+#undef DPE_STEP
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, 63), hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// inclusive prefix sums over the 64 lanes
+__device__ __forceinline__ unsigned int wave_scan_addu(unsigned int v)
+{
+#define DPE_STEP(CTRL, RM) v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, 0xf, false);
+    DPE_STEP(0x111, 0xf) DPE_STEP(0x112, 0xf) DPE_STEP(0x114, 0xf) DPE_STEP(0x118, 0xf) DPE_STEP(0x142, 0xa) DPE_STEP(0x143, 0xc)
+#undef DPE_STEP
+    return v;
+}
+
+constexpr int kAcqStatsR = 10;   // delays per thread: rows up to 2 560
+__global__ __launch_bounds__(256) void acq_stats_small_kernel(const float *__restrict__ surf, const float *__restrict__ mp, int B, int M, int maskS, int iLo,
+                                                              double fLo, int iHi, double fHi, int *__restrict__ codeIdx, int *__restrict__ doppIdx,
+                                                              AcqStats *__restrict__ out)
+{
+    constexpr int R = kAcqStatsR;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ unsigned int hist[2 * 2048];
+    __shared__ unsigned int sTmp[8], sSel[4], sCnt[2], sWu[4][4];
+    __shared__ float sCand[2][64], sWf[4][4], sF[2];
+    __shared__ double sWd[4];
+    const float *m = mp + (size_t)p * M;
+    float rv[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int j = tid + 256 * i;
+        rv[i] = j < M ? m[j] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hist[tid + 256 * i] = 0u;
+    if (tid < 2) sCnt[tid] = 0u;
+    // max_code_idx: the FIRST maximum of the row (correlator.py:88) -- largest value, then smallest index
+    float lsum = 0.f, lmax = -1.f;
+    unsigned int lidx = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int j = tid + 256 * i;
+        if (j < M) {
+            lsum += rv[i];
+            if (rv[i] > lmax) { lmax = rv[i]; lidx = (unsigned int)j; }
+        }
+    }
+    {
+        const float wmax = wave_max63(fmaxf(lmax, 0.f));
+        const unsigned int widx = wave_minu63(lmax == wmax ? lidx : 0xFFFFFFFFu);
+        const float wsum = wave_sum63(lsum);
+        if (lane == 0) { sWf[w][0] = wmax; sWu[w][0] = widx; sWf[w][1] = wsum; }
+    }
+    __syncthreads();   // (also: the cleared histogram and counters)
+    float peak = sWf[0][0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) peak = fmaxf(peak, sWf[q][0]);
+    unsigned int ciU = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ciU = (sWf[q][0] == peak && sWu[q][0] < ciU) ? sWu[q][0] : ciU;
+    const int ci = (int)ciU;
+    const float binScale = 256.0f * (float)M / fmaxf((sWf[0][1] + sWf[1][1]) + (sWf[2][1] + sWf[3][1]), 1e-30f);   // 256 bins per row mean
+    // the peak's column of the surface: loads issued here, reduced at the end (they arrive under the selection passes)
+    float dmax = -1.f;
+    unsigned int didx = 0xFFFFFFFFu;
+    for (int b = tid; b < B; b += 256) {
+        const float v = surf[((size_t)p * B + b) * M + ci];
+        if (v > dmax) { dmax = v; didx = (unsigned int)b; }
+    }
+    // row values with the +-maskS delays about the peak zeroed (indices wrap at both ends, see dpe_hip.h), formed once
+    float vm[R], mxT = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int j = tid + 256 * i;
+        int d = j - ci;
+        if (d < 0) d += M;
+        const int c = d < M - d ? d : M - d;
+        vm[i] = c <= maskS ? 0.f : rv[i];
+        if (j < M) mxT = fmaxf(mxT, vm[i]);
+    }
+    auto bin_of = [&](float v) -> unsigned int {
+        const float t = v * binScale;
+        return t >= 2047.f ? 2047u : (unsigned int)t;
+    };
+    // the iLo-th and the iHi-th smallest (0-based) of the masked row: one histogram over 2048 linear bins of width mean / 256, the handful
+    // of values of the selected bins ranked inside one wave; rows with more than 64 values in a selected bin take the radix passes below
+    float selV[2];
+    bool selected = false;
+    {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (tid + 256 * i < M) atomicAdd(&hist[bin_of(vm[i])], 1u);
+        __syncthreads();
+        unsigned int tot = 0u;
+#pragma unroll
+        for (unsigned int q = 0; q < 8u; ++q) tot += hist[tid * 8u + q];
+        const unsigned int inc = wave_scan_addu(tot);
+        if (lane == 63) sTmp[w] = inc;
+        __syncthreads();
+        unsigned int excl0 = inc - tot;
+        for (int q = 0; q < w; ++q) excl0 += sTmp[q];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned int kr = (unsigned int)(r ? iHi : iLo);
+            if (tot && kr >= excl0 && kr < excl0 + tot) {   // the rank lies among this thread's bins
+                unsigned int excl = excl0;
+                for (unsigned int q = 0; q < 8u; ++q) {
+                    const unsigned int c = hist[tid * 8u + q];
+                    if (kr < excl + c) { sSel[2 * r] = tid * 8u + q; sSel[2 * r + 1] = kr - excl; break; }
+                    excl += c;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned int selBin[2] = {sSel[0], sSel[2]}, kIn[2] = {sSel[1], sSel[3]};
+        const unsigned int nC[2] = {hist[selBin[0]], hist[selBin[1]]};
+        if (nC[0] <= 64u && nC[1] <= 64u) {   // (block-uniform)
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (tid + 256 * i < M) {
+                    const unsigned int b = bin_of(vm[i]);
+                    if (b == selBin[0]) sCand[0][atomicAdd(&sCnt[0], 1u)] = vm[i];
+                    if (b == selBin[1]) sCand[1][atomicAdd(&sCnt[1], 1u)] = vm[i];
+                }
+            }
+            __syncthreads();
+            if (w < 2) {
+                const int n = __builtin_amdgcn_readfirstlane((int)nC[w]);
+                const float v = lane < n ? sCand[w][lane] : 3.0e38f;
+                unsigned int below = 0u;
+                for (int j = 0; j < n; ++j) {
+                    const float cj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+                    below += (cj < v || (cj == v && j < lane)) ? 1u : 0u;
+                }
+                if (lane < n && below == kIn[w]) sF[w] = v;
+            }
+            __syncthreads();
+            selV[0] = sF[0];
+            selV[1] = sF[1];
+            selected = true;
+        }
+    }
+    if (!selected) {
+        // radix selection over the values' bit patterns (>= 0, so unsigned order is float order), 11 / 11 / 10 bits, one histogram per rank
+        __syncthreads();   // (the fast path's histogram is dead: the passes below clear and reuse it)
+        unsigned int prefix[2] = {0u, 0u}, kk[2] = {(unsigned int)iLo, (unsigned int)iHi}, mask = 0u;
+        const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = shifts[pass];
+            const unsigned int nbin = 1u << widths[pass];
+            for (unsigned int i = tid; i < 2u * nbin; i += 256) hist[i] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                if (tid + 256 * i < M) {
+                    const unsigned int u = __float_as_uint(vm[i]), dgt = (u >> shift) & (nbin - 1u);
+                    if ((u & mask) == prefix[0]) atomicAdd(&hist[dgt], 1u);
+                    if ((u & mask) == prefix[1]) atomicAdd(&hist[nbin + dgt], 1u);
+                }
+            }
+            __syncthreads();
+            const unsigned int per = nbin / 256u;   // 8 or 4 consecutive digits per thread
+            unsigned int tot[2] = {0u, 0u};
+            for (unsigned int q = 0; q < per; ++q) { tot[0] += hist[tid * per + q]; tot[1] += hist[nbin + tid * per + q]; }
+            const unsigned int inc[2] = {wave_scan_addu(tot[0]), wave_scan_addu(tot[1])};
+            if (lane == 63) { sTmp[w] = inc[0]; sTmp[4 + w] = inc[1]; }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                unsigned int excl = inc[r] - tot[r];
+                for (int q = 0; q < w; ++q) excl += sTmp[4 * r + q];
+                if (tot[r] && kk[r] >= excl && kk[r] < excl + tot[r]) {   // the rank lies among this thread's digits
+                    for (unsigned int q = 0; q < per; ++q) {
+                        const unsigned int c = hist[r * nbin + tid * per + q];
+                        if (kk[r] < excl + c) { sSel[2 * r] = prefix[r] | ((tid * per + q) << shift); sSel[2 * r + 1] = kk[r] - excl; break; }
+                        excl += c;
+                    }
+                }
+            }
+            __syncthreads();
+            prefix[0] = sSel[0]; kk[0] = sSel[1]; prefix[1] = sSel[2]; kk[1] = sSel[3];
+            mask |= (nbin - 1u) << shift;
+        }
+        selV[0] = __uint_as_float(prefix[0]);
+        selV[1] = __uint_as_float(prefix[1]);
+    }
+    // the order statistics after the two selected ones (x itself if it occurs beyond rank k, else the smallest larger value)
+    // and the masked maximum
+    float mx, nxt[2];
+    {
+        unsigned int le[2] = {0u, 0u};
+        float mn[2] = {3.0e38f, 3.0e38f};
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (tid + 256 * i < M) {
+                const float v = vm[i];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    le[r] += v <= selV[r] ? 1u : 0u;
+                    mn[r] = (v > selV[r] && v < mn[r]) ? v : mn[r];
+                }
+            }
+        }
+        const unsigned int l0 = wave_addu63(le[0]), l1 = wave_addu63(le[1]);
+        const float m0 = wave_min63(mn[0]), m1 = wave_min63(mn[1]), mw = wave_max63(mxT);
+        if (lane == 0) { sWu[w][1] = l0; sWu[w][2] = l1; sWf[w][2] = m0; sWf[w][3] = m1; sWf[w][0] = mw; }
+        __syncthreads();
+        mx = fmaxf(fmaxf(sWf[0][0], sWf[1][0]), fmaxf(sWf[2][0], sWf[3][0]));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned int nLe = sWu[0][1 + r] + sWu[1][1 + r] + sWu[2][1 + r] + sWu[3][1 + r];
+            const float mnr = fminf(fminf(sWf[0][2 + r], sWf[1][2 + r]), fminf(sWf[2][2 + r], sWf[3][2 + r]));
+            nxt[r] = nLe > (unsigned int)(r ? iHi : iLo) + 1u ? selV[r] : mnr;
+        }
+    }
+    // percentiles: lo + (hi - lo) * f with a float difference, as the host expression (and scipy) evaluate it
+    double pLo = (double)selV[0], pHi = (double)selV[1];
+    if (iLo + 1 < M) pLo = (double)selV[0] + (double)(nxt[0] - selV[0]) * fLo;
+    if (iHi + 1 < M) pHi = (double)selV[1] + (double)(nxt[1] - selV[1]) * fHi;
+    double sum = 0.0;
+    unsigned int cnt = 0u;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (tid + 256 * i < M) {
+            const float v = vm[i];
+            if ((double)v > pLo && (double)v < pHi) { sum += (double)v; ++cnt; }
+        }
+    }
+    {
+        const double ws = wave_sumd63(sum);
+        const unsigned int wc = wave_addu63(cnt);
+        const float wd = wave_max63(fmaxf(dmax, 0.f));
+        const unsigned int wi = wave_minu63((dmax == wd && didx != 0xFFFFFFFFu) ? didx : 0xFFFFFFFFu);
+        __syncthreads();   // (the reads of sWf / sWu above)
+        if (lane == 0) { sWd[w] = ws; sWu[w][0] = wc; sWf[w][0] = wd; sWu[w][3] = wi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float dpk = sWf[0][0];
+        for (int q = 1; q < 4; ++q) dpk = fmaxf(dpk, sWf[q][0]);
+        unsigned int di = 0xFFFFFFFFu;
+        for (int q = 0; q < 4; ++q) di = (sWf[q][0] == dpk && sWu[q][3] < di) ? sWu[q][3] : di;
+        codeIdx[p] = ci; doppIdx[p] = (int)di;
+        AcqStats r;
+        r.peak = peak; r.maxRest = mx; r.ci = ci; r.di = (int)di;
+        r.sum = ((sWd[0] + sWd[1]) + sWd[2]) + sWd[3]; r.cnt = (long long)(sWu[0][0] + sWu[1][0] + sWu[2][0] + sWu[3][0]); r.lo = pLo; r.hi = pHi;
+        out[p] = r;
+    }
+}
+
 }  // namespace dpe
 
 struct dpe_acq {
@@ -1075,6 +1356,10 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         // (the kernel's static LDS is ~17 KB: the row joins it only while the sum stays below the 64 KB a launch gets without
         //  an opt-in -- M <= 10 240 -- and is read from memory beyond)
         const int rowInLds = (size_t)M * sizeof(float) <= 40 * 1024 ? 1 : 0;
+        if (M <= 256 * kAcqStatsR && !(getenv("DPE_ACQ_STATS_LDS") && atoi(getenv("DPE_ACQ_STATS_LDS")) != 0))
+            hipLaunchKernelGGL(acq_stats_small_kernel, dim3(P), dim3(256), 0, st, h->surf_d, h->mp_d, B, M, maskS, iLo, posLo - (double)iLo, iHi,
+                               posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P, h->stats_hd);
+        else
         hipLaunchKernelGGL(acq_stats_kernel, dim3(P), dim3(256), rowInLds ? (size_t)M * sizeof(float) : 0, st, h->surf_d, h->mp_d, B, M,
                            rowInLds, maskS, iLo, posLo - (double)iLo, iHi, posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P,
                            h->stats_hd);   // (48 bytes per PRN straight into the pinned mirror: a D2H copy command behind the kernel cost ~5 us of stream time)
