@@ -175,6 +175,7 @@ __device__ __forceinline__ void acq_idft10(af2 (&v)[10])
 }
 }  // namespace dpe
 #include "dpe_acq_pack.h"
+#include "dpe_acq_mixed.h"
 namespace dpe {
 constexpr int kAcqFusedLen = 2500;
 constexpr int kAcqFusedBins = 6;     // bins per block: 21 x 32 blocks are resident at once (three per CU) on 256 CUs
@@ -1133,6 +1134,7 @@ struct dpe_acq {
     float2 *tw_d = nullptr;     // exp(+j 2 pi n / 2500): the fused searches (acq_corr2500_kernel), else null
     float2 *tw25k_d = nullptr;  // exp(+j 2 pi n / 25000): the radix-10 stage of the fused non-coherent search
     bool fused = false, fusedAlias = false;
+    int fusedLen = 2500;        // fused coherent / textbook search: 2 500 (acq_corr2500_kernel) or 4 000 / 5 000 (acq_corr_mixed_kernel, dpe_acq_mixed.h)
     bool fwdPack = true;        // packed form: wipe-off + forward transform in acq_fwd25k_pack_kernel (DPE_ACQ_NO_FWD_PACK=1: wipe kernel + rocFFT + decimation)
     int cus = 256;              // compute units of the device (the packed form launches one persistent block per CU)
     bool packForm = false;      // fusedAlias through acq_corr25k_pack_kernel (dpe_acq_pack.h); DPE_ACQ_NO_PACK=1 keeps acq_radix10_kernel + the four-pass transform (A/B runs)
@@ -1189,7 +1191,7 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     const size_t S = h->SX, B = h->B, P = h->P;
     // coherent / textbook search at 2 500 delays per code period: the fused kernel, which needs neither the product buffer nor
     // the inverse plan (DPE_ACQ_NO_FUSED=1 keeps the rocFFT chain, for A/B runs and as the cross-check of the parity tests)
-    const bool wantFused = (cfg->mode == 0 || cfg->mode == 2) && h->M == kAcqFusedLen && !getenv("DPE_ACQ_NO_FUSED");
+    const bool wantFused = (cfg->mode == 0 || cfg->mode == 2) && (h->M == kAcqFusedLen || h->M == 4000 || h->M == 5000) && !getenv("DPE_ACQ_NO_FUSED");
     // the reference's non-coherent search at 10 x 2 500 samples: radix-10 stage + ten fused 2 500-point transforms per (PRN, bin);
     // the product buffer holds the radix-10 stage's output, no inverse plan
     const bool wantAlias = cfg->mode == 1 && h->M == kAcqFusedLen && h->N == 10 && !getenv("DPE_ACQ_NO_FUSED");
@@ -1276,16 +1278,28 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     }
     h->fusedFwd = !(getenv("DPE_ACQ_NO_FUSED_FWD") && atoi(getenv("DPE_ACQ_NO_FUSED_FWD")) != 0);
     if (!rc && (wantFused || wantAlias)) {
-        std::vector<float2> tw(kAcqFusedLen);
-        for (int n = 0; n < kAcqFusedLen; ++n) {
-            const double a = 6.283185307179586476925286766559 * (double)n / (double)kAcqFusedLen;
+        const int L = h->M;   // (2 500 for wantAlias)
+        std::vector<float2> tw((size_t)L);
+        for (int n = 0; n < L; ++n) {
+            const double a = 6.283185307179586476925286766559 * (double)n / (double)L;
             tw[n] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
-        h->tw_d = dev_alloc<float2>(kAcqFusedLen);
+        h->tw_d = dev_alloc<float2>((size_t)L);
         if (!h->tw_d || hipMemcpy(h->tw_d, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess) {
             set_error("[Acquisition] create: twiddle table");
             rc = -1;
-        } else h->fused = wantFused;
+        } else {
+            h->fused = wantFused;
+            h->fusedLen = L;
+        }
+        if (!rc && wantFused && L != kAcqFusedLen &&
+            (hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<4000, 10, 8, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)AcqMixedShape<4000, 10, 8, 5>::ldsBytes) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<5000, 10, 10, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)AcqMixedShape<5000, 10, 10, 5>::ldsBytes) != hipSuccess)) {
+            set_error("[Acquisition] create: LDS size of the fused search");
+            rc = -1;
+        }
     }
     if (rc) {
         dpe_acq_destroy(h);
@@ -1304,7 +1318,7 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     if (h->packForm && h->fwdPack) {
         hipLaunchKernelGGL(acq_fwd25k_pack_kernel, dim3(B), dim3(512), kPkLdsBytes, st, samples_dev, h->cfg.binStartHz, h->cfg.binStepHz,
                            1.0 / h->cfg.samplingFrequency, h->tw2_d, h->tw25k_d, h->Y_d, h->mp_d, (long long)P * M);
-    } else if (h->fused && h->fusedFwd && h->cfg.mode != 0) {
+    } else if (h->fused && h->fusedLen == kAcqFusedLen && h->fusedFwd && h->cfg.mode != 0) {
         // textbook mode (N rows of 2 500 per bin): wipe-off and the forward transform in one launch, 0.271 -> 0.260 ms per 32-PRN window.
         // (Coherent mode keeps the two launches: one block per bin would have to fold ten periods -- a hundred sin / cos pairs per
         // thread on 125 blocks -- and measured 0.066 against 0.060 ms.)
@@ -1319,7 +1333,17 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                                h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M);
         if (h->planFwd.exec(st, h->X_d)) return -1;
     }
-    if (h->fused)
+    if (h->fused && h->fusedLen != kAcqFusedLen) {
+        // 4 / 5 Msps: the generic four-pass transform (dpe_acq_mixed.h); five bins per block: 25 x 32 blocks, two or three resident per CU
+        const int bpb = 5, nSeg = h->cfg.mode == 0 ? 1 : h->N;
+        constexpr size_t lds4 = AcqMixedShape<4000, 10, 8, 5>::ldsBytes, lds5 = AcqMixedShape<5000, 10, 10, 5>::ldsBytes;
+        if (h->fusedLen == 4000)
+            hipLaunchKernelGGL((acq_corr_mixed_kernel<4000, 10, 8, 5>), dim3((B + bpb - 1) / bpb, P), dim3(400), lds4, st, h->X_d,
+                               h->Rc_d, h->tw_d, B, nSeg, bpb, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+        else
+            hipLaunchKernelGGL((acq_corr_mixed_kernel<5000, 10, 10, 5>), dim3((B + bpb - 1) / bpb, P), dim3(500), lds5, st, h->X_d,
+                               h->Rc_d, h->tw_d, B, nSeg, bpb, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+    } else if (h->fused)
         hipLaunchKernelGGL(acq_corr2500_kernel<false>, dim3((B + kAcqFusedBins - 1) / kAcqFusedBins, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
                            B, h->cfg.mode == 0 ? 1 : h->N, kAcqFusedBins, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {

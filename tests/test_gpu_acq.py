@@ -184,6 +184,59 @@ def test_fused_noncoherent_search_equals_the_rocfft_chain():
     assert {4, 9, 23, 29} <= {r["prn"] for r in r0 if r["found"]}   # (PRN 16, the weakest, stays below cppm = 2 on this raster in both forms)
 
 
+@pytest.mark.parametrize("fs", [4.0e6, 5.0e6])
+@pytest.mark.parametrize("mode", ["coherent", "textbook"])
+def test_fused_search_at_4_and_5_msps(oracle, fs, mode):
+    """Correlator.coarse_acquisition is rate-agnostic (correlator.py:53-103); at 4 000 / 5 000 samples per code period the fused
+    search runs through the generic four-pass transform of csrc/dpe_acq_mixed.h.  Against the oracle (surface within 2e-5 of the
+    peak, same cells, statistics within 1e-4) for present and absent PRNs, and against the rocFFT chain (DPE_ACQ_NO_FUSED=1) on
+    32 PRNs x 31 bins (a short last block of bins): surface within 3e-6 of the peak, identical cells."""
+    import os
+    import torch
+    n_ms = 10
+    S = int(round(fs * 1e-3)) * n_ms
+    present = [6, 13, 21, 27]
+    ch = dpe.synth.random_channels(311, 4, prns=present)
+    step = 100.0 if mode == "coherent" else 500.0
+    bins = (np.arange(31) - 15) * step
+    ch["fi"] = np.array([-3.2, 1.7, 9.4, -11.1]) * step
+    ch["fc"] = 1.023e6 * (1.0 + ch["fi"] / 1.57542e9)
+    ch["cp_ref"] = ch["cp"].copy()
+    iq = dpe.synth.gen_iq(312, fs, S, ch, amp=150.0, flip=np.zeros(4, dtype=bool))
+    d = torch.from_numpy(iq).to("cuda:0")
+    prns = list(range(1, 33))
+    out = {}
+    for form in ("fused", "rocfft"):
+        old = os.environ.get("DPE_ACQ_NO_FUSED")
+        if form == "rocfft":
+            os.environ["DPE_ACQ_NO_FUSED"] = "1"
+        try:
+            acq = dpe.Acquisition(fs, S, prns, bins, mode=mode, prn_chunk=8)
+        finally:
+            if form == "rocfft":
+                if old is None:
+                    os.environ.pop("DPE_ACQ_NO_FUSED", None)
+                else:
+                    os.environ["DPE_ACQ_NO_FUSED"] = old
+        acq.search(d)
+        acq.search(d)
+        out[form] = (acq.results(), acq.read_surface().copy())
+        acq.close()
+    (r0, s0), (r1, s1) = out["fused"], out["rocfft"]
+    assert s0.shape == s1.shape == (32, 31, S // n_ms)
+    assert np.abs(s0 - s1).max() < 3e-6 * s1.max()
+    for a, b in zip(r0, r1):
+        assert a["max_code_idx"] == b["max_code_idx"] and a["max_dopp_idx"] == b["max_dopp_idx"] and a["found"] == b["found"]
+        assert abs(a["cppm"] / b["cppm"] - 1) < 1e-5 and abs(a["cppr"] / b["cppr"] - 1) < 1e-5
+    assert set(present) <= {r["prn"] for r in r0 if r["found"]}
+    for prn in present + [2, 30]:
+        q = prns.index(prn)
+        ref = oracle.coarse_acquisition(iq, fs, prn, bins, coherent=(mode == "coherent"), mode="textbook" if mode == "textbook" else None)
+        assert np.abs(s0[q] - ref["surface"]).max() < 2e-5 * ref["surface"].max()
+        assert (r0[q]["max_code_idx"], r0[q]["max_dopp_idx"]) == (ref["max_code_idx"], ref["max_dopp_idx"])
+        assert abs(r0[q]["cppm"] / ref["cppm"] - 1) < 1e-4 and abs(r0[q]["cppr"] / ref["cppr"] - 1) < 1e-4
+
+
 def test_acq_statistics_with_a_long_delay_row(oracle):
     """16.368 Msps x 1 ms: 16 368 delays per PRN -- the statistics kernel's row no longer fits the LDS a launch gets without an
     opt-in beside its 17 KB of static LDS and is read from memory instead.  Peak cell and statistics against the

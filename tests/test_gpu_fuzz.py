@@ -132,7 +132,7 @@ N_ACQ = int(os.environ.get("DPE_FUZZ_ACQ_CASES", "6"))
 
 def draw_acq(i):
     rng = np.random.Generator(np.random.PCG64(SEED * 7919 + i))
-    fs = float(rng.choice([2.046e6, 2.5e6, 4.0e6]))
+    fs = float(rng.choice([2.046e6, 2.5e6, 4.0e6, 5.0e6]))
     n_ms = int(rng.choice([2, 4, 5, 10]))
     mode = str(rng.choice(["coherent", "noncoherent", "textbook"]))
     present = sorted(int(p) for p in rng.choice(np.arange(1, 33), size=int(rng.integers(1, 5)), replace=False))
@@ -150,7 +150,7 @@ def draw_acq(i):
 @pytest.mark.parametrize("i", range(N_ACQ))
 def test_random_acquisition_case(i):
     """Coarse acquisition vs the oracle's restatement of Correlator.coarse_acquisition: window lengths of 2..10 code
-    periods at three sampling rates, all three modes, random PRN sets (present and absent), rasters and chunk sizes."""
+    periods at four sampling rates, all three modes, random PRN sets (present and absent), rasters and chunk sizes."""
     import torch
     import navlab_dpe_sdr_amd as dpe
     o = helpers._oracle()
