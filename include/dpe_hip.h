@@ -31,8 +31,9 @@ extern "C" {
  * DPE_BCS_NO_CHIP=1 / DPE_BCS_NO_CHIP2=1 (no chip-boundary kernel / not its second form), DPE_BCS_NO_FUSE=1 (single
  * windows run the separate DC-sum kernel), DPE_BCS_FORCE_FFT=1 (full-length FFT form), DPE_BCS_TPB16=n / DPE_BCS_CHIP_TPB=n /
  * DPE_BCS_CHIP2_P=n (tiles or passes per block of the batch / chip kernels), DPE_BCM_NO_POLL=1 (dpe_bcm_results always
- * waits for the stream), DPE_ACQ_NO_FUSED=1 (the coherent acquisition search keeps the rocFFT chain instead of the fused
- * transform kernel), DPE_COMM_TIMEOUT_S (rendezvous time-out).  Ablation switches that skip work (DPE_BCS_CHIP_DBG,
+ * waits for the stream), DPE_ACQ_NO_FUSED=1 (the acquisition searches keep the rocFFT chain instead of the fused transform
+ * kernels), DPE_ACQ_NO_PACK=1 / DPE_ACQ_NO_FWD_PACK=1 (non-coherent search: round 4's radix-10 kernel + four-pass transforms / the forward
+ * transform left to rocFFT), DPE_ACQ_STATS_LDS=1 (peak statistics through the LDS-row kernel also for short rows), DPE_COMM_TIMEOUT_S (rendezvous time-out).  Ablation switches that skip work (DPE_BCS_CHIP_DBG,
  * DPE_BCS_FAT, DPE_BCM_SPLIT) exist only in builds with -DDPE_EXPERIMENTS. */
 #define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
 #define DPE_MAX_LAG_HALF_WIDTH 292  /* widest code-lag bank of the windowed stage-1 kernels: +-32 and four 65-lag chunks per side */
@@ -452,8 +453,9 @@ int dpe_ekf_state(dpe_ekf *h, double *xk1k1, double *xkk1, double *Pk1k1, double
 /* Cold-start coarse acquisition.  Only the reference's Python twin implements it:
  * Correlator.coarse_acquisition, pygnss/pythonreceiver/scalar/correlator.py:53-103 (CUDARecv only
  * forward-declares the classes, cudarecv/dsp/inc/dsp.h:207-209).  Full code-delay x Doppler search
- * with batched FFTs (rocFFT, called directly: csrc/dpe_fft.h) and, for the coherent / textbook searches at 2 500 delays, a fused
- * hand-written transform kernel. */
+ * with hand-written fused transform kernels where the window shape allows -- coherent / textbook searches at 2 500, 4 000 and 5 000
+ * delays per code period (2.5 / 4 / 5 Msps), the reference's non-coherent search at 10 x 2 500 samples -- and batched FFTs (rocFFT,
+ * called directly: csrc/dpe_fft.h) for every other shape. */
 typedef struct dpe_acq dpe_acq;
 typedef struct dpe_acq_config {
     int32_t samplesPerWindow;   /* S = round(T fs), e.g. 25000 for 10 ms at 2.5 Msps (rawfile.py:162) */
