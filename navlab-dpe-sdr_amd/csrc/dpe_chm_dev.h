@@ -394,7 +394,9 @@ __device__ static inline void ekf_dev_mul(const double *a, const double *b, bool
     c[l] = s;
     __syncthreads();
 }
-// inverse through LU with partial pivoting (getrf + getri, cuekf.cu:681-694); false: singular
+// inverse through LU with partial pivoting (getrf + getri, cuekf.cu:681-694); false: singular.  (The pivot search and the two
+// substitutions work on registers: with the candidate row as an LDS address the search was seven dependent round trips per column, and
+// the back substitution re-read its own column of the inverse from LDS -- ~6 us of an 8 x 8 inverse.)
 __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double *inv, int *piv)
 {
 #pragma clang fp contract(off)
@@ -402,11 +404,20 @@ __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double
     lu[l] = a[l];
     if (l < 8) piv[l] = l;
     __syncthreads();
+#pragma unroll 1
     for (int c = 0; c < 8; ++c) {
-        int p = c;   // (every lane finds the same pivot row)
-        for (int q = c + 1; q < 8; ++q)
-            if (fabs(lu[q * 8 + c]) > fabs(lu[p * 8 + c])) p = q;
-        if (lu[p * 8 + c] == 0.0) return false;
+        double col[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) col[q] = lu[q * 8 + c];
+        int p = c;   // (every lane finds the same pivot row: the first largest |.| at or below the diagonal)
+        double best = -1.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double av = fabs(col[q]);
+            if (q == c) best = av;
+            if (q > c && av > best) { best = av; p = q; }
+        }
+        if (best == 0.0) return false;
         __syncthreads();
         if (p != c) {
             if (r == 0) { const double t = lu[p * 8 + kk]; lu[p * 8 + kk] = lu[c * 8 + kk]; lu[c * 8 + kk] = t; }
@@ -420,84 +431,107 @@ __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double
         __syncthreads();
     }
     if (l < 8) {   // one column of the inverse per lane
-        const int col = l;
-        double y[8];
+        const int cl = l;
+        double y[8], x[8];
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
-            double s = (piv[i] == col) ? 1.0 : 0.0;
+            double s = (piv[i] == cl) ? 1.0 : 0.0;
+#pragma unroll
             for (int k = 0; k < i; ++k) s -= lu[i * 8 + k] * y[k];
             y[i] = s;
         }
+#pragma unroll
         for (int i = 7; i >= 0; --i) {
             double s = y[i];
-            for (int k = i + 1; k < 8; ++k) s -= lu[i * 8 + k] * inv[k * 8 + col];
-            inv[i * 8 + col] = s / lu[i * 8 + i];
+#pragma unroll
+            for (int k = i + 1; k < 8; ++k) s -= lu[i * 8 + k] * x[k];
+            x[i] = s / lu[i * 8 + i];
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) inv[i * 8 + cl] = x[i];
     }
     __syncthreads();
     return true;
 }
 // StepUpdate (:660-721) with the measurement z and R = I as BatchCorrManifold emits it (:2003-2011), then StepPredict (:626-656).
-// Leaves x_k|k in xOut1 and x_k+1|k in xOutK (LDS or global), returns false when S is singular (state untouched).
+// Returns false when S is singular (state untouched).  sm: kEkfDevScratch doubles of LDS.  The filter's operands (H, F, P, x, the speed
+// average's taps) are staged in LDS once: read from device memory by every product they were a chain of ~1 us round trips in a kernel
+// of 64 threads (twelve products and three dependent loads for the speed average: 7.3 of the window's 47 us).
+constexpr int kEkfDevScratch = 11 * 64, kEkfDevXk = 640, kEkfDevX1 = 648;   // (x_k+1|k and x_k|k stay at these offsets of the scratch)
 __device__ static inline bool ekf_dev_step(EkfDev *e, const double *z, double *sm, int *piv)
 {
 #pragma clang fp contract(off)
     const int l = threadIdx.x;
     double *T = sm, *S = sm + 64, *Sinv = sm + 128, *lu = sm + 192, *y = sm + 256, *tmp = sm + 320;
+    double *H = sm + 384, *F = sm + 448, *P = sm + 512, *P1 = sm + 576, *xk = sm + 640, *x1 = sm + 648, *lpf = sm + 656, *lpfAvgS = sm + 676;
+    H[l] = e->H[l];
+    F[l] = e->F[l];
+    P[l] = e->Pkk1[l];
+    if (l < 8) xk[l] = e->xkk1[l];
+    if (l < 20) lpf[l] = e->lpfVals[l];
+    int lpfIdx = 0;
+    double lpfAvg = 0.0;
+    if (l == 0) { lpfIdx = e->lpfIdx; lpfAvg = e->lpfAvg; }
+    __syncthreads();
     if (l < 8) {                                                   // y = z - H x_k|k-1
         double s = z[l];
-        for (int k = 0; k < 8; ++k) s -= e->H[l * 8 + k] * e->xkk1[k];
+        for (int k = 0; k < 8; ++k) s -= H[l * 8 + k] * xk[k];
         y[l] = s;
     }
-    ekf_dev_mul(e->H, e->Pkk1, false, T);                          // S = H P H^T + R
-    ekf_dev_mul(T, e->H, true, S);
+    ekf_dev_mul(H, P, false, T);                                   // S = H P H^T + R
+    ekf_dev_mul(T, H, true, S);
     S[l] += (l % 9 == 0) ? 1.0 : 0.0;
     __syncthreads();
     if (!ekf_dev_invert(S, lu, Sinv, piv)) return false;
-    ekf_dev_mul(e->Pkk1, e->H, true, T);                           // K = P H^T S^-1
+    ekf_dev_mul(P, H, true, T);                                    // K = P H^T S^-1
     ekf_dev_mul(T, Sinv, false, tmp);
     e->K[l] = tmp[l];
     __syncthreads();
     if (l < 8) {                                                   // x_k|k = x_k|k-1 + K y
-        double s = e->xkk1[l];
+        double s = xk[l];
         for (int k = 0; k < 8; ++k) s += tmp[l * 8 + k] * y[k];
+        x1[l] = s;
         e->xk1k1[l] = s;
     }
-    ekf_dev_mul(tmp, e->H, false, T);                              // P_k|k = (I - K H) P_k|k-1
+    ekf_dev_mul(tmp, H, false, T);                                 // P_k|k = (I - K H) P_k|k-1
     T[l] = -T[l];
     if (l % 9 == 0) T[l] += 1.0;
     __syncthreads();
-    ekf_dev_mul(T, e->Pkk1, false, tmp);
-    e->Pk1k1[l] = tmp[l];
-    __syncthreads();
+    ekf_dev_mul(T, P, false, P1);
+    e->Pk1k1[l] = P1[l];
     // ---- StepPredict with GetQVal (:733-742) and EKF_Update_Q (:42-78)
     if (l == 0) {
-        const double *x = e->xk1k1;
-        const double v = sqrt(x[4] * x[4] + x[5] * x[5] + x[6] * x[6]);
-        e->lpfAvg = e->lpfAvg - e->lpfVals[e->lpfIdx] + (v / 20.0);
-        e->lpfVals[e->lpfIdx] = v / 20.0;
-        if (++e->lpfIdx >= 20) e->lpfIdx = 0;
+        const double v = sqrt(x1[4] * x1[4] + x1[5] * x1[5] + x1[6] * x1[6]);
+        lpfAvg = lpfAvg - lpf[lpfIdx] + (v / 20.0);
+        e->lpfVals[lpfIdx] = v / 20.0;
+        e->lpfAvg = lpfAvg;
+        lpfAvgS[0] = lpfAvg;
+        if (++lpfIdx >= 20) lpfIdx = 0;
+        e->lpfIdx = lpfIdx;
     }
     __syncthreads();
     {
-        const double q = 1.0 + 250.0 / fmin(fmax(e->lpfAvg * e->lpfAvg, 50.0), 125.0);
+        const double av = lpfAvgS[0];
+        const double q = 1.0 + 250.0 / fmin(fmax(av * av, 50.0), 125.0);
         double q0 = 0.0;
         if (l == 4 * 8 + 4 || l == 5 * 8 + 5 || l == 6 * 8 + 6) q0 = q;
         if (l == 7 * 8 + 7) q0 = (2.5e-10) * (2.5e-10) * kC * kC;   // Q_CLOCK_DRIFT, cuekf.h:28
         S[l] = q0;                                                 // (S is free again: Q0)
     }
     __syncthreads();
-    ekf_dev_mul(e->F, S, false, T);                                // Q = F Q0 F^T
-    ekf_dev_mul(T, e->F, true, tmp);
-    e->Q[l] = tmp[l];
-    __syncthreads();
+    ekf_dev_mul(F, S, false, T);                                   // Q = F Q0 F^T
+    ekf_dev_mul(T, F, true, tmp);
+    const double qv = tmp[l];
+    e->Q[l] = qv;
     if (l < 8) {                                                   // x_k+1|k = F x_k|k
         double s = 0.0;
-        for (int k = 0; k < 8; ++k) s += e->F[l * 8 + k] * e->xk1k1[k];
+        for (int k = 0; k < 8; ++k) s += F[l * 8 + k] * x1[k];
+        xk[l] = s;                                                 // (left in the scratch for the caller: kEkfDevXk)
         e->xkk1[l] = s;
     }
-    ekf_dev_mul(e->F, e->Pk1k1, false, T);                         // P_k+1|k = F P F^T + Q
-    ekf_dev_mul(T, e->F, true, S);
-    e->Pkk1[l] = S[l] + e->Q[l];
+    ekf_dev_mul(F, P1, false, T);                                  // P_k+1|k = F P F^T + Q
+    ekf_dev_mul(T, F, true, S);
+    e->Pkk1[l] = S[l] + qv;
     __syncthreads();
     return true;
 }
@@ -505,7 +539,7 @@ __device__ static inline bool ekf_dev_step(EkfDev *e, const double *z, double *s
 __device__ static inline void chm_k1(const ChmKArgs &a)
 {
     __shared__ double sX1[8], sXk[8], sZ[8];   // x_k|k, x_k+1|k, the measurement
-    __shared__ double sEkf[6 * 64];
+    __shared__ double sEkf[kEkfDevScratch];
     __shared__ int sPiv[8];
     __shared__ int sFlags;
     ChmDevState *st = a.st;
@@ -549,7 +583,7 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
         const bool ok = sFlags == 0 && ekf_dev_step(a.ekf, sZ, sEkf, sPiv);
         __syncthreads();
         if (k < 8) {
-            if (ok) { sX1[k] = a.ekf->xk1k1[k]; sXk[k] = a.ekf->xkk1[k]; }
+            if (ok) { sX1[k] = sEkf[kEkfDevX1 + k]; sXk[k] = sEkf[kEkfDevXk + k]; }
             else { sX1[k] = a.p.xkk1[k]; sXk[k] = a.p.xkk1[k]; }   // (no measurement, or S singular: hold the predicted state)
         }
         if (!ok && k == 0 && sFlags == 0) { atomicOr(&sFlags, 32); a.ekf->failed = 1; }
