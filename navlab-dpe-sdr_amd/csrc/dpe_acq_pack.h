@@ -184,17 +184,27 @@ __global__ __launch_bounds__(512) void acq_fwd25k_pack_kernel(const int16_t *__r
     const bool act = tid < 500;
     const int L = act ? tid : 499, q = L / 50, a = L - 50 * q;
     af2 Z[50];
+    int rawN[10];   // the next chunk's samples, requested a chunk ahead (one exposed memory latency instead of five)
+#pragma unroll
+    for (int m = 0; m < 10; ++m) rawN[m] = x[(act ? tid : 0) + 2500 * m];
     __syncthreads();   // (the tables)
 #pragma unroll
     for (int ch = 0; ch < 5; ++ch) {
         float2 *E = acqPkLds + (ch & 1) * 5000;   // [q][500]
+        int rawC[10];
+#pragma unroll
+        for (int m = 0; m < 10; ++m) rawC[m] = rawN[m];
+        if (ch < 4) {
+#pragma unroll
+            for (int m = 0; m < 10; ++m) rawN[m] = x[500 * (ch + 1) + (act ? tid : 0) + 2500 * m];
+        }
         if (act) {
             const int n1 = 500 * ch + tid;
             af2 v[10];
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
                 const int i = n1 + 2500 * m;
-                const int raw = x[i];
+                const int raw = rawC[m];
                 const float re = (float)(short)(raw & 0xFFFF), im = (float)(raw >> 16);
                 double ph = cyclesPerSample * (double)i;
                 ph -= floor(ph);
