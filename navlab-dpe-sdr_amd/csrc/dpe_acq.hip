@@ -456,9 +456,9 @@ __global__ __launch_bounds__(512) void acq_wipe_fft2500_kernel(const int16_t *__
 // buffer it transformed in place and the fold pass over it are replaced by this kernel and ten 2 500-point transforms per
 // (PRN, bin) in acq_corr2500_kernel<true>.
 __global__ __launch_bounds__(256) void acq_radix10_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc, const float2 *__restrict__ tw25k,
-                                                         int B, float2 *__restrict__ Z)
+                                                         int B, int M, float2 *__restrict__ Z)   // (M = 2 500, or 4 000 / 5 000 with tw25k = exp(+j 2 pi n / 10 M))
 {
-    constexpr int M = kAcqFusedLen, S = 10 * kAcqFusedLen;
+    const int S = 10 * M;
     const int m = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, p = blockIdx.z;
     if (m >= M) return;
     const float2 *x = X + (size_t)b * S + m, *r = Rc + (size_t)p * S + m;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void acq_radix10_kernel(const float2 *__restri
     for (int k0 = 0; k0 < 10; ++k0) {
         af2 y = v[k0];
         if (k0) {
-            const float2 w = tw25k[m * k0];   // m k0 <= 2499 * 9 < 25000
+            const float2 w = tw25k[m * k0];   // m k0 <= (M - 1) * 9 < 10 M
             y = acq_cmul(y, af2{w.x, w.y});
         }
         // (streaming store: the 800 MB of Z written per 32 x 125 search must not push X and Rc -- re-read by every block -- out of L2)
@@ -1194,10 +1194,10 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     const bool wantFused = (cfg->mode == 0 || cfg->mode == 2) && (h->M == kAcqFusedLen || h->M == 4000 || h->M == 5000) && !getenv("DPE_ACQ_NO_FUSED");
     // the reference's non-coherent search at 10 x 2 500 samples: radix-10 stage + ten fused 2 500-point transforms per (PRN, bin);
     // the product buffer holds the radix-10 stage's output, no inverse plan
-    const bool wantAlias = cfg->mode == 1 && h->M == kAcqFusedLen && h->N == 10 && !getenv("DPE_ACQ_NO_FUSED");
+    const bool wantAlias = cfg->mode == 1 && (h->M == kAcqFusedLen || h->M == 4000 || h->M == 5000) && h->N == 10 && !getenv("DPE_ACQ_NO_FUSED");
     h->X_d = dev_alloc<float2>(B * S);
     h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
-    const bool wantPack = wantAlias && !(getenv("DPE_ACQ_NO_PACK") && atoi(getenv("DPE_ACQ_NO_PACK")) != 0);
+    const bool wantPack = wantAlias && h->M == kAcqFusedLen && !(getenv("DPE_ACQ_NO_PACK") && atoi(getenv("DPE_ACQ_NO_PACK")) != 0);
     h->Y_d = dev_alloc<float2>(wantFused ? 1 : wantPack ? B * S : (size_t)h->chunk * B * S);   // (packed form: the bins' decimated spectra)
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
@@ -1242,9 +1242,9 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     int rc = finish();
     pr.destroy();
     if (!rc && wantAlias) {
-        std::vector<float2> tw(10 * kAcqFusedLen);
-        for (int n = 0; n < 10 * kAcqFusedLen; ++n) {
-            const double a = 6.283185307179586476925286766559 * (double)n / (double)(10 * kAcqFusedLen);
+        std::vector<float2> tw((size_t)10 * h->M);
+        for (int n = 0; n < 10 * h->M; ++n) {
+            const double a = 6.283185307179586476925286766559 * (double)n / (double)(10 * h->M);
             tw[n] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
         h->tw25k_d = dev_alloc<float2>(tw.size());
@@ -1292,10 +1292,14 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             h->fused = wantFused;
             h->fusedLen = L;
         }
-        if (!rc && wantFused && L != kAcqFusedLen &&
-            (hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<4000, 10, 8, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (!rc && L != kAcqFusedLen &&
+            (hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<4000, 10, 8, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)AcqMixedShape<4000, 10, 8, 5>::ldsBytes) != hipSuccess ||
-             hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<5000, 10, 10, 5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+             hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<5000, 10, 10, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)AcqMixedShape<5000, 10, 10, 5>::ldsBytes) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<4000, 10, 8, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)AcqMixedShape<4000, 10, 8, 5>::ldsBytes) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr_mixed_kernel<5000, 10, 10, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)AcqMixedShape<5000, 10, 10, 5>::ldsBytes) != hipSuccess)) {
             set_error("[Acquisition] create: LDS size of the fused search");
             rc = -1;
@@ -1338,11 +1342,11 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         const int bpb = 5, nSeg = h->cfg.mode == 0 ? 1 : h->N;
         constexpr size_t lds4 = AcqMixedShape<4000, 10, 8, 5>::ldsBytes, lds5 = AcqMixedShape<5000, 10, 10, 5>::ldsBytes;
         if (h->fusedLen == 4000)
-            hipLaunchKernelGGL((acq_corr_mixed_kernel<4000, 10, 8, 5>), dim3((B + bpb - 1) / bpb, P), dim3(400), lds4, st, h->X_d,
-                               h->Rc_d, h->tw_d, B, nSeg, bpb, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+            hipLaunchKernelGGL((acq_corr_mixed_kernel<4000, 10, 8, 5, false>), dim3((B + bpb - 1) / bpb, P), dim3(400), lds4, st, h->X_d,
+                               h->Rc_d, h->tw_d, B, nSeg, bpb, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
         else
-            hipLaunchKernelGGL((acq_corr_mixed_kernel<5000, 10, 10, 5>), dim3((B + bpb - 1) / bpb, P), dim3(500), lds5, st, h->X_d,
-                               h->Rc_d, h->tw_d, B, nSeg, bpb, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+            hipLaunchKernelGGL((acq_corr_mixed_kernel<5000, 10, 10, 5, false>), dim3((B + bpb - 1) / bpb, P), dim3(500), lds5, st, h->X_d,
+                               h->Rc_d, h->tw_d, B, nSeg, bpb, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     } else if (h->fused)
         hipLaunchKernelGGL(acq_corr2500_kernel<false>, dim3((B + kAcqFusedBins - 1) / kAcqFusedBins, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
                            B, h->cfg.mode == 0 ? 1 : h->N, kAcqFusedBins, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
@@ -1357,10 +1361,19 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         }
         if (h->fusedAlias) {
             hipLaunchKernelGGL(acq_radix10_kernel, dim3((M + 255) / 256, B, pc), dim3(256), 0, st, h->X_d, h->Rc_d + (size_t)p0 * h->len, h->tw25k_d,
-                               B, h->Y_d);
+                               B, M, h->Y_d);
             // one bin per block: 10 transforms each, B x pc blocks (25 x 32 = 800 at the reference's raster: one round of the chip)
-            hipLaunchKernelGGL(acq_corr2500_kernel<true>, dim3(B, pc), dim3(256), 0, st, h->Y_d, (const float2 *)nullptr, h->tw_d, B, h->N, 1, p0,
-                               h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+            if (M == 4000) {
+                constexpr size_t lds4 = AcqMixedShape<4000, 10, 8, 5>::ldsBytes;
+                hipLaunchKernelGGL((acq_corr_mixed_kernel<4000, 10, 8, 5, true>), dim3(B, pc), dim3(400), lds4, st, h->Y_d, (const float2 *)nullptr, h->tw_d, B, h->N, 1, p0,
+                                   h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+            } else if (M == 5000) {
+                constexpr size_t lds5 = AcqMixedShape<5000, 10, 10, 5>::ldsBytes;
+                hipLaunchKernelGGL((acq_corr_mixed_kernel<5000, 10, 10, 5, true>), dim3(B, pc), dim3(500), lds5, st, h->Y_d, (const float2 *)nullptr, h->tw_d, B, h->N, 1, p0,
+                                   h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+            } else
+                hipLaunchKernelGGL(acq_corr2500_kernel<true>, dim3(B, pc), dim3(256), 0, st, h->Y_d, (const float2 *)nullptr, h->tw_d, B, h->N, 1, p0,
+                                   h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
             continue;
         }
         hipLaunchKernelGGL(acq_mul_kernel, dim3((S + 1023) / 1024, B, pc), dim3(256), 0, st, h->X_d,

@@ -47,9 +47,13 @@ struct AcqMixedShape {
 
 // nSeg = 1: X[b][M] holds the time-folded window (coherent mode); nSeg = N: X[b][N][M] the N code periods (textbook mode), magnitudes
 // summed in registers before they go out -- as acq_corr2500_kernel<false>.  tw = exp(+j 2 pi n / M), M entries.
-template <int M, int R2, int R3, int R4>
+// ALIAS (the reference's coherent = False at 10 x M samples, correlator.py:77-82): X = Z[p][b][k0][M], the output of acq_radix10_kernel -- product and
+// first decimation-in-frequency stage of the 10 M-point transform already applied -- nSeg = 10 transforms per (PRN, bin), no multiply; the ten lag
+// aliases of delay j = 10 r + k0 are the outputs r + (M / 10) n of transform k0: their magnitudes are summed and written at stride 10 (as
+// acq_corr2500_kernel<true>).  pOffset: first PRN of the chunk Z holds.
+template <int M, int R2, int R3, int R4, bool ALIAS>
 __global__ __launch_bounds__(M / 10) __attribute__((amdgpu_waves_per_eu(4))) void acq_corr_mixed_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc, const float2 *__restrict__ tw, int B,
-                                                                int nSeg, int binsPerBlock, float *__restrict__ surf, unsigned int *__restrict__ mpBits)
+                                                                int nSeg, int binsPerBlock, int pOffset, float *__restrict__ surf, unsigned int *__restrict__ mpBits)
 {
     using Sh = AcqMixedShape<M, R2, R3, R4>;
     constexpr int T = Sh::T, L2 = Sh::L2, L3 = Sh::L3, NB4 = Sh::NB4;
@@ -60,11 +64,14 @@ __global__ __launch_bounds__(M / 10) __attribute__((amdgpu_waves_per_eu(4))) voi
     for (int n = t; n < L2; n += T) sW2[n] = tw[(M / L2) * n];
     for (int n = t; n < L3; n += T) sW3[n] = tw[(M / L3) * n];
     // the PRN's spectrum and the pass-1 twiddles W_M^(t k) of this thread's ten elements stay in registers across the bins
-    af2 rc[10], w1[10];
+    af2 rc[ALIAS ? 1 : 10], w1[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
-        const float2 r = Rc[(size_t)p * M + t + T * q], a = tw[t * q];   // t k <= (M / 10 - 1) * 9 < M
-        rc[q] = af2{r.x, r.y};
+        if constexpr (!ALIAS) {
+            const float2 r = Rc[(size_t)p * M + t + T * q];
+            rc[q] = af2{r.x, r.y};
+        }
+        const float2 a = tw[t * q];   // t k <= (M / 10 - 1) * 9 < M
         w1[q] = af2{a.x, a.y};
     }
     float mx[10], macc[NB4 * R4];
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(M / 10) __attribute__((amdgpu_waves_per_eu(4))) voi
     const int b0 = blockIdx.x * binsPerBlock;
     const int nb = (B - b0) < binsPerBlock ? (B - b0) : binsPerBlock;
     const int nTr = nb * nSeg;
-    const float2 *x0 = X + (size_t)b0 * nSeg * M;
+    const float2 *x0 = X + ((ALIAS ? (size_t)p * B : (size_t)0) + (size_t)b0) * nSeg * M;
     float2 xn[10];   // the next transform's spectrum, fetched under this one
 #pragma unroll
     for (int q = 0; q < 10; ++q) xn[q] = x0[t + T * q];
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(M / 10) __attribute__((amdgpu_waves_per_eu(4))) voi
         {   // spectrum product (correlator.py:75) and pass 1: radix 10 over the stride-M/10 elements, twiddle W_M^(t k)
             af2 v[10];
 #pragma unroll
-            for (int q = 0; q < 10; ++q) v[q] = acq_cmul(af2{xn[q].x, xn[q].y}, rc[q]);
+            for (int q = 0; q < 10; ++q) v[q] = ALIAS ? af2{xn[q].x, xn[q].y} : acq_cmul(af2{xn[q].x, xn[q].y}, rc[ALIAS ? 0 : q]);
             if (e + 1 < nTr) {
 #pragma unroll
                 for (int q = 0; q < 10; ++q) xn[q] = x0[(size_t)(e + 1) * M + t + T * q];
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(M / 10) __attribute__((amdgpu_waves_per_eu(4))) voi
             }
         }
         __syncthreads();
-        const bool last = seg == nSeg - 1;   // block-uniform
+        const bool last = ALIAS || seg == nSeg - 1;   // block-uniform
         // pass 4: the last radix, no twiddle; position sub R4 + k with sub = k1 R2 R3 + k2 R3 + k3 holds output k1 + 10 (k2 + R2 (k3 + R3 k))
 #pragma unroll
         for (int h = 0; h < NB4; ++h) {
@@ -152,12 +159,19 @@ __global__ __launch_bounds__(M / 10) __attribute__((amdgpu_waves_per_eu(4))) voi
 #pragma unroll
             for (int k = 0; k < R4; ++k) {
                 const float mg = __builtin_amdgcn_sqrtf(d[k].x * d[k].x + d[k].y * d[k].y);   // | . |  (correlator.py:80)
-                macc[h * R4 + k] = seg == 0 ? mg : macc[h * R4 + k] + mg;
+                macc[h * R4 + k] = (ALIAS || seg == 0) ? mg : macc[h * R4 + k] + mg;
                 if (last) sMag[n0 + 10 * R2 * R3 * k] = macc[h * R4 + k];
             }
         }
         __syncthreads();   // (also orders this pass's reads of sA before the next transform's pass-1 writes)
-        if (last) {
+        if constexpr (ALIAS) {
+            float sv = 0.f;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) sv += sMag[t + T * q];   // the ten lag aliases of delay 10 t + seg (correlator.py:80-82)
+            surf[((size_t)(pOffset + p) * B + b) * M + 10 * t + seg] = sv;
+            atomicMax(&mpBits[(size_t)(pOffset + p) * M + 10 * t + seg], __float_as_uint(sv));   // max over the bins (:87)
+            if (++seg == nSeg) { seg = 0; ++b; }
+        } else if (last) {
             float *o = surf + ((size_t)p * B + b) * M;
 #pragma unroll
             for (int q = 0; q < 10; ++q) {
@@ -169,8 +183,10 @@ __global__ __launch_bounds__(M / 10) __attribute__((amdgpu_waves_per_eu(4))) voi
             // (sMag is rewritten only after the next transform's three barriers)
         } else ++seg;
     }
+    if constexpr (!ALIAS) {
 #pragma unroll
-    for (int q = 0; q < 10; ++q) atomicMax(&mpBits[(size_t)p * M + t + T * q], __float_as_uint(mx[q]));   // max over the bins (:87)
+        for (int q = 0; q < 10; ++q) atomicMax(&mpBits[(size_t)p * M + t + T * q], __float_as_uint(mx[q]));   // max over the bins (:87)
+    }
 }
 
 }  // namespace dpe

@@ -185,10 +185,11 @@ def test_fused_noncoherent_search_equals_the_rocfft_chain():
 
 
 @pytest.mark.parametrize("fs", [4.0e6, 5.0e6])
-@pytest.mark.parametrize("mode", ["coherent", "textbook"])
+@pytest.mark.parametrize("mode", ["coherent", "textbook", "noncoherent"])
 def test_fused_search_at_4_and_5_msps(oracle, fs, mode):
     """Correlator.coarse_acquisition is rate-agnostic (correlator.py:53-103); at 4 000 / 5 000 samples per code period the fused
-    search runs through the generic four-pass transform of csrc/dpe_acq_mixed.h.  Against the oracle (surface within 2e-5 of the
+    search runs through the generic four-pass transform of csrc/dpe_acq_mixed.h (the reference's non-coherent mode: radix-10 kernel
+    + ten such transforms per (PRN, bin)).  Against the oracle (surface within 2e-5 of the
     peak, same cells, statistics within 1e-4) for present and absent PRNs, and against the rocFFT chain (DPE_ACQ_NO_FUSED=1) on
     32 PRNs x 31 bins (a short last block of bins): surface within 3e-6 of the peak, identical cells."""
     import os
@@ -228,13 +229,15 @@ def test_fused_search_at_4_and_5_msps(oracle, fs, mode):
     for a, b in zip(r0, r1):
         assert a["max_code_idx"] == b["max_code_idx"] and a["max_dopp_idx"] == b["max_dopp_idx"] and a["found"] == b["found"]
         assert abs(a["cppm"] / b["cppm"] - 1) < 1e-5 and abs(a["cppr"] / b["cppr"] - 1) < 1e-5
-    assert set(present) <= {r["prn"] for r in r0 if r["found"]}
+    if mode != "noncoherent":   # (the magnitude sum over ten aliases raises the floor: a PRN between two 500 Hz bins stays below cppm = 2 in both forms and in the oracle)
+        assert set(present) <= {r["prn"] for r in r0 if r["found"]}
     for prn in present + [2, 30]:
         q = prns.index(prn)
         ref = oracle.coarse_acquisition(iq, fs, prn, bins, coherent=(mode == "coherent"), mode="textbook" if mode == "textbook" else None)
         assert np.abs(s0[q] - ref["surface"]).max() < 2e-5 * ref["surface"].max()
         assert (r0[q]["max_code_idx"], r0[q]["max_dopp_idx"]) == (ref["max_code_idx"], ref["max_dopp_idx"])
         assert abs(r0[q]["cppm"] / ref["cppm"] - 1) < 1e-4 and abs(r0[q]["cppr"] / ref["cppr"] - 1) < 1e-4
+        assert r0[q]["found"] == ref["found"]
 
 
 def test_acq_statistics_with_a_long_delay_row(oracle):
