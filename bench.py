@@ -200,8 +200,10 @@ def acq_line(modes=("coherent", "textbook", "noncoherent"), cpu_budget_s=5.0):
                                   "(BASELINE.json configs[4])", "mode": modes[0], "prns": len(prns), "bins": int(bins.size), "delays": M},
            "x_realtime": 10.0 / ms0, "modes": per_mode, "found": found,
            "roofline": {"bound": "hbm", "bound_physical": "the fused transform kernel's VALU / LDS work and the one-block-per-PRN statistics chain",
-                        "kernel": "dpe_acq_search (acq_wipe[_fold] + rocFFT fwd + acq_corr2500 [product, 2500-point inverse "
-                                  "transforms, |.| summed over the code periods in the textbook mode, column max] + acq_stats)",
+                        "kernel": "dpe_acq_search (coherent / textbook: acq_wipe[_fold] + forward transform + acq_corr2500 [product, 2500-point "
+                                  "inverse transforms, |.| summed over the code periods in the textbook mode, column max]; non-coherent: "
+                                  "acq_fwd25k_pack + acq_corr25k_pack [ten packed 2500-point transforms per (PRN, bin), ten-point stage, alias sums]; "
+                                  "+ acq_stats_small)",
                         "achieved": alg_bytes / (ms0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / (ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms0,
