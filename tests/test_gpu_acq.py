@@ -317,3 +317,33 @@ def test_o9_fine_frequency_and_two_window_driver(golden):
         d = abs(r["ri"] - g["final"][i, 1])
         assert min(d, 1.0 - d) < 2e-5
     acq.close()
+
+
+@pytest.mark.parametrize("fs", [4.0e6, 5.0e6])
+def test_search_signal_at_4_and_5_msps(oracle, fs):
+    """Correlator.search_signal (correlator.py:38-51: coarse, then fine frequency) away from the reference's rate: the fused coarse
+    search of csrc/dpe_acq_mixed.h feeding the fine-frequency stage (zero-padded 8 << S.bit_length() point FFT).  Against the
+    oracle: same coarse cell, same fine FFT bin (hence rc / fi / fc exact), ri within 2e-5 cycles, statistics within 2e-4."""
+    import torch
+    S = int(round(fs * 1e-2))
+    present = [5, 14, 23]
+    ch = dpe.synth.random_channels(411, 3, prns=present)
+    bins = (np.arange(41) - 20) * 100.0
+    ch["fi"] = np.array([-1234.0, 310.0, 1777.0])
+    ch["fc"] = 1.023e6 * (1.0 + ch["fi"] / 1.57542e9)
+    ch["cp_ref"] = ch["cp"].copy()
+    iq = dpe.synth.gen_iq(412, fs, S, ch, amp=150.0, flip=np.zeros(3, dtype=bool))
+    prns = present + [9]
+    acq = dpe.Acquisition(fs, S, prns, bins, mode="coherent")
+    got = acq.search_signal(torch.from_numpy(iq).to("cuda:0"))
+    acq.close()
+    for r, prn in zip(got, prns):
+        ref = oracle.search_signal(iq, fs, prn, bins=bins, coherent=True)
+        assert r["found"] == ref["found"] and (prn not in present or r["found"])
+        assert (r["max_code_idx"], r["max_dopp_idx"]) == (ref["max_code_idx"], ref["max_dopp_idx"])
+        assert r["max_carr_idx"] == ref["max_carr_idx"]
+        assert abs(r["rc"] - ref["rc"]) < 1e-9 and abs(r["fi"] - ref["fi"]) < 1e-9 and abs(r["fc"] - ref["fc"]) < 1e-6
+        d = abs(r["ri"] - ref["ri"])
+        assert min(d, 1.0 - d) < 2e-5
+        assert abs(r["cppr"] / ref["cppr"] - 1) < 2e-4 and abs(r["cppm"] / ref["cppm"] - 1) < 2e-4
+
