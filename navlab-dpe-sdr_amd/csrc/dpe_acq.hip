@@ -1338,8 +1338,10 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         if (h->planFwd.exec(st, h->X_d)) return -1;
     }
     if (h->fused && h->fusedLen != kAcqFusedLen) {
-        // 4 / 5 Msps: the generic four-pass transform (dpe_acq_mixed.h); five bins per block: 25 x 32 blocks, two or three resident per CU
-        const int bpb = 5, nSeg = h->cfg.mode == 0 ? 1 : h->N;
+        // 4 / 5 Msps: the generic four-pass transform (dpe_acq_mixed.h), two blocks resident per CU; bins per block measured over 1 .. 8
+        // (profiles/r5_ab_acq_rates.txt)
+        const int nSeg = h->cfg.mode == 0 ? 1 : h->N;
+        const int bpb = h->cfg.mode == 0 ? 8 : 4;   // 16 x 32 = 512 blocks = one round at two per CU / 32 x 32 = two rounds of ten transforms per bin
         constexpr size_t lds4 = AcqMixedShape<4000, 10, 8, 5>::ldsBytes, lds5 = AcqMixedShape<5000, 10, 10, 5>::ldsBytes;
         if (h->fusedLen == 4000)
             hipLaunchKernelGGL((acq_corr_mixed_kernel<4000, 10, 8, 5, false>), dim3((B + bpb - 1) / bpb, P), dim3(400), lds4, st, h->X_d,
@@ -1347,9 +1349,14 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         else
             hipLaunchKernelGGL((acq_corr_mixed_kernel<5000, 10, 10, 5, false>), dim3((B + bpb - 1) / bpb, P), dim3(500), lds5, st, h->X_d,
                                h->Rc_d, h->tw_d, B, nSeg, bpb, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
-    } else if (h->fused)
-        hipLaunchKernelGGL(acq_corr2500_kernel<false>, dim3((B + kAcqFusedBins - 1) / kAcqFusedBins, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
-                           B, h->cfg.mode == 0 ? 1 : h->N, kAcqFusedBins, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+    } else if (h->fused) {
+        // bins per block: six in the coherent mode (672 blocks = one round of the 768 resident ones); ONE in the textbook mode, whose blocks
+        // already run ten transforms per bin -- 4 000 short blocks balance the tail (0.229 -> 0.206 ms per 32 x 125 search; five bins per
+        // block, 800 blocks = one round plus 32 stragglers, measured 0.265)
+        const int bpb = h->cfg.mode == 0 ? kAcqFusedBins : 1;
+        hipLaunchKernelGGL(acq_corr2500_kernel<false>, dim3((B + bpb - 1) / bpb, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
+                           B, h->cfg.mode == 0 ? 1 : h->N, bpb, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
+    }
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
         if (h->packForm) {
