@@ -9,7 +9,7 @@
 //   sub LS + tt + (LS / R) q;  output k is multiplied by W_LS^(tt k) and stored at sub LS + tt + (LS / R) k.
 //   After the last pass position p = k1 (M / R1) + k2 (M / (R1 R2)) + k3 R4 + k4 holds output k1 + R1 (k2 + R2 (k3 + R3 k4)): the last
 //   pass knows every output's natural index and writes the magnitudes in natural order.
-// (Index scheme checked against numpy.fft.ifft in fp64 before it was written in HIP: scratch/mixed_proto.py, 2e-13.)  The tuned 2 500-point
+// (Index scheme checked against numpy.fft.ifft in fp64 before it was written in HIP: scripts/proto/acq_mixed_radix_proto.py, 2e-13.)  The tuned 2 500-point
 // kernel (acq_corr2500_kernel: padded sub-sequence strides, ping-pong buffers) stays for the reference's rate.
 #pragma once
 
