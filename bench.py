@@ -43,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak, 256 CUs x 128 lanes x 2 flop x 2.4 GHz
 
 # What physically limits each kernel (rocprofv3 SQ counters, profiles/*_sq_counters.json): none of them
 # is HBM-bound -- the "hbm" roofline below is SURVEY 8(d)'s algorithmic-bytes convention, not the physical limiter.
@@ -65,23 +66,29 @@ def pmc_traffic(config, windows, kernel):
     return None, None
 
 
-def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0):
+def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0, all_cores=True, windows=None):
     """Oracle (fp64 port of the reference algorithm: FFT BatchCorrScores in numpy + C grid scan) timed on the host,
-    on whole windows of the same workload: one thread (the contract's cpu_baseline), then one process per usable
-    core over independent windows, with the host description beside them."""
+    on whole windows of the same workload: one thread (the contract's cpu_baseline), then -- `all_cores`, the headline
+    only -- one process per usable core over independent windows, with the host description beside them.
+    `windows`: (iq, cs, ce, bw) of the GPU line's own synthetic batch, of which the first two are timed (H: 1.7 s of numpy
+    to synthesise each, so they are not built twice); at least one whole window is always completed (H: one window is
+    12 SVs x (five 500 000-point + one 4 194 304-point fp64 transforms) + the two scans, several seconds)."""
     import shutil
     import tempfile
     import navlab_dpe_sdr_amd as dpe
     from oracle import mp_baseline as mb
     fs, S, K, G, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["G"], cfg["L"], cfg["B"]
-    iq, cs, ce, bw = dpe.workload.build_windows(2, fs, S, K, seed=99, amp=cfg["amp"])
+    if windows is not None:
+        iq, cs, ce, bw = (np.ascontiguousarray(a[:2]) for a in windows)
+    else:
+        iq, cs, ce, bw = dpe.workload.build_windows(2, fs, S, K, seed=99, amp=cfg["amp"])
     _, _, pos, vel, _ = dpe.workload.build_grids(G)
     d = {"fs": np.float64(fs), "S": np.int64(S), "L": np.int64(L), "B": np.int64(B), "iq": iq, "cs": cs, "ce": ce,
          "bw": bw, "pos": pos, "vel": vel}
     mb.o.lib()
     n, t0 = 0, time.perf_counter()
     while True:
-        mb.full_window(d, n % 2)
+        mb.full_window(d, n % iq.shape[0])
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s:
@@ -89,6 +96,8 @@ def cpu_baseline(cfg, budget_s=10.0, mp_budget_s=8.0):
     out = {"value": n * 2.0 * G * K / dt, "unit": "gridpoint*SV/s", "cores": 1, "kind": "port",
            "sample": "%d full windows (FFT BCS in numpy + C grid scan, fp64), %.1f s" % (n, dt),
            "x_realtime": n / dt / 50.0, "host": mb.host_info()}
+    if not all_cores:
+        return out
     # all usable cores: independent processes (no profiler preload, one thread each) behind a file barrier
     # at most 64 workers: the windows stream 67 MB FFT batches, and on the 256-thread host of the GPU box 256
     # workers measured half the aggregate rate of 64 (memory bound), 14 s per window
@@ -193,6 +202,16 @@ def acq_line(modes=("coherent", "textbook", "noncoherent"), cpu_budget_s=5.0):
     alg_bytes = 4.0 * S + 4.0 * cells                    # int16 I/Q once + the fp32 |.| surface once
     n_fft = bins.size + len(prns) * bins.size            # forward (time-folded rows) + inverse transforms of length M
     flops = n_fft * 5.0 * M * math.log2(M) + 6.0 * cells
+    # Transform flops of each mode (5 n log2 n per complex transform + 6 per spectrum product), priced against the fp32 VECTOR peak:
+    # the transform kernels are LDS / VALU bound, so this -- not the HBM fraction -- says how far each is from its limiter.
+    mode_flops = {"coherent": flops,
+                  "textbook": N * n_fft * 5.0 * M * math.log2(M) + 6.0 * N * cells,           # ten 2500-point correlations per (PRN, bin)
+                  "noncoherent": n_fft * 5.0 * S * math.log2(S) + 6.0 * N * cells}             # one 25 000-point correlation per (PRN, bin)
+    mode_flops["noncoherent_25x500Hz"] = (25 + len(prns) * 25) * 5.0 * S * math.log2(S) + 6.0 * N * len(prns) * 25 * M
+    for m_, d_ in per_mode.items():
+        d_["transform_flops"] = mode_flops[m_]
+        d_["TFLOPs"] = mode_flops[m_] / (d_["ms_per_window"] * 1e-3) / 1e12
+        d_["flop_frac"] = d_["TFLOPs"] / FP32_VECTOR_PEAK_TFLOPS
     out = {"metric": "acquisition search cells (PRN x Doppler bin x code delay) per second", "value": cells / (ms0 * 1e-3),
            "unit": "cell/s", "n_gpus": 1, "ms_per_step": ms0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic", "headline": False,
@@ -207,7 +226,8 @@ def acq_line(modes=("coherent", "textbook", "noncoherent"), cpu_budget_s=5.0):
                         "achieved": alg_bytes / (ms0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / (ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms0,
-                        "transform_flops_per_window": flops, "achieved_TFLOPs": flops / (ms0 * 1e-3) / 1e12}}
+                        "transform_flops_per_window": flops, "achieved_TFLOPs": flops / (ms0 * 1e-3) / 1e12,
+                        "flop_peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS, "flop_frac": flops / (ms0 * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS}}
     from oracle import oracle as o
     t0 = time.perf_counter()
     k = 0
@@ -291,65 +311,84 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     w0 = rank * Wl if shard1 else 0
     iq_d = torch.from_numpy(np.ascontiguousarray(iq[w0:w0 + Wl])).to(dev)     # inputs resident in HBM before the timed region
     cs_l = np.ascontiguousarray(cs[w0:w0 + Wl])
-    bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=Wl, max_channels=K)
-    bcs.Start()
-    bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B, max_windows=W,
-                                max_channels=K, write_scores=write_scores, pos_index_offset=off, vel_index_offset=off)
-    bcm.Start()
+    # The library's batches-in-flight form (include/dpe_hip.h, dpe_pipe_*): `--in-flight` lanes -- a BatchCorrScores /
+    # BatchCorrManifold handle pair and a stream each, one device copy of the grids -- that consecutive steps are dealt to, so that
+    # stage 1 of step n + 1 runs beside the grid scan of step n (what the reference gets from SampleBlock's ring and its side
+    # streams).  The isolated-kernel passes and `one_stream_ms_per_step` run with one lane (dpe_pipe_set_in_flight(1)).
+    n_lanes = max(1, args.in_flight)
+    pipe = dpe.Pipe(fs, S, pos, vel, lag_half_width=L, bin_half_width=B, max_windows=Wl, max_channels=K, in_flight=n_lanes,
+                    write_scores=write_scores, pos_index_offset=off, vel_index_offset=off, bcm_max_windows=W)
     stream = torch.cuda.current_stream()
     nLag, nBin = 2 * L + 1, 2 * B + 1
-    if shard1:
-        loc_code = device_view(bcs.CodeScores, (Wl, K, nLag, 2), "<f4", dev)
-        loc_carr = device_view(bcs.CarrScores, (Wl, K, nBin, 2), "<f4", dev)
-        full_code = torch.empty((W, K, nLag, 2), dtype=torch.float32, device=dev)
-        full_carr = torch.empty((W, K, nBin, 2), dtype=torch.float32, device=dev)
-        code_ptr, carr_ptr = full_code.data_ptr(), full_carr.data_ptr()
-    else:
-        code_ptr, carr_ptr = bcs.CodeScores, bcs.CarrScores
-    key_views = {}
+    lanes = []           # per lane: handles, stream, and the buffers of this rank's exchanges
+    for i in range(n_lanes):
+        b_, m_, ls = pipe.lane_at(i)
+        ln = {"bcs": b_, "bcm": m_, "stream": ls, "code": b_.CodeScores, "carr": b_.CarrScores, "key_views": {}}
+        if ctx.use_dist:
+            ln["tstream"] = torch.cuda.ExternalStream(ls, device=dev)      # torch.distributed enqueues on torch's CURRENT stream
+        if shard1:
+            ln["loc_code"] = device_view(b_.CodeScores, (Wl, K, nLag, 2), "<f4", dev)
+            ln["loc_carr"] = device_view(b_.CarrScores, (Wl, K, nBin, 2), "<f4", dev)
+            ln["full_code"] = torch.empty((W, K, nLag, 2), dtype=torch.float32, device=dev)
+            ln["full_carr"] = torch.empty((W, K, nBin, 2), dtype=torch.float32, device=dev)
+            ln["code"], ln["carr"] = ln["full_code"].data_ptr(), ln["full_carr"].data_ptr()
+        if ctx.use_dist and args.exchange == "scores":
+            ln["glob_p"] = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
+            ln["glob_v"] = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
+            ln["loc_p"] = device_view(m_.PosScores, (W, m_.PosScoresPitch), "<f4", dev)[:, :G]     # rows are 128-byte aligned (pitch >= G)
+            ln["loc_v"] = device_view(m_.VelScores, (W, m_.VelScoresPitch), "<f4", dev)[:, :G]
+        lanes.append(ln)
+    by_handle = {ln["bcs"]._h.value: ln for ln in lanes}
+    bcs, bcm = lanes[0]["bcs"], lanes[0]["bcm"]          # lane 0: the one-stream passes
+    last = [None]        # lane of the last step
 
-    def keys_tensor():
-        """torch view of the handle's packed keys of the LAST Update (two device sets alternate); int64:
+    def keys_tensor(ln):
+        """torch view of a lane's packed keys of ITS last Update (two device sets alternate per handle); int64:
         scores are >= 0 so the sign bit is clear"""
-        ptr = bcm.Keys
-        if ptr not in key_views:
-            key_views[ptr] = device_view(ptr, (W, 2), "<i8", dev)
-        return key_views[ptr]
+        ptr = ln["bcm"].Keys
+        if ptr not in ln["key_views"]:
+            ln["key_views"][ptr] = device_view(ptr, (W, 2), "<i8", dev)
+        return ln["key_views"][ptr]
 
-    if ctx.use_dist and args.exchange == "scores":
-        glob_p = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
-        glob_v = torch.zeros((W, G_global), dtype=torch.float32, device=dev)
-        loc_p = device_view(bcm.PosScores, (W, bcm.PosScoresPitch), "<f4", dev)[:, :G]     # rows are 128-byte aligned (pitch >= G)
-        loc_v = device_view(bcm.VelScores, (W, bcm.VelScoresPitch), "<f4", dev)[:, :G]
-
-    def gather_banks():
+    def gather_banks(ln):
         if ctx.comm is not None:      # --comm dpe: the C-ABI's own exchange (dpe_bcs_allgather_banks)
-            bcs.allgather_banks(ctx.comm, code_ptr, carr_ptr, stream=stream)
+            ln["bcs"].allgather_banks(ctx.comm, ln["code"], ln["carr"], stream=ln["stream"])
         elif ctx.backend == "nccl":
-            dist.all_gather_into_tensor(full_code, loc_code)
-            dist.all_gather_into_tensor(full_carr, loc_carr)
+            dist.all_gather_into_tensor(ln["full_code"], ln["loc_code"])
+            dist.all_gather_into_tensor(ln["full_carr"], ln["loc_carr"])
         else:   # gloo (functional tests on one GPU): through host memory
-            for full, loc in ((full_code, loc_code), (full_carr, loc_carr)):
+            for full, loc in ((ln["full_code"], ln["loc_code"]), (ln["full_carr"], ln["loc_carr"])):
                 parts = [torch.empty(loc.shape, dtype=loc.dtype) for _ in range(world)]
                 dist.all_gather(parts, loc.cpu())
                 full.copy_(torch.cat(parts))
 
-    def step():
-        bcs.Update(iq_d, cs_l, stream=stream)
-        if shard1:
-            gather_banks()
-        bcm.Update(code_ptr, carr_ptr, bw, ce, stream=stream)
-        if ctx.use_dist:
+    def step(src=None, in_stream=None):
+        src = iq_d if src is None else src
+        if not ctx.use_dist:           # one GPU: the whole step is one C call (dpe_pipe_submit)
+            t = pipe.submit(src, cs_l, bw, ce, stream=in_stream or stream)
+            last[0] = (t, lanes[0])
+            return
+        # N > 1: the same lane, driven in pieces -- this rank's exchanges go between the stages, on the lane's stream
+        t, b_, m_, ls = pipe.acquire(stream)
+        ln = by_handle[b_._h.value]
+        b_.Update(src, cs_l, stream=ls)
+        pipe.mark_stage1(t)
+        with torch.cuda.stream(ln["tstream"]):
+            if shard1:
+                gather_banks(ln)
+            m_.Update(ln["code"], ln["carr"], bw, ce, stream=ls)
             if ctx.comm is not None:  # --comm dpe: dpe_bcm_exchange_keys, all-reduce(MAX) in place on the handle's keys
-                bcm.exchange_keys(ctx.comm, stream=stream, to_host=False)
+                m_.exchange_keys(ctx.comm, stream=ls, to_host=False)
             elif args.exchange == "keys":
-                dpe.sharding.allreduce_argmax(keys_tensor(), dist)
+                dpe.sharding.allreduce_argmax(keys_tensor(ln), dist)
             else:
-                glob_p.zero_(); glob_v.zero_()
-                glob_p[:, off:off + G].copy_(loc_p); glob_v[:, off:off + G].copy_(loc_v)
-                dist.all_reduce(glob_p, op=dist.ReduceOp.SUM)
-                dist.all_reduce(glob_v, op=dist.ReduceOp.SUM)
-                torch.argmax(glob_p, dim=1); torch.argmax(glob_v, dim=1)
+                ln["glob_p"].zero_(); ln["glob_v"].zero_()
+                ln["glob_p"][:, off:off + G].copy_(ln["loc_p"]); ln["glob_v"][:, off:off + G].copy_(ln["loc_v"])
+                dist.all_reduce(ln["glob_p"], op=dist.ReduceOp.SUM)
+                dist.all_reduce(ln["glob_v"], op=dist.ReduceOp.SUM)
+                torch.argmax(ln["glob_p"], dim=1); torch.argmax(ln["glob_v"], dim=1)
+        pipe.commit(t, W, K)
+        last[0] = (t, ln)
 
     def fence():
         if ctx.use_dist:
@@ -363,6 +402,18 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def timed(n_batches, n_steps):
+        out_ms = []
+        for _ in range(n_batches):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                step()
+            fence()
+            out_ms.append(max_over_ranks(time.perf_counter() - t0) / n_steps * 1e3)
+        return out_ms
+
+    pipe.set_in_flight(1)
     for _ in range(warmup):
         step()
     fence()
@@ -383,92 +434,67 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     side.update(bcm.profile(False))
     kernels_ms = {k: v[0] / max(v[1], 1) * (v[1] / n_side) for k, v in side.items()}   # per step (side chunks of a wide lag window add up)
     dominant = max(kernels_ms, key=kernels_ms.get)
-    # Timed region: only the dominant kernel carries HIP events (a pair of events around every kernel costs ~2 % of a step)
-    est = 0.0
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    fence()
-    est = max_over_ranks(time.perf_counter() - t0) / steps
+    est = timed(1, steps)[0] * 1e-3
     reps = max(1, int(math.ceil(args.min_batch_s / max(est * steps, 1e-9))))
+    # One stream (one lane): the isolated dominant kernel between HIP events for the `roofline` stanza (a pair of events around
+    # every kernel costs ~2 % of a step, so only the dominant one carries them), and `one_stream_ms_per_step`.
     if dominant == "bcm_scan":
         bcm.profile(True)
     else:
         bcs.profile(dominant)
-    batch_ms = []
-    for _ in range(args.batches):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(reps * steps):
-            step()
-        fence()
-        batch_ms.append(max_over_ranks(time.perf_counter() - t0) / (reps * steps) * 1e3)
+    one_ms = timed(args.batches if n_lanes == 1 else 3, reps * steps)
     kern = dict(bcm.profile(False)) if dominant == "bcm_scan" else dict(bcs.profile(False))
+    one_stream_ms = float(np.median(one_ms))
+    # The timed region proper: `--in-flight` lanes
+    if n_lanes > 1:
+        pipe.set_in_flight(n_lanes)
+        for _ in range(2 * n_lanes):
+            step()
+        batch_ms = timed(args.batches, reps * steps)
+    else:
+        batch_ms = one_ms
     ms_step = float(np.median(batch_ms))
     # Stage-1 device status after the timed region: batches of the high-rate chip kernel compute their DC sums inside the stage-1
     # launch, and a correlator block that had to wait too long for them sums its window itself (right, but slower) -- bits 2 / 16
     # say that it happened; a timed region in which it did is not the steady state this line claims.
-    stage1_status = None
-    try:
-        stage1_status = int(bcs.dev_status(stream=stream))
-    except dpe.engine.DpeError:
-        pass          # (no device-side status on this path: per-sample kernels with host parameters)
-    assert not stage1_status, "stage-1 device status %r after the timed region" % stage1_status
+    stage1_status = 0
+    have_status = False
+    for ln in lanes:
+        try:
+            stage1_status |= int(ln["bcs"].dev_status(stream=ln["stream"]))
+            have_status = True
+        except dpe.engine.DpeError:
+            pass          # (no device-side status on this path: per-sample kernels with host parameters)
+    if not have_status:
+        stage1_status = None
+    # bits 1 / 2 / 8 are input errors (PRN / code frequency out of range, a broken chip-kernel promise): the line would describe
+    # another computation -- fail loudly (an exception, not an assert: `python -O` must not strip it).  Bits 4 / 16 (a correlator
+    # block summed its window itself) leave the results exact: the status travels in the JSON line as `stage1_dev_status`.
+    if stage1_status and stage1_status & 11:
+        raise RuntimeError("stage-1 device status %r after the timed region" % stage1_status)
 
-    # result sanity on rank 0: finite fix; with one rank the exchanged keys decode to what the handle itself reports,
-    # and the banks must cover every index the grids reach
+    # result sanity on rank 0: finite fix; every lane's last batch gives the same answer (same inputs); with one rank the
+    # exchanged keys decode to what the handle itself reports, and the banks must cover every index the grids reach
+    t_last, ln_last = last[0]
     if ctx.use_dist:
-        res = bcm.results_from_keys(keys_tensor().cpu().numpy().view(np.uint64), pos_g, vel_g)
+        with torch.cuda.stream(ln_last["tstream"]):
+            kt = keys_tensor(ln_last).cpu()
+        res = ln_last["bcm"].results_from_keys(kt.numpy().view(np.uint64), pos_g, vel_g)
         if world == 1:
-            ref = bcm.results()
+            ref = pipe.results(t_last)
             assert all(a["posIndex"] == b["posIndex"] and a["velIndex"] == b["velIndex"] and
                        np.array_equal(a["zVal"], b["zVal"]) for a, b in zip(res, ref))
             res = ref
     else:
-        res = bcm.results()
+        res = pipe.results(t_last)
+        if n_lanes > 1:
+            r2 = pipe.results(t_last - 1)
+            assert all(a["posIndex"] == b_["posIndex"] and a["velIndex"] == b_["velIndex"] and np.array_equal(a["zVal"], b_["zVal"])
+                       for a, b_ in zip(r2, res)), "the lanes disagree"
     assert all(np.isfinite(r["zVal"]).all() for r in res)
     fixes = [[int(r["posIndex"]), int(r["velIndex"]), float(r["posScore"]), float(r["velScore"])] for r in res[:16]]
     if world == 1:
         assert all(r["posOutOfWindow"] == 0 and r["velOutOfWindow"] == 0 for r in res), "bank window too narrow"
-
-    # Two steps in flight (a product option, never the headline): a second handle pair on a second stream, steps alternating
-    # between the pairs, so that stage 1 of step n + 1 runs beside the scan of step n.  Nothing in the library is special for
-    # it -- a handle serves one stream at a time, a host that wants the overlap creates two pairs.  The `roofline` stanza
-    # stays on the isolated kernel of the one-stream region above.
-    pipelined = None
-    if not ctx.use_dist and not args.no_pipelined:
-        bcs2 = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=Wl, max_channels=K)
-        bcs2.Start()
-        bcm2 = dpe.BatchCorrManifold(fs, S, bcs2.NumFFTPoints, pos, vel, lag_half_width=L, bin_half_width=B, max_windows=W, max_channels=K,
-                                     write_scores=write_scores, pos_index_offset=off, vel_index_offset=off)
-        bcm2.Start()
-        pairs = ((bcs, bcm, torch.cuda.Stream()), (bcs2, bcm2, torch.cuda.Stream()))
-        cnt = [0]
-
-        def step2():
-            b_, m_, st_ = pairs[cnt[0] & 1]
-            cnt[0] += 1
-            b_.Update(iq_d, cs_l, stream=st_)
-            m_.Update(b_.CodeScores, b_.CarrScores, bw, ce, stream=st_)
-        for _ in range(2 * max(warmup, 2)):
-            step2()
-        torch.cuda.synchronize()
-        pb = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(reps * steps):
-                step2()
-            torch.cuda.synchronize()
-            pb.append((time.perf_counter() - t1) / (reps * steps) * 1e3)
-        r2 = bcm2.results()
-        assert all(a["posIndex"] == b_["posIndex"] and a["velIndex"] == b_["velIndex"] for a, b_ in zip(r2, res)), "pipelined pair disagrees"
-        pms = float(np.median(pb))
-        pipelined = {"ms_per_step": pms, "value": W * 2.0 * G_global * K / (pms * 1e-3), "streams": 2, "handle_pairs": 2,
-                     "batch_ms_per_step": pb, "vs_one_stream": pms / ms_step,
-                     "note": "steps alternate between two handle pairs on two streams; informational, never the headline"}
-        bcm2.Stop(); bcs2.Stop()
 
     pcie_value = pcie_overlapped = None
     if args.include_h2d and headline and not ctx.use_dist:
@@ -476,7 +502,8 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
         fence()
         t1 = time.perf_counter()
         for _ in range(steps):
-            iq_d.copy_(iq_pin, non_blocking=True)     # SampleBlock's H2D leg (sampleblock.cu:356-410), same stream
+            pipe.samples_consumed(last[0][0], stream=stream)     # the refill waits (on the device) for stage 1 of the step before
+            iq_d.copy_(iq_pin, non_blocking=True)                # SampleBlock's H2D leg (sampleblock.cu:356-410), same stream
             step()
         fence()
         pcie_value = float(steps) * W * 2.0 * G * K / (time.perf_counter() - t1)
@@ -484,28 +511,23 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
         # travels while batch n is processed
         copy_stream = torch.cuda.Stream()
         bufs = [iq_d, torch.empty_like(iq_d)]
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        freed = [torch.cuda.Event(), torch.cuda.Event()]
-        for e in freed:
-            e.record(torch.cuda.current_stream())
+        used_by = [None, None]          # ticket of the step that last read the buffer
 
         def upload(i):
+            if used_by[i] is not None:
+                pipe.samples_consumed(used_by[i], stream=copy_stream)
             with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(freed[i])
                 bufs[i].copy_(iq_pin, non_blocking=True)
-                ready[i].record(copy_stream)
 
         fence()
         t2 = time.perf_counter()
         upload(0)
         for n in range(steps):
             cur = n & 1
+            step(bufs[cur], in_stream=copy_stream)       # the lane waits for the upload enqueued so far on the copy stream
+            used_by[cur] = last[0][0]
             if n + 1 < steps:
                 upload(cur ^ 1)
-            torch.cuda.current_stream().wait_event(ready[cur])
-            bcs.Update(bufs[cur], cs_l, stream=stream)
-            bcm.Update(code_ptr, carr_ptr, bw, ce, stream=stream)
-            freed[cur].record(torch.cuda.current_stream())
         fence()
         pcie_overlapped = float(steps) * W * 2.0 * G * K / (time.perf_counter() - t2)
 
@@ -538,11 +560,17 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
                        "comm": ("dpe_comm (C-ABI)" if ctx.comm is not None else "torch.distributed") if ctx.use_dist else "none",
                        "stage1": ("sharded by window + bank all-gather" if shard1 else "replicated") if ctx.use_dist else "local",
                        "scores_written": write_scores,
+                       # batches in flight (dpe_pipe): lanes the steps of the timed region are dealt to; ms_per_step / value are
+                       # THIS form's, one_stream_ms_per_step the same steps on one lane, the roofline stanza the isolated kernel
+                       "in_flight": n_lanes,
                        # SURVEY 8(d) asks for batches of >= 256 resident windows; H is timed at 128 (2 MB each, 8 distinct ones repeated):
                        # per-window time measured equal at 64 / 128 / 256 windows per step (profiles/archive/r3a_H_w*_bench.json)
                        **({"windows_per_step_note": "128 per step against SURVEY 8(d)'s >= 256: same time per window at 64 / 128 / 256 "
                                                     "(profiles/archive/r3a_H_w64|w128|w256_bench.json)"} if name == "H" and W == 128 else {})},
+            "one_stream_ms_per_step": one_stream_ms,
+            "one_stream_value": units_per_step / (one_stream_ms * 1e-3),
             "timing": {"timed_batches": args.batches, "steps_per_timed_batch": reps * steps, "batch_ms_per_step": batch_ms,
+                       "one_stream_batch_ms_per_step": one_ms,
                        "statistic": "median of the batches, each the max over ranks"},
             "x_realtime": windows_per_s / 50.0, "windows_per_s": windows_per_s,
             "roofline": {"bound": "hbm", "bound_physical": BOUND_PHYSICAL.get(kname, "valu"), "kernel": kname,
@@ -558,9 +586,6 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
             # count that scans the same global grid (config M), which is what the multi-rank tests compare
             "fixes": fixes,
         }
-        if pipelined is not None:
-            out["pipelined"] = pipelined
-            out["pipelined_value"] = pipelined["value"]
         if pcie_value is not None:
             out["pcie_inclusive_value"] = pcie_value
             out["pcie_inclusive_overlapped_value"] = pcie_overlapped
@@ -572,10 +597,34 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
                 # what the kernel really pulls from HBM (PMC bytes / launch time): the grids are shared by the windows
                 # of a batch and stay in L2, so the algorithmic rate may exceed the physical ceiling
                 "physical_GBps": traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms else None}
-    bcm.Stop(); bcs.Stop()
-    del iq_d
+    pipe.close()
+    del iq_d, lanes, by_handle
     torch.cuda.empty_cache()
     return out, {"key": (fs, S, K, W), "data": (iq, cs, ce, bw)}
+
+
+def brief(out):
+    """The few numbers of a non-headline line that travel inside the headline JSON's `others` stanza (the driver records the last
+    line only): time, value, the dominant kernel's roofline fractions, the device status and the CPU baseline of that configuration."""
+    if out is None:
+        return None
+    r = out.get("roofline", {})
+    b = {"ms_per_step": out["ms_per_step"], "value": out["value"], "unit": out["unit"], "x_realtime": out.get("x_realtime"),
+         "roofline": {k: r.get(k) for k in ("kernel", "frac", "whole_step_frac", "avg_launch_ms", "flop_frac") if r.get(k) is not None}}
+    if "modes" in out:      # acquisition: every mode's time and its fraction of the fp32 vector peak
+        b["mode"] = out["config"].get("mode")
+        b["modes"] = {m: {"ms": d["ms_per_window"], "flop_frac": d.get("flop_frac")} for m, d in out["modes"].items()}
+        b["roofline"]["kernel"] = "dpe_acq_search"
+    else:
+        b["stage1_dev_status"] = out.get("stage1_dev_status")
+        b["windows_per_step"] = out["config"]["windows_per_step"]
+        for k in ("in_flight", "one_stream_ms_per_step"):
+            if k in out.get("config", {}) or k in out:
+                b[k] = out.get(k, out["config"].get(k))
+    c = out.get("cpu_baseline")
+    if c:
+        b["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    return b
 
 
 def spawn_ranks(args, argv):
@@ -618,12 +667,20 @@ def main():
     ap.add_argument("--batches", type=int, default=5, help="timed batches (the median is reported)")
     ap.add_argument("--min-batch-s", type=float, default=0.2, help="each timed batch repeats the --steps steps until it lasts this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-steps-in-flight pass (`pipelined` stanza)")
+    ap.add_argument("--cpu-budget-s", type=float, default=10.0,
+                    help="seconds of one-thread oracle time behind the headline's cpu_baseline (H / M: 0.4 / 0.5 of it, at least one "
+                         "whole window each); below 5 the all-cores leg is skipped")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight in the timed region (lanes of the library's dpe_pipe: stage 1 of step n + 1 beside the scan "
+                         "of step n); 1 = one stream.  `one_stream_ms_per_step` is reported beside it either way")
+    ap.add_argument("--no-pipelined", action="store_true", help="same as --in-flight 1 (kept for the profile collection scripts)")
     ap.add_argument("--no-scores", action="store_true", help="skip the per-point score write (arg-max only)")
     ap.add_argument("--include-h2d", action="store_true",
                     help="also time the steps with the window batch uploaded from pinned host memory inside the timed "
                          "region (reported as pcie_inclusive_value; never the headline value)")
     args = ap.parse_args()
+    if args.no_pipelined:
+        args.in_flight = 1
     if args.acq:
         return acq_main(args.acq)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -680,21 +737,37 @@ def main():
 
     headline = args.config or "R"
     cached = None
+    configs = {"R": dpe.workload.CONFIG_R, "H": dpe.workload.CONFIG_H, "M": dpe.workload.CONFIG_M}
+    want_cpu = ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline
+    others = {}
     if args.config is None and not args.no_extras:
         extra_steps = min(args.steps, 20)
         if ctx.world == 1 and not ctx.use_dist:
             try:
-                emit(acq_line())                  # BASELINE.json configs[4]
+                out = acq_line()                  # BASELINE.json configs[4]
+                emit(out)
+                others["acq"] = brief(out)
             except Exception as e:                # (an extra line must never cost the headline)
                 sys.stderr.write("bench.py: acquisition line failed: %r\n" % (e,))
-            out, _ = run_workload("H", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
+            out, hc = run_workload("H", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
+            if want_cpu:      # the CPU restatement beside every configuration; one thread, one whole window at H
+                out["cpu_baseline"] = cpu_baseline(configs["H"], budget_s=0.4 * args.cpu_budget_s, all_cores=False, windows=hc["data"])
             emit(out)
+            others["H"] = brief(out)
+            del hc
         out, cached = run_workload("M", ctx, args, extra_steps, min(args.warmup, 2), headline=False)
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(configs["M"], budget_s=0.5 * args.cpu_budget_s, all_cores=False, windows=cached["data"])
         emit(out)
+        if ctx.rank == 0:
+            others["M"] = brief(out)
     out, _ = run_workload(headline, ctx, args, args.steps, args.warmup, headline=True, cached=cached)
-    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
-        cfg = {"R": dpe.workload.CONFIG_R, "H": dpe.workload.CONFIG_H, "M": dpe.workload.CONFIG_M}[headline]
-        out["cpu_baseline"] = cpu_baseline(dict(cfg, G=min(cfg["G"], 390625)))
+    if want_cpu:
+        cfg = configs[headline]
+        out["cpu_baseline"] = cpu_baseline(dict(cfg, G=min(cfg["G"], 390625)), budget_s=args.cpu_budget_s,
+                                           all_cores=args.cpu_budget_s >= 5.0)
+    if ctx.rank == 0 and others:
+        out["others"] = others        # the non-headline lines in brief: the driver records only this last line
     if ctx.use_dist:
         dist.barrier()
     emit(out)

@@ -37,8 +37,10 @@ extern "C" {
  * DPE_BCS_FAT, DPE_BCM_SPLIT) exist only in builds with -DDPE_EXPERIMENTS. */
 #define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
 #define DPE_MAX_LAG_HALF_WIDTH 292  /* widest code-lag bank of the windowed stage-1 kernels: +-32 and four 65-lag chunks per side */
-#define DPE_ABI_VERSION 3   /* 2: dpe_bcm_config.referencePair, pitched score rows, sizes in dpe_bcm_results_from_keys, *_update_dev;
-                             * 3: the dpe_chm_dev_ family -- device-resident cuChanMgr + measurement hand-over -- and the _update_prepared forms */
+#define DPE_ABI_VERSION 4   /* 2: dpe_bcm_config.referencePair, pitched score rows, sizes in dpe_bcm_results_from_keys, *_update_dev;
+                             * 3: the dpe_chm_dev_ family -- device-resident cuChanMgr + measurement hand-over -- and the _update_prepared forms;
+                             * 4: dpe_chm_dev_set_shard, dpe_chm_dev_set_ekf; dpe_bcs_dev_status bit 2 is per launch (was sticky), bit 4 the
+                             *    sticky one; dpe_fix_record.status bits 32 / 64; the dpe_pipe_ family (batches in flight) */
 
 typedef void *dpe_stream_t;        /* hipStream_t (reference: cudaStream_t* flow stream, module.h:23) */
 typedef struct dpe_bcs dpe_bcs;    /* opaque: one BatchCorrScores instance */
@@ -303,6 +305,48 @@ int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWi
                               const double *velGridGlobal, int64_t velGridGlobalSize,
                               dpe_bcm_result *results);
 
+/* ------------------------------------------------------------------ batches in flight ------ */
+/* Several batches of the path on the device at once -- what the reference gets from SampleBlock's 32-slot ring and reader thread
+ * (sampleblock.cu:327-447) and from the side streams of BatchCorrScores / BatchCorrManifold (batchcorrscores.h:60-64,
+ * batchcorrmanifold.cu:2573-2586): the correlations of batch n + 1 run beside the grid scan of batch n.  A dpe_bcs / dpe_bcm handle
+ * serves one stream, so a dpe_pipe owns `inFlight` LANES (a handle pair created from the two configurations, a non-blocking
+ * stream, events) and deals consecutive batches to them round robin; the lanes' BatchCorrManifold handles share one device copy
+ * of the grids.  Every lane runs exactly the launches a lone handle pair would: results are bit-identical to the one-stream path.
+ * A batch is named by its TICKET (0, 1, 2, ...); its banks, scores, keys and results live in its lane until the lane is dealt
+ * again, i.e. until `inFlight` later batches have been issued -- collect them before that.  One thread drives a pipe. */
+typedef struct dpe_pipe dpe_pipe;
+int dpe_pipe_create(const dpe_bcs_config *bcsCfg, const dpe_bcm_config *bcmCfg, int32_t inFlight /* 1..8 */, dpe_pipe **out);
+int dpe_pipe_destroy(dpe_pipe *p);                       /* waits for the lanes, then destroys their handles */
+int dpe_pipe_in_flight(const dpe_pipe *p);
+/* Deal to the first `inFlight` lanes only from now on (1 = one stream: the latency form; at most the lanes made at create). */
+int dpe_pipe_set_in_flight(dpe_pipe *p, int32_t inFlight);
+/* The handles and stream of lane `lane` (0 .. lanes - 1) whatever it holds: set-up calls on the lanes' handles (dpe_*_profile,
+ * dpe_*_set_graph, ...), never an Update. */
+int dpe_pipe_lane_at(dpe_pipe *p, int32_t lane, dpe_bcs **bcs, dpe_bcm **bcm, dpe_stream_t *laneStream);
+/* One batch: dpe_bcs_update + dpe_bcm_update (same arguments) on the next lane, which first waits -- on the device -- for
+ * everything enqueued so far on `inputStream` (the stream that produced samples_dev).  Asynchronous; never waits for the lane's
+ * previous batch on the host.  samples_dev must stay valid until stage 1 of the batch is through (dpe_pipe_samples_consumed). */
+int dpe_pipe_submit(dpe_pipe *p, const int16_t *samples_dev, int64_t windowStrideSamples, int32_t nWindows, int32_t nChan,
+                    const dpe_chan_start *chanStart_host, const dpe_bcm_window *win_host, const dpe_chan_end *chanEnd_host,
+                    dpe_stream_t inputStream, int64_t *ticket);
+/* The same in pieces, for a host that puts its own work between the two stages (multi-GPU: the bank all-gather and the key
+ * exchange, on the lane's stream): acquire hands out the next lane's handles and stream (which waits for `inputStream` as above);
+ * the host calls dpe_bcs_update / ... / dpe_bcm_update on them with that stream, optionally dpe_pipe_mark_stage1 once the samples
+ * are consumed, and dpe_pipe_commit at the end. */
+int dpe_pipe_acquire(dpe_pipe *p, dpe_stream_t inputStream, int64_t *ticket, dpe_bcs **bcs, dpe_bcm **bcm, dpe_stream_t *laneStream);
+int dpe_pipe_mark_stage1(dpe_pipe *p, int64_t ticket);
+int dpe_pipe_commit(dpe_pipe *p, int64_t ticket, int32_t nWindows);
+/* Handles and stream of the lane that holds `ticket` (error once the lane has been dealt again): dpe_bcs_outputs, dpe_bcm_scores,
+ * dpe_bcm_keys ... of that batch. */
+int dpe_pipe_lane(dpe_pipe *p, int64_t ticket, dpe_bcs **bcs, dpe_bcm **bcm, dpe_stream_t *laneStream);
+/* dpe_bcm_results of that batch: waits for ITS lane only -- later batches keep running. */
+int dpe_pipe_results(dpe_pipe *p, int64_t ticket, dpe_bcm_result *results);
+/* Stream-ordered hand-backs (no host wait): `stream` continues once stage 1 of the batch has read its samples (a SampleBlock ring
+ * slot may then be refilled: sampleblock.cu:421-447) / once every committed batch is complete. */
+int dpe_pipe_samples_consumed(dpe_pipe *p, int64_t ticket, dpe_stream_t stream);
+int dpe_pipe_join(dpe_pipe *p, dpe_stream_t stream);
+int dpe_pipe_synchronize(dpe_pipe *p);                   /* host wait for all lanes */
+
 /* ------------------------------------------------------------------ multi-GPU exchange ------ */
 /* One process per GPU; the manifold grid is sharded (posGridIndexOffset / velGridIndexOffset), stage 1 may be sharded by
  * window.  The only data-path collectives are the arg-max exchange -- all-reduce(MAX) of the packed keys, 16 B per window --
@@ -390,7 +434,7 @@ typedef struct dpe_fix_record {
 } dpe_fix_record;
 int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans, const double *timeGrid_host, int32_t dimT,
                        dpe_chm_dev **out);
-int dpe_chm_dev_destroy(dpe_chm_dev *h);
+int dpe_chm_dev_destroy(dpe_chm_dev *h);    /* in any order with the handles it is attached to: whichever goes first detaches */
 /* Before Start: bcs / bcm (either may be NULL) get their parameter blocks from this channel manager; with bcm a ring of
  * fixRingDepth fixes is set up and dpe_chm_dev_step becomes available. */
 int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRingDepth);
@@ -421,7 +465,10 @@ int dpe_chm_dev_update(dpe_chm_dev *h, const double *xk1k1_dev, const double *xk
  * blocks of the next window, fix -> ring.  Asynchronous; never waits. */
 int dpe_chm_dev_step(dpe_chm_dev *h, dpe_stream_t stream);
 /* Fix of window `window` (0 = the first dpe_chm_dev_step).  timeoutMicros < 0: wait; otherwise returns 1 when the fix has not
- * arrived within that time (0 = just look).  -1: never enqueued, or already overwritten (the host fell fixRingDepth behind). */
+ * arrived within that time (0 = just look).  -1: never enqueued, already overwritten (the host fell fixRingDepth behind), or the
+ * loop died (its streams report an error, or have drained on two consecutive probes without the record arriving).  One thread
+ * drives a manager: dpe_chm_dev_step and dpe_chm_dev_fix come from the same thread (or are serialised by the caller); the
+ * streams passed to dpe_chm_dev_step must outlive the manager and the handles attached to it. */
 int dpe_chm_dev_fix(dpe_chm_dev *h, int64_t window, dpe_fix_record *out, int32_t timeoutMicros);
 /* Diagnostics / tests: the state in the form of dpe_chm_outputs (synchronises `stream`). */
 int dpe_chm_dev_read(dpe_chm_dev *h, dpe_chan_start *start, dpe_chan_end *end, dpe_bcm_window *win, double *batchSatStates,

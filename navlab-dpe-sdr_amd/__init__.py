@@ -5,6 +5,6 @@ synthetic-input and file-format utilities.  Imported as `navlab_dpe_sdr_amd` thr
 root-level shim navlab_dpe_sdr_amd.py (the directory name carries a hyphen).
 """
 from . import engine, handoff, pipeline, rinex, sharding, synth, workload  # noqa: F401
-from .engine import Acquisition, BatchCorrManifold, BatchCorrScores, ChanMgr, DpeError, cuEKF  # noqa: F401
+from .engine import Acquisition, BatchCorrManifold, BatchCorrScores, ChanMgr, DpeError, Pipe, cuEKF  # noqa: F401
 
 __all__ = ["engine", "handoff", "pipeline", "rinex", "sharding", "synth", "workload", "BatchCorrScores", "BatchCorrManifold", "ChanMgr", "Acquisition", "DpeError", "cuEKF"]

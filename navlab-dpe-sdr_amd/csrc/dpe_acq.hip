@@ -1197,7 +1197,14 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     const bool wantAlias = cfg->mode == 1 && (h->M == kAcqFusedLen || h->M == 4000 || h->M == 5000) && h->N == 10 && !getenv("DPE_ACQ_NO_FUSED");
     h->X_d = dev_alloc<float2>(B * S);
     h->Rc_d = dev_alloc<float2>(P * (size_t)h->len);
-    const bool wantPack = wantAlias && h->M == kAcqFusedLen && !(getenv("DPE_ACQ_NO_PACK") && atoi(getenv("DPE_ACQ_NO_PACK")) != 0);
+    bool wantPack = wantAlias && h->M == kAcqFusedLen && !(getenv("DPE_ACQ_NO_PACK") && atoi(getenv("DPE_ACQ_NO_PACK")) != 0);
+    // the packed form keeps ten transforms of a (PRN, bin) in 128 000 B of dynamic LDS: a device (or partition) that does not grant
+    // that much per work group runs the radix-10 kernel + four-pass transforms instead -- decided here, before the buffers are sized
+    if (wantPack && (hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPkLdsBytes) != hipSuccess ||
+                     hipFuncSetAttribute(reinterpret_cast<const void *>(acq_fwd25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPkLdsBytes) != hipSuccess)) {
+        (void)hipGetLastError();
+        wantPack = false;
+    }
     h->Y_d = dev_alloc<float2>(wantFused ? 1 : wantPack ? B * S : (size_t)h->chunk * B * S);   // (packed form: the bins' decimated spectra)
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
     h->mp_d = dev_alloc<float>(P * (size_t)h->M);
@@ -1262,9 +1269,7 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             }
         h->tw2_d = dev_alloc<float2>(t2.size());
         h->Rcq_d = dev_alloc<float2>(P * (size_t)h->len);
-        if (!h->tw2_d || !h->Rcq_d || hipMemcpy(h->tw2_d, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_corr25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPkLdsBytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(acq_fwd25k_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPkLdsBytes) != hipSuccess) {
+        if (!h->tw2_d || !h->Rcq_d || hipMemcpy(h->tw2_d, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice) != hipSuccess) {
             set_error("[Acquisition] create: packed-form tables");
             rc = -1;
         } else {
@@ -1273,7 +1278,8 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
             else { h->packForm = true; h->fwdPack = !(getenv("DPE_ACQ_NO_FWD_PACK") && atoi(getenv("DPE_ACQ_NO_FWD_PACK")) != 0); }
             int dev = 0;
             hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) h->cus = prop.multiProcessorCount / 8 * 8;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 1)
+                h->cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : prop.multiProcessorCount;
         }
     }
     h->fusedFwd = !(getenv("DPE_ACQ_NO_FUSED_FWD") && atoi(getenv("DPE_ACQ_NO_FUSED_FWD")) != 0);

@@ -34,7 +34,7 @@ constexpr int kPkRow = 50;                 // row stride (float2) of a half tran
 constexpr int kPkBuf = 25 * kPkRow;        // float2 per transform
 constexpr int kPkTransforms = 10;
 constexpr int kPkHalf = 1250;              // delays per exchange round
-constexpr size_t kPkLdsBytes = ((size_t)kPkTransforms * kPkBuf + 2500 + 1000) * sizeof(float2);   // 130 000 B: one block per CU
+constexpr size_t kPkLdsBytes = ((size_t)kPkTransforms * kPkBuf + 2500 + 1000) * sizeof(float2);   // 128 000 B: one block per CU
 static_assert(kPkTransforms * kPkBuf >= kPkTransforms * kPkHalf, "the exchange buffer lies over the transposes");
 
 // complex product with the second factor in scalar registers (compile-time twiddles: two literals, no vector register)

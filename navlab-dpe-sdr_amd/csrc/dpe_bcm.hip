@@ -559,6 +559,9 @@ struct dpe_bcm {
     dpe_bcm_config cfg;
     std::vector<double> posGrid_h, velGrid_h;  // local shard, fp64 (for zVal)
     float4 *posGrid_d = nullptr, *velGrid_d = nullptr;
+    dpe_owner_detach_fn ownerDetach = nullptr;   // an attached device-resident channel manager: told first when this handle is destroyed
+    void *owner = nullptr;
+    bool gridsBorrowed = false;   // the fp32 device grids belong to another handle of the same dpe_pipe (dpe_bcm_create_sharing)
     double *posGrid64_d = nullptr, *velGrid64_d = nullptr;   // fp64 copies for a measurement formed on the device (dpe_bcm_hook_get)
     float *posScores_d = nullptr, *velScores_d = nullptr;
     long long posPitch = 0, velPitch = 0;   // floats between the score rows of consecutive windows (grid size rounded up to 32)
@@ -854,8 +857,17 @@ extern "C" {
 
 int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
 {
+    return dpe_bcm_create_sharing(cfg, nullptr, out);
+}
+
+// donor != nullptr: a handle for the same configuration and grids as `donor` (a further lane of a dpe_pipe) that uses donor's device
+// copy of the fp32 grids; donor must outlive it.
+int dpe_bcm_create_sharing(const dpe_bcm_config *cfg, dpe_bcm *donor, dpe_bcm **out)
+{
     using namespace dpe;
     DPE_REQUIRE(cfg && out, "[BatchCorrManifold] create: null argument");
+    DPE_REQUIRE(!donor || ((int64_t)donor->posGrid_h.size() == 4 * cfg->posGridSize && (int64_t)donor->velGrid_h.size() == 4 * cfg->velGridSize &&
+                           !donor->gridsBorrowed), "[BatchCorrManifold] create: the grids to share are not these grids");
     DPE_REQUIRE(cfg->samplesPerWindow > 0 && (cfg->samplesPerWindow % 2) == 0,
                 "[BatchCorrManifold] create: samplesPerWindow must be even and positive");
     DPE_REQUIRE(cfg->samplingFrequency > 0 && cfg->numFFTPoints > 0, "[BatchCorrManifold] create: bad fs / numFFTPoints");
@@ -904,8 +916,12 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
     h->posExtent = posExt * 1.000001 + maxR2 / 2.0e7 + 1e-3;   // + second-order term bound (range > 2e7 m) + fp32 slack
     h->velExtent = velExt * 1.000001 + 1e-6;
     const size_t W = cfg->maxWindows, K = cfg->maxChannels;
-    if (upload_grid(cfg->posGrid, cfg->posGridSize, h->posGrid_h, &h->posGrid_d) ||
-        upload_grid(cfg->velGrid, cfg->velGridSize, h->velGrid_h, &h->velGrid_d)) {
+    if (donor) {      // a further lane of a dpe_pipe: the same grids, one device copy
+        h->posGrid_h = donor->posGrid_h; h->velGrid_h = donor->velGrid_h;
+        h->posGrid_d = donor->posGrid_d; h->velGrid_d = donor->velGrid_d;
+        h->gridsBorrowed = true;
+    } else if (upload_grid(cfg->posGrid, cfg->posGridSize, h->posGrid_h, &h->posGrid_d) ||
+               upload_grid(cfg->velGrid, cfg->velGridSize, h->velGrid_h, &h->velGrid_d)) {
         dpe_bcm_destroy(h);
         return -1;
     }
@@ -970,6 +986,8 @@ int dpe_bcm_create(const dpe_bcm_config *cfg, dpe_bcm **out)
 int dpe_bcm_destroy(dpe_bcm *h)
 {
     if (!h) return 0;
+    if (h->ownerDetach) h->ownerDetach(h->owner, 1);
+    if (h->gridsBorrowed) h->posGrid_d = h->velGrid_d = nullptr;
     void *bufs[] = {h->posGrid64_d, h->velGrid64_d, h->posGrid_d, h->velGrid_d, h->posScores_d, h->velScores_d, h->sv_d, h->keys_d, h->wsum_d, h->done_d, h->refPatched_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->svBase_h) (void)hipHostFree(h->svBase_h);
@@ -1221,6 +1239,15 @@ int dpe_bcm_hook_get(dpe_bcm *h, dpe_bcm_hook *out)
     out->S = h->cfg.samplesPerWindow; out->L = h->cfg.lagHalfWidth; out->B = h->cfg.binHalfWidth;
     out->maxWindows = h->cfg.maxWindows; out->maxChannels = h->cfg.maxChannels;
     out->C = h->cfg.numFFTPoints;
+    return 0;
+}
+
+int dpe_bcm_hook_set_owner(dpe_bcm *h, dpe_owner_detach_fn detach, void *owner)
+{
+    DPE_REQUIRE(h, "[BatchCorrManifold] hook: null handle");
+    DPE_REQUIRE(!owner || !h->owner || h->owner == owner, "[BatchCorrManifold] hook: the handle is attached to another channel manager");
+    h->ownerDetach = owner ? detach : nullptr;
+    h->owner = owner;
     return 0;
 }
 

@@ -1169,6 +1169,8 @@ struct dpe_bcs {
     const char *lastKernel = "";   // stage-1 kernel of the last Update (dpe_bcs_stage1_kernel)
     dpe::ChmKArgs co{};            // a task of the device-resident channel manager for the next stage-1 launch (dpe_bcs_cotask_set)
     bool coPending = false;
+    dpe_owner_detach_fn ownerDetach = nullptr;   // an attached device-resident channel manager: told first when this handle is destroyed
+    void *owner = nullptr;
     int devHint = 0;               // dpe_bcs_set_dev_hint: bit 0 = the caller promises the chip kernels' conditions for the device-parameter form
     int *hintViol_h = nullptr, *hintViol_hd = nullptr;   // pinned word a device-side check raises when the promise did not hold: the hint is then dropped
     std::vector<int32_t> idxNext_h;
@@ -1372,6 +1374,7 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
 int dpe_bcs_destroy(dpe_bcs *h)
 {
     if (!h) return 0;
+    if (h->ownerDetach) h->ownerDetach(h->owner, 0);   // (runs the parked time update, forgets this handle)
     void *bufs[] = {h->tTable_d, h->chipTable_d, h->chipBits_d, h->sums_d, h->rideWord_d, h->chan_d, h->part_d, h->mom_d, h->momRep_d, h->codeBank_d, h->carrBank_d, h->info_d, h->status_d};
     for (void *b : bufs) (void)hipFree(b);
     if (h->chanBase_h) (void)hipHostFree(h->chanBase_h);
@@ -1928,6 +1931,16 @@ int dpe_bcs_cotask_flush(dpe_bcs *h, void *stream)
     hipLaunchKernelGGL(dpe::chm_k2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, h->co);
     h->coPending = false;
     DPE_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int dpe_bcs_hook_set_owner(dpe_bcs *h, dpe_owner_detach_fn detach, void *owner)
+{
+    DPE_REQUIRE(h, "[BatchCorrScores] hook: null handle");
+    DPE_REQUIRE(!owner || !h->owner || h->owner == owner, "[BatchCorrScores] hook: the handle is attached to another channel manager");
+    h->ownerDetach = owner ? detach : nullptr;
+    h->owner = owner;
+    if (!owner) h->coPending = false;   // (the manager is going away: whatever it parked points into its buffers)
     return 0;
 }
 

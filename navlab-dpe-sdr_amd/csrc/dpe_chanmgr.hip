@@ -154,6 +154,7 @@ struct dpe_chm_dev {
     int ringDepth = 0;
     long long enqueued = 0;          // Updates enqueued since Start
     hipStream_t lastStream = nullptr;
+    std::vector<hipStream_t> slotStream;   // per ring slot: the stream its window's dpe_chm_dev_step was enqueued on (liveness probe of dpe_chm_dev_fix)
     // sharded grid (dpe_chm_dev_set_shard): the keys are all-reduced before the measurement kernel, which decodes them against the global grids
     dpe_comm *comm = nullptr;
     double *gPos_d = nullptr, *gVel_d = nullptr;
@@ -217,6 +218,22 @@ static int chm_dev_launch(dpe_chm_dev *h, int mode, int meas, const double *xk1k
     return 0;
 }
 
+// Called by dpe_bcs_destroy / dpe_bcm_destroy when the handle goes first (dpe_*_hook_set_owner): the handle is still whole.
+static void chm_dev_detach(void *owner, int which)
+{
+    dpe_chm_dev *h = static_cast<dpe_chm_dev *>(owner);
+    if (which == 0 && h->bcs) {
+        // a time update may be parked in the handle for its next stage-1 launch: run it now (it writes this manager's state and ports
+        // and sends the last window's fix) and let the stream drain -- the handle's buffers are freed next
+        (void)dpe_bcs_cotask_flush(h->bcs, h->lastStream);
+        (void)hipStreamSynchronize(h->lastStream);
+        h->bcs = nullptr;
+    } else if (which == 1 && h->bcm) {
+        (void)hipStreamSynchronize(h->lastStream);   // (a measurement kernel may still be reading its keys)
+        h->bcm = nullptr;
+    }
+}
+
 extern "C" {
 
 int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans, const double *timeGrid, int32_t dimT, dpe_chm_dev **out)
@@ -273,7 +290,8 @@ int dpe_chm_dev_create(const dpe_chm_config *cfg, const dpe_chm_init_chan *chans
     return 0;
 }
 
-// (the manager must be destroyed BEFORE the handles it is attached to: it detaches from them here)
+// The manager and the handles it is attached to may be destroyed in ANY order: whichever goes first tells the other (the handles
+// through dpe_*_hook_set_owner -> chm_dev_detach above, the manager here).
 int dpe_chm_dev_destroy(dpe_chm_dev *h)
 {
     if (!h) return 0;
@@ -282,8 +300,12 @@ int dpe_chm_dev_destroy(dpe_chm_dev *h)
     if (h->bcs) {
         (void)dpe_bcs_cotask_flush(h->bcs, h->lastStream);
         (void)hipStreamSynchronize(h->lastStream);
+        (void)dpe_bcs_hook_set_owner(h->bcs, nullptr, nullptr);
     }
-    if (h->bcm) (void)dpe_bcm_hook_set_publish(h->bcm, 1);
+    if (h->bcm) {
+        (void)dpe_bcm_hook_set_publish(h->bcm, 1);
+        (void)dpe_bcm_hook_set_owner(h->bcm, nullptr, nullptr);
+    }
     (void)hipFree(h->st_d);
     (void)hipFree(h->portBuf_d);
     (void)hipFree(h->gPos_d);
@@ -302,12 +324,14 @@ int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRi
     if (bcs) {
         if (dpe_bcs_hook_get(bcs, &h->hb)) return -1;
         DPE_REQUIRE(h->hb.maxChannels >= h->K, "[cuChanMgr] attach: the BatchCorrScores handle holds %d channels, %d tracked", h->hb.maxChannels, h->K);
+        if (dpe_bcs_hook_set_owner(bcs, chm_dev_detach, h)) return -1;
         h->bcs = bcs;
     }
     if (bcm) {
         if (dpe_bcm_hook_get(bcm, &h->hm)) return -1;
         DPE_REQUIRE(h->hm.maxWindows == 1, "[cuChanMgr] attach: the BatchCorrManifold handle must be a single-window one (the closed loop)");
         DPE_REQUIRE(h->hm.maxChannels >= h->K, "[cuChanMgr] attach: the BatchCorrManifold handle holds %d channels, %d tracked", h->hm.maxChannels, h->K);
+        if (dpe_bcm_hook_set_owner(bcm, chm_dev_detach, h)) return -1;
         h->bcm = bcm;
         if (dpe_bcm_hook_set_publish(bcm, 0)) return -1;   // chm_k1 reads the keys on the device; the fix goes out through the ring
         if (!h->ring_h) {
@@ -315,6 +339,7 @@ int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRi
             memset(h->ring_h, 0, sizeof(dpe_fix_record) * (size_t)fixRingDepth);
             DPE_CHECK_HIP(hipHostGetDevicePointer((void **)&h->ring_hd, h->ring_h, 0));
             h->ringDepth = fixRingDepth;
+            h->slotStream.assign((size_t)fixRingDepth, nullptr);
             h->stage_d = dpe::dev_alloc<dpe_fix_record>(1);
             DPE_REQUIRE(h->stage_d, "[cuChanMgr] attach: device allocation failed");
         }
@@ -413,6 +438,7 @@ int dpe_chm_dev_step(dpe_chm_dev *h, dpe_stream_t stream)
     if (h->comm && dpe_bcm_exchange_keys(h->bcm, h->comm, nullptr, stream)) return -1;
     if (chm_dev_launch(h, 1, 1, nullptr, nullptr, true, (hipStream_t)stream)) return -1;
     h->lastStream = (hipStream_t)stream;
+    h->slotStream[(size_t)(h->enqueued % h->ringDepth)] = (hipStream_t)stream;
     h->enqueued += 1;
     return 0;
 }
@@ -428,6 +454,7 @@ int dpe_chm_dev_fix(dpe_chm_dev *h, int64_t window, dpe_fix_record *out, int32_t
     const unsigned long long want = (unsigned long long)window + 1ull;
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    int idleProbes = 0;
     for (unsigned spins = 0;; ++spins) {
         const unsigned long long seq = __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE);
         if (seq == want) break;
@@ -438,17 +465,28 @@ int dpe_chm_dev_fix(dpe_chm_dev *h, int64_t window, dpe_fix_record *out, int32_t
             const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
             if (us > (double)timeoutMicros) return 1;   // not there yet
         }
-        // liveness: a kernel of the loop that faulted never sends the record -- report the stream's error instead of spinning for ever;
-        // a stream that has drained without the record having arrived (one more look: the write may just have landed) is an error too
-        if ((spins & 0x3ff) == 0x3ff) {
-            const hipError_t q = hipStreamQuery(h->lastStream);
-            if (q != hipSuccess && q != hipErrorNotReady) {
-                dpe::set_error("[cuChanMgr] fix: the loop's stream reports %s while window %lld is awaited", hipGetErrorString(q), (long long)window);
-                return -1;
+        // liveness (every 16 384 polls, ~100 us: the probe takes the stream's lock, which the thread that enqueues the loop wants too):
+        // a kernel of the loop that faulted never sends the record -- report the stream's error instead of spinning for ever.  The
+        // record of window w is sent by the time update BEHIND its measurement kernel, which rides in window w + 1's stage-1 launch:
+        // both windows' streams are looked at, and only when both have drained on two consecutive probes without the record having
+        // arrived is that an error (a single "idle" answer may race the write landing, or a step another stream has yet to flush).
+        if ((spins & 0x3fff) == 0x3fff) {
+            bool idle = true;
+            for (long long w = window; w <= window + 1 && w < h->enqueued; ++w) {
+                const hipError_t q = hipStreamQuery(h->slotStream[(size_t)(w % h->ringDepth)]);
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                    dpe::set_error("[cuChanMgr] fix: the loop's stream reports %s while window %lld is awaited", hipGetErrorString(q), (long long)window);
+                    return -1;
+                }
+                idle = idle && q == hipSuccess;
             }
-            if (q == hipSuccess && __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != want) {
-                dpe::set_error("[cuChanMgr] fix: the stream is idle and window %lld's record never arrived", (long long)window);
-                return -1;
+            if (idle && __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE) != want) {
+                if (++idleProbes >= 2) {
+                    dpe::set_error("[cuChanMgr] fix: the loop's streams are idle and window %lld's record never arrived", (long long)window);
+                    return -1;
+                }
+            } else {
+                idleProbes = 0;
             }
         }
 #if defined(__x86_64__)

@@ -646,7 +646,11 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
     __syncthreads();
     if (k == 0) {
         if (sFlags) st->status |= sFlags;
-        if (a.bcsStatus) *a.bcsStatus = (sFlags >> 3) & 11;   // BatchCorrScores' input flags: bits 0, 1 and 3 (bit 2 is the batch kernels' own)
+        if (a.bcsStatus) {   // BatchCorrScores' input flags: bits 0, 1 and 3 replaced; bit 2 (the batch kernels' own) and the sticky bit 4 kept, as bcs_prep_kernel does
+            const int v = (int)((sFlags >> 3) & 11u);
+            const int old = *a.bcsStatus;          // (one thread, stream order: nothing else writes the word while this kernel runs)
+            if ((old & ~11) != old || v) *a.bcsStatus = (old & ~11) | v;
+        }
     }
 }
 

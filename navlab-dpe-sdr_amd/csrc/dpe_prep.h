@@ -145,6 +145,12 @@ __host__ __device__ inline bool hint_broken(const dpe::BcsChanDev &d, int hintL1
     return (int)d.invStep != hintL1 || d.codeStep > hintStepMax || 6.283185307179586 * fabs(d.fi) > 0.25 * d.fc || offBoundary;
 }
 int dpe_bcs_hook_get(dpe_bcs *h, dpe_bcs_hook *out);
+// Destruction in any order: a device-resident channel manager attached to a handle registers itself here, and the handle's destroy
+// calls `detach(owner, which)` FIRST (which = 0 BatchCorrScores, 1 BatchCorrManifold), while the handle is still whole -- the manager
+// runs what it parked there and forgets the handle.  owner = nullptr unregisters (the manager's own destroy).
+typedef void (*dpe_owner_detach_fn)(void *owner, int which);
+int dpe_bcs_hook_set_owner(dpe_bcs *h, dpe_owner_detach_fn detach, void *owner);
+int dpe_bcm_hook_set_owner(dpe_bcm *h, dpe_owner_detach_fn detach, void *owner);
 // The device-resident channel manager's time update (chm_k2, dpe_chm_dev.h) as a task for this handle's next stage-1 launch:
 // `args` = a dpe::ChmKArgs; the launch carries it as an extra block when its kernel form can (single-window bcs_bank_kernel),
 // otherwise -- and from dpe_bcs_cotask_flush -- it runs as a kernel of its own first.
@@ -161,6 +167,8 @@ struct dpe_bcm_hook {
     long long C;
 };
 int dpe_bcm_hook_get(dpe_bcm *h, dpe_bcm_hook *out);
+// dpe_bcm_create for a further lane of a dpe_pipe (dpe_pipe.hip): the fp32 device grids are donor's (which must outlive the handle)
+int dpe_bcm_create_sharing(const dpe_bcm_config *cfg, dpe_bcm *donor, dpe_bcm **out);
 // enable = 0: the device-parameter Updates of this handle leave keys and counts in device memory only (no ticket, no stores over the
 // host link at the end of the scan); dpe_bcm_results then fetches them with a copy.  Set by dpe_chm_dev_attach.
 int dpe_bcm_hook_set_publish(dpe_bcm *h, int enable);

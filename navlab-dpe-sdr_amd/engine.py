@@ -33,6 +33,8 @@ EXPORTS = [
     "dpe_chm_dev_create", "dpe_chm_dev_destroy", "dpe_chm_dev_attach", "dpe_chm_dev_ports", "dpe_chm_dev_start", "dpe_chm_dev_update",
     "dpe_chm_dev_step", "dpe_chm_dev_fix", "dpe_chm_dev_read", "dpe_bcs_update_prepared", "dpe_bcm_update_prepared", "dpe_bcs_set_dev_hint",
     "dpe_chm_dev_set_shard", "dpe_chm_dev_set_ekf",
+    "dpe_pipe_create", "dpe_pipe_destroy", "dpe_pipe_in_flight", "dpe_pipe_submit", "dpe_pipe_acquire", "dpe_pipe_mark_stage1",
+    "dpe_pipe_commit", "dpe_pipe_lane", "dpe_pipe_set_in_flight", "dpe_pipe_lane_at", "dpe_pipe_results", "dpe_pipe_samples_consumed", "dpe_pipe_join", "dpe_pipe_synchronize",
 ]
 
 
@@ -316,10 +318,25 @@ class BatchCorrScores:
 
     def Stop(self):
         if self.Started:
-            _check(lib().dpe_bcs_destroy(self._h))
+            if getattr(self, "_owned", True):      # (a lane of a Pipe is destroyed by the pipe)
+                _check(lib().dpe_bcs_destroy(self._h))
             self._h = C.c_void_p(None)
             self.Started = False
         return 0
+
+    @classmethod
+    def _adopt(cls, handle, fs, S, L, B, max_windows, max_channels):
+        """Python face of a handle that a dpe_pipe owns."""
+        self = cls(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_windows=max_windows, max_channels=max_channels)
+        self._h, self._owned = C.c_void_p(handle), False
+        code, carr = C.c_void_p(), C.c_void_p()
+        nlag, nbin, nfft = C.c_int32(), C.c_int32(), C.c_int64()
+        _check(lib().dpe_bcs_outputs(self._h, C.byref(code), C.byref(carr), C.byref(nlag), C.byref(nbin), C.byref(nfft)))
+        self.CodeScores, self.CarrScores = code.value, carr.value
+        self.nLag, self.nBin, self.NumFFTPoints = nlag.value, nbin.value, nfft.value
+        self.Started = True
+        self._W = self._K = 0
+        return self
 
     def __del__(self):
         try:            # at interpreter shutdown module globals may already be gone
@@ -404,19 +421,7 @@ class BatchCorrManifold:
                         self.pos_grid.shape[0], self.vel_grid.shape[0], self.pos_off, self.vel_off,
                         1 if self.write_scores else 0, 1 if self.weighted_mean else 0, 1 if self.reference_pair else 0, 0)
         _check(lib().dpe_bcm_create(C.byref(cfg), C.byref(self._h)))
-        self.PosScores = self.VelScores = None
-        if self.write_scores:
-            ps, vs = C.c_void_p(), C.c_void_p()
-            _check(lib().dpe_bcm_scores(self._h, C.byref(ps), C.byref(vs)))
-            self.PosScores, self.VelScores = ps.value, vs.value
-        pp, vp = C.c_int64(), C.c_int64()
-        _check(lib().dpe_bcm_scores_pitch(self._h, C.byref(pp), C.byref(vp)))
-        self.PosScoresPitch, self.VelScoresPitch = pp.value, vp.value     # floats between the rows of consecutive windows
-        keys = C.c_void_p()
-        _check(lib().dpe_bcm_keys(self._h, C.byref(keys)))
-        self.Keys = keys.value
-        self.Started = True
-        self._W = 0
+        self._bind_outputs()
         return 0
 
     def Update(self, CodeScores, CarrScores, win, chan, stream=None):
@@ -510,14 +515,171 @@ class BatchCorrManifold:
 
     def Stop(self):
         if self.Started:
-            _check(lib().dpe_bcm_destroy(self._h))
+            if getattr(self, "_owned", True):      # (a lane of a Pipe is destroyed by the pipe)
+                _check(lib().dpe_bcm_destroy(self._h))
             self._h = C.c_void_p(None)
             self.Started = False
         return 0
 
+    def _bind_outputs(self):
+        self.PosScores = self.VelScores = None
+        if self.write_scores:
+            ps, vs = C.c_void_p(), C.c_void_p()
+            _check(lib().dpe_bcm_scores(self._h, C.byref(ps), C.byref(vs)))
+            self.PosScores, self.VelScores = ps.value, vs.value
+        pp, vp = C.c_int64(), C.c_int64()
+        _check(lib().dpe_bcm_scores_pitch(self._h, C.byref(pp), C.byref(vp)))
+        self.PosScoresPitch, self.VelScoresPitch = pp.value, vp.value     # floats between the rows of consecutive windows
+        keys = C.c_void_p()
+        _check(lib().dpe_bcm_keys(self._h, C.byref(keys)))
+        self.Keys = keys.value
+        self.Started = True
+        self._W = 0
+
+    @classmethod
+    def _adopt(cls, handle, *args, **kw):
+        """Python face of a handle that a dpe_pipe owns."""
+        self = cls(*args, **kw)
+        self._h, self._owned = C.c_void_p(handle), False
+        self._bind_outputs()
+        return self
+
     def __del__(self):
         try:            # at interpreter shutdown module globals may already be gone
             self.Stop()
+        except Exception:
+            pass
+
+
+class Pipe:
+    """dpe_pipe: `in_flight` batches of the BatchCorrScores -> BatchCorrManifold path on the device at once (the reference's
+    overlap of ingest and compute: sampleblock.cu:327-447, batchcorrscores.h:60-64).  submit() deals a batch to the next lane and
+    returns its ticket; results(ticket) waits for that batch only.  lane(ticket) -> (BatchCorrScores, BatchCorrManifold, stream)
+    of the batch (banks, scores, keys), valid until `in_flight` later batches have been issued."""
+
+    def __init__(self, SamplingFrequency, samples_per_window, pos_grid, vel_grid, lag_half_width=8, bin_half_width=48,
+                 max_windows=1, max_channels=8, in_flight=2, LPower=1, write_scores=True, pos_index_offset=0, vel_index_offset=0,
+                 bcm_max_windows=None, weighted_mean=False):
+        self.fs, self.S = float(SamplingFrequency), int(samples_per_window)
+        self.L, self.B = int(lag_half_width), int(bin_half_width)
+        self.max_windows, self.max_channels = int(max_windows), int(max_channels)
+        self.bcm_max_windows = int(bcm_max_windows) if bcm_max_windows else self.max_windows   # (stage 1 sharded by window: the scan sees all)
+        self.pos_grid = np.ascontiguousarray(pos_grid, dtype=np.float64)
+        self.vel_grid = np.ascontiguousarray(vel_grid, dtype=np.float64)
+        self._bcm_kw = dict(LPower=int(LPower), lag_half_width=self.L, bin_half_width=self.B, max_windows=self.bcm_max_windows,
+                            max_channels=self.max_channels, write_scores=bool(write_scores), pos_index_offset=int(pos_index_offset),
+                            vel_index_offset=int(vel_index_offset), weighted_mean=bool(weighted_mean))
+        bcs = BcsConfig(self.S, self.L, self.B, self.max_windows, self.max_channels, 0, self.fs)
+        dp = C.POINTER(C.c_double)
+        bcm = BcmConfig(self.S, self.L, self.B, int(LPower), self.bcm_max_windows, self.max_channels, carr_fft_len(self.S), self.fs,
+                        self.pos_grid.ctypes.data_as(dp), self.vel_grid.ctypes.data_as(dp), self.pos_grid.shape[0],
+                        self.vel_grid.shape[0], int(pos_index_offset), int(vel_index_offset), 1 if write_scores else 0,
+                        1 if weighted_mean else 0, 0, 0)
+        self._h = C.c_void_p(None)
+        _check(lib().dpe_pipe_create(C.byref(bcs), C.byref(bcm), C.c_int32(in_flight), C.byref(self._h)))
+        self.lanes = self.in_flight = int(in_flight)
+        self._faces = {}      # handle pair -> (BatchCorrScores, BatchCorrManifold) faces of a lane
+        self._nw = {}         # ticket -> (windows, channels) of the batches the lanes hold
+
+    def set_in_flight(self, n):
+        """Deal to the first n lanes only (1: one stream)."""
+        _check(lib().dpe_pipe_set_in_flight(self._h, C.c_int32(n)))
+        self.in_flight = int(n)
+
+    def lane_at(self, i):
+        """(BatchCorrScores, BatchCorrManifold, stream) of lane i, for set-up calls (profile, set_graph)."""
+        b, m, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().dpe_pipe_lane_at(self._h, C.c_int32(i), C.byref(b), C.byref(m), C.byref(st)))
+        return self._lane_faces(b, m, st)
+
+    def _note(self, ticket, W, K):
+        self._nw[ticket] = (W, K)
+        for t in [t for t in self._nw if t <= ticket - self.lanes]:
+            del self._nw[t]
+
+    def _lane_faces(self, bcs_h, bcm_h, st):
+        key = (bcs_h.value, bcm_h.value)
+        if key not in self._faces:
+            b = BatchCorrScores._adopt(bcs_h.value, self.fs, self.S, self.L, self.B, self.max_windows, self.max_channels)
+            m = BatchCorrManifold._adopt(bcm_h.value, self.fs, self.S, b.NumFFTPoints, self.pos_grid, self.vel_grid, **self._bcm_kw)
+            self._faces[key] = (b, m)
+        b, m = self._faces[key]
+        return b, m, st.value
+
+    def submit(self, Samples, chan_start, win, chan_end, window_stride=None, stream=None):
+        """One batch: Samples device int16 [W, 2 S]; chan_start CHAN_START_DTYPE [W, K]; win BCM_WINDOW_DTYPE [W]; chan_end
+        CHAN_END_DTYPE [W, K].  `stream`: the stream that produced Samples (the lane waits for it on the device).  -> ticket"""
+        cs = np.ascontiguousarray(chan_start)
+        ce = np.ascontiguousarray(chan_end)
+        win = np.ascontiguousarray(np.atleast_1d(win))
+        if cs.ndim == 1:
+            cs, ce = cs[None, :], ce[None, :]
+        W, K = cs.shape
+        assert ce.shape == (W, K) and win.shape[0] == W
+        t = C.c_int64(-1)
+        stride = self.S if window_stride is None else int(window_stride)
+        _check(lib().dpe_pipe_submit(self._h, _ptr(Samples), C.c_int64(stride), C.c_int32(W), C.c_int32(K),
+                                     cs.ctypes.data_as(C.POINTER(ChanStart)), win.ctypes.data_as(C.POINTER(BcmWindow)),
+                                     ce.ctypes.data_as(C.POINTER(ChanEnd)), _stream(stream), C.byref(t)))
+        self._note(t.value, W, K)
+        return t.value
+
+    def acquire(self, stream=None):
+        """The next lane for a host that drives the two stages itself (multi-GPU exchanges in between):
+        -> (ticket, BatchCorrScores, BatchCorrManifold, lane stream); finish with commit(ticket, n_windows)."""
+        t, b, m, st = C.c_int64(-1), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().dpe_pipe_acquire(self._h, _stream(stream), C.byref(t), C.byref(b), C.byref(m), C.byref(st)))
+        return (t.value,) + self._lane_faces(b, m, st)
+
+    def mark_stage1(self, ticket):
+        _check(lib().dpe_pipe_mark_stage1(self._h, C.c_int64(ticket)))
+
+    def commit(self, ticket, n_windows, n_chan=None):
+        _check(lib().dpe_pipe_commit(self._h, C.c_int64(ticket), C.c_int32(n_windows)))
+        self._note(ticket, int(n_windows), n_chan)
+
+    def lane(self, ticket):
+        b, m, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().dpe_pipe_lane(self._h, C.c_int64(ticket), C.byref(b), C.byref(m), C.byref(st)))
+        fb, fm, s = self._lane_faces(b, m, st)
+        held = self._nw.get(ticket)
+        if held:
+            fm._W = held[0]
+            fb._W, fb._K = min(held[0], self.max_windows), held[1] or fb._K
+        return fb, fm, s
+
+    def results(self, ticket):
+        held = self._nw.get(ticket)
+        W = held[0] if held else self.bcm_max_windows
+        res = (BcmResult * W)()
+        _check(lib().dpe_pipe_results(self._h, C.c_int64(ticket), res))
+        return [dict(zVal=np.array(r.zVal), RVal=np.eye(8), posIndex=r.posIndex, velIndex=r.velIndex,
+                     posScore=r.posScore, velScore=r.velScore, posOutOfWindow=r.posOutOfWindow,
+                     velOutOfWindow=r.velOutOfWindow, zValMean=np.array(r.zValMean),
+                     weightedSums=np.array([list(r.weightedSums[0]), list(r.weightedSums[1])])) for r in res]
+
+    def samples_consumed(self, ticket, stream=None):
+        _check(lib().dpe_pipe_samples_consumed(self._h, C.c_int64(ticket), _stream(stream)))
+
+    def join(self, stream=None):
+        _check(lib().dpe_pipe_join(self._h, _stream(stream)))
+
+    def synchronize(self):
+        _check(lib().dpe_pipe_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            for b, m in self._faces.values():
+                b.Stop(); m.Stop()          # (faces only: the pipe owns the handles)
+            self._faces = {}
+            _check(lib().dpe_pipe_destroy(self._h))
+            self._h = C.c_void_p(None)
+
+    Stop = close
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -25,7 +25,7 @@ def test_header_symbols_exported(built):
     for n in sorted(names):
         assert hasattr(built, n), n
     assert names == set(dpe.engine.EXPORTS)
-    assert built.dpe_abi_version() == 3
+    assert built.dpe_abi_version() == 4
 
 
 def test_ca_code_host(built, golden):

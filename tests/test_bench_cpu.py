@@ -61,3 +61,35 @@ def test_config_table():
         vel = dpe.synth.rand_grid(4, 4096, half=(6.0, 6.0, 6.0, 3.0))
         L, B = dpe.pipeline.bank_half_widths(pos, vel, c["fs"], dpe.engine.carr_fft_len(c["S"]))
         assert L <= c["L"] + 2 and B <= c["B"] + 3
+
+
+OTHERS_KEYS = {"ms_per_step", "value", "unit", "x_realtime", "roofline", "cpu_baseline"}
+
+
+def test_others_stanza_schema():
+    """The headline JSON line carries the non-headline configurations in brief (`others`: acq, H, M) -- the driver records the
+    last line only.  bench.brief() on lines of the shape run_workload / acq_line produce."""
+    import bench
+    cpu = {"value": 1.0e7, "unit": "gridpoint*SV/s", "cores": 1, "kind": "port", "sample": "1 full windows", "x_realtime": 0.01, "host": {}}
+    line = {"ms_per_step": 0.65, "value": 4.7e11, "unit": "gridpoint*SV/s", "x_realtime": 3900.0, "stage1_dev_status": 0,
+            "one_stream_ms_per_step": 0.71,
+            "config": {"workload": "H: ...", "windows_per_step": 128, "in_flight": 2},
+            "roofline": {"bound": "hbm", "kernel": "bcs_bank_chip2_kernel", "frac": 0.058, "whole_step_frac": 0.14, "avg_launch_ms": 0.55,
+                         "achieved": 465.0, "peak": 8000.0, "note": "long text that must not travel"},
+            "cpu_baseline": cpu, "kernels_ms_per_step": {"bcs_bank": 0.55}, "fixes": [[1, 2, 3.0, 4.0]] * 16}
+    b = bench.brief(line)
+    assert OTHERS_KEYS | {"stage1_dev_status", "windows_per_step", "in_flight", "one_stream_ms_per_step"} <= set(b)
+    assert set(b["roofline"]) == {"kernel", "frac", "whole_step_frac", "avg_launch_ms"}
+    assert set(b["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and b["in_flight"] == 2
+    acq = {"ms_per_step": 0.055, "value": 1.8e11, "unit": "cell/s", "x_realtime": 180.0, "config": {"workload": "acq: ...", "mode": "coherent"},
+           "modes": {m: {"ms_per_window": t, "cells_per_s": 1.0, "flop_frac": f} for m, t, f in
+                     (("coherent", 0.055, 0.07), ("textbook", 0.24, 0.15), ("noncoherent", 0.30, 0.15), ("noncoherent_25x500Hz", 0.11, 0.1))},
+           "roofline": {"bound": "hbm", "kernel": "dpe_acq_search (a long description)", "frac": 0.09, "flop_frac": 0.075, "avg_launch_ms": 0.055},
+           "cpu_baseline": {"value": 3.6e6, "unit": "cell/s", "cores": 1, "kind": "port", "sample": "x"}}
+    a = bench.brief(acq)
+    assert OTHERS_KEYS | {"modes", "mode"} <= set(a) and set(a["modes"]) == set(acq["modes"])
+    assert all(set(v) == {"ms", "flop_frac"} for v in a["modes"].values()) and a["roofline"]["flop_frac"] == 0.075
+    # short enough to survive beside the headline's own fields
+    assert len(json.dumps({"acq": a, "H": b, "M": b})) < 2500
+    assert bench.brief(None) is None
+    assert bench.FP32_VECTOR_PEAK_TFLOPS == 157.3 and bench.HBM_PEAK_GBS == 8000.0

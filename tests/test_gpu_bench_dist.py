@@ -137,3 +137,32 @@ def test_one_rank_rccl_self_test_through_the_c_abi():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["config"]["comm"] == "dpe_comm (C-ABI)" and d["value"] > 0
+
+
+def test_default_invocation_carries_every_configuration_in_the_last_line():
+    """`python bench.py` (N = 1): acq, H and M lines first, then the R headline whose `others` stanza repeats them in brief --
+    time, value, roofline fractions, device status, CPU baseline -- because the driver records the last line only.  The timed
+    regions run with two batches in flight (the library's dpe_pipe), the one-stream time beside them."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DPE_BENCH_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--clock-warmup-s", "0", "--min-batch-s", "0.01",
+           "--batches", "2", "--cpu-budget-s", "0.5", "--windows", "32", "--extra-windows", "32"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 4 and [l["headline"] for l in lines] == [False, False, False, True]
+    d = lines[-1]
+    assert d["config"]["workload"].startswith("R:") and d["config"]["in_flight"] == 2 and d["one_stream_ms_per_step"] > 0
+    assert d["roofline"]["kernel"] == "bcm_scan_kernel" and 0 < d["roofline"]["frac"] < 1.0
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    o = d["others"]
+    assert set(o) == {"acq", "H", "M"}
+    for k in ("H", "M"):
+        assert o[k]["ms_per_step"] > 0 and o[k]["value"] > 0 and o[k]["in_flight"] == 2 and o[k]["one_stream_ms_per_step"] > 0
+        assert o[k]["stage1_dev_status"] in (0, None) and 0 < o[k]["roofline"]["frac"] < 1.0 and o[k]["roofline"]["whole_step_frac"] > 0
+        assert o[k]["cpu_baseline"]["kind"] == "port" and o[k]["cpu_baseline"]["cores"] == 1 and o[k]["cpu_baseline"]["value"] > 0
+    assert o["H"]["roofline"]["kernel"] == "bcs_bank_chip2_kernel" and o["M"]["roofline"]["kernel"] == "bcm_scan_kernel"
+    assert set(o["acq"]["modes"]) == {"coherent", "textbook", "noncoherent", "noncoherent_25x500Hz"}
+    assert all(0 < m["flop_frac"] < 1 and m["ms"] > 0 for m in o["acq"]["modes"].values())
+    assert o["acq"]["cpu_baseline"]["value"] > 0 and 0 < o["acq"]["roofline"]["flop_frac"] < 1
+    # the brief copies are the lines' own numbers
+    assert o["H"]["ms_per_step"] == lines[1]["ms_per_step"] and o["M"]["value"] == lines[2]["value"] and o["acq"]["value"] == lines[0]["value"]

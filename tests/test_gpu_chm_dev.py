@@ -188,3 +188,53 @@ def test_cpp_flow_device_loop_with_the_filter_matches_the_host_driven_filter(tmp
         assert rows[name].shape == (W, 8)
     assert np.array_equal(rows["dev"], rows["host"])               # "%f" rows
     assert not np.array_equal(rows["dev"], rows["pass"])           # ... and the filter really ran (the pass-through rows differ)
+
+
+@pytest.mark.parametrize("order", ["handles_first", "manager_first", "mixed"])
+def test_manager_and_attached_handles_may_be_destroyed_in_any_order(order):
+    """The device-resident channel manager parks a time update in the attached BatchCorrScores handle and reads the attached
+    BatchCorrManifold's keys: whichever of the three is destroyed first tells the others (dpe_*_hook_set_owner), also with a time
+    update still parked -- dsp::Flow::Stop() stops modules in Add order, i.e. the handles BEFORE the manager (flow.cu:168-170).
+    After the handles are gone the manager still answers reads, and refuses a step with a message."""
+    import torch
+    fs, S, K = 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(2, fs, S, K, seed=3, amp=200.0)
+    ho = dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV)
+    g = dpe.synth.uniform_grid(9, 1.0)
+    tg = np.unique(g[:, 3])
+    L, B = dpe.pipeline.bank_half_widths(g, g, fs, dpe.engine.carr_fft_len(S))
+    x = np.array(ho["X_ECEF"], dtype=np.float64)
+    iq_d = torch.from_numpy(iq).to("cuda:0")
+    bcs = dpe.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_channels=K)
+    bcs.Start()
+    bcm = dpe.BatchCorrManifold(fs, S, bcs.NumFFTPoints, g, g, lag_half_width=L, bin_half_width=B, max_channels=K)
+    bcm.Start()
+    cm = dpe.engine.ChanMgrDev.from_handoff(ho, S / fs, K, tg)
+    cm.attach(bcs, bcm, 4)
+    cm.Start(x)
+    for w in range(2):
+        bcs.UpdatePrepared(iq_d[w], K)
+        bcm.UpdatePrepared(bcs.CodeScores, bcs.CarrScores, K)
+        cm.step()                      # leaves window w's time update parked in `bcs` for the next stage-1 launch
+    first = cm.fix(0)
+    assert np.isfinite(first["zVal"]).all()
+    if order == "handles_first":
+        bcs.Stop(); bcm.Stop()
+        second = cm.fix(1, timeout_us=2000000)     # the parked update ran when `bcs` went: it sent window 1's fix
+        assert second is not None and np.isclose(second["rxTime"] - first["rxTime"], S / fs, rtol=0, atol=1e-9)
+        s, e, win = cm.outputs()
+        assert np.isfinite(win["rxTime"][0]) and cm.status == 0
+        with pytest.raises(dpe.DpeError, match="attached"):
+            cm.step()
+        cm.Stop()
+    elif order == "manager_first":
+        cm.Stop()
+        # the handles are ordinary handles again: a host-parameter Update works and publishes its results
+        _, cs, ce, bw = dpe.workload.build_windows(1, fs, S, K, seed=3, amp=200.0)
+        bcs.Update(iq_d[0], cs[0])
+        bcm.Update(bcs.CodeScores, bcs.CarrScores, bw[:1], ce[0])
+        r = bcm.results()[0]
+        assert r["posIndex"] >= 0 and np.isfinite(r["zVal"]).all()
+        bcm.Stop(); bcs.Stop()
+    else:
+        bcm.Stop(); cm.Stop(); bcs.Stop()
