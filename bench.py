@@ -460,11 +460,13 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     stage1_status = 0
     have_status = False
     for ln in lanes:
+        if ln["bcs"].stage1_kernel != "bcs_bank_chip2_kernel":
+            continue      # (no device-side status on the other paths: per-sample kernels with host parameters)
         try:
             stage1_status |= int(ln["bcs"].dev_status(stream=ln["stream"]))
             have_status = True
         except dpe.engine.DpeError:
-            pass          # (no device-side status on this path: per-sample kernels with host parameters)
+            pass          # (a batch too small for the riding DC sums)
     if not have_status:
         stage1_status = None
     # bits 1 / 2 / 8 are input errors (PRN / code frequency out of range, a broken chip-kernel promise): the line would describe

@@ -229,7 +229,10 @@ static void chm_dev_detach(void *owner, int which)
         (void)hipStreamSynchronize(h->lastStream);
         h->bcs = nullptr;
     } else if (which == 1 && h->bcm) {
-        (void)hipStreamSynchronize(h->lastStream);   // (a measurement kernel may still be reading its keys)
+        // the parked time update also writes the NEXT window's coefficient blocks of this BatchCorrManifold handle: run it while they
+        // exist; a measurement kernel may still be reading the handle's keys
+        if (h->bcs) (void)dpe_bcs_cotask_flush(h->bcs, h->lastStream);
+        (void)hipStreamSynchronize(h->lastStream);
         h->bcm = nullptr;
     }
 }
