@@ -365,11 +365,13 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
     def step(src=None, in_stream=None):
         src = iq_d if src is None else src
         if not ctx.use_dist:           # one GPU: the whole step is one C call (dpe_pipe_submit)
-            t = pipe.submit(src, cs_l, bw, ce, stream=in_stream or stream)
+            # (the timed region's samples are resident in HBM since before it started: no input dependency -- DPE_STREAM_NONE;
+            #  the PCIe-inclusive passes hand over the stream their upload runs on)
+            t = pipe.submit(src, cs_l, bw, ce, stream=in_stream or dpe.engine.STREAM_NONE)
             last[0] = (t, lanes[0])
             return
         # N > 1: the same lane, driven in pieces -- this rank's exchanges go between the stages, on the lane's stream
-        t, b_, m_, ls = pipe.acquire(stream)
+        t, b_, m_, ls = pipe.acquire(in_stream or dpe.engine.STREAM_NONE)
         ln = by_handle[b_._h.value]
         b_.Update(src, cs_l, stream=ls)
         pipe.mark_stage1(t)
@@ -506,7 +508,7 @@ def run_workload(name, ctx, args, steps, warmup, headline, cached=None):
         for _ in range(steps):
             pipe.samples_consumed(last[0][0], stream=stream)     # the refill waits (on the device) for stage 1 of the step before
             iq_d.copy_(iq_pin, non_blocking=True)                # SampleBlock's H2D leg (sampleblock.cu:356-410), same stream
-            step()
+            step(in_stream=stream)
         fence()
         pcie_value = float(steps) * W * 2.0 * G * K / (time.perf_counter() - t1)
         # the same with the upload double-buffered on a copy stream (what SampleBlock does per window): batch n+1

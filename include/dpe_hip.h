@@ -147,12 +147,13 @@ int dpe_bcs_dev_status(dpe_bcs *h, int32_t *status, dpe_stream_t stream);
  * (|fi| below ~40 kHz) and a code frequency within 1e-5 of 1.023 MHz.  The call then decides from nominal values, reads nothing
  * back and does not wait for the stream; the prep kernel checks the promise (and that the nav-bit boundary falls on a chip boundary
  * of the replica, which it does unless fp64 rounding separates the two expressions -- about once in 1e10 windows): bit 3 of
- * dpe_bcs_dev_status = it did not hold for that window (banks then within the chip kernel's error for such input, not within the
- * stated tolerance; re-run the window without the hint).  A broken promise also withdraws the hint: the device-side check raises a
- * pinned word, and from the next call that finds it raised the handle reads the derived block back and chooses the kernel from the
- * real values again, for the rest of its life (the flagged window -- at most the few the host had already enqueued -- keeps its bit 3).
- * The same check runs in the device-resident channel manager's kernel for dpe_bcs_update_prepared, which launches no prep kernel
- * (bit 6 = 64 of the fix record's status).  0 clears the promise. */
+ * dpe_bcs_dev_status = it did not hold for that window, AND THE WINDOW WAS RE-RUN: behind every hinted chip-kernel launch the call
+ * enqueues the general per-sample kernels guarded by that bit (two launches whose blocks leave at once when it is clear), so the
+ * banks of a flagged window are the per-sample kernels' -- within the stated tolerance like every other window's.  A broken promise
+ * also withdraws the hint: the device-side check raises a pinned word, and from the next call that finds it raised the handle reads
+ * the derived block back and chooses the kernel from the real values again, for the rest of its life.  The same check and the same
+ * guarded re-run serve dpe_bcs_update_prepared, whose parameter block the device-resident channel manager's kernel writes (bit 6 =
+ * 64 of the fix record's status).  0 clears the promise. */
 #define DPE_DEV_HINT_CHIP 1
 int dpe_bcs_set_dev_hint(dpe_bcs *h, int32_t flags);
 /* Output ports CodeScores / CarrScores / NumFFTPoints (batchcorrscores.cu:696-698,869-874).
@@ -315,6 +316,9 @@ int dpe_bcm_results_from_keys(dpe_bcm *h, const uint64_t *keys_host, int32_t nWi
  * A batch is named by its TICKET (0, 1, 2, ...); its banks, scores, keys and results live in its lane until the lane is dealt
  * again, i.e. until `inFlight` later batches have been issued -- collect them before that.  One thread drives a pipe. */
 typedef struct dpe_pipe dpe_pipe;
+/* inputStream value for "the samples are already there" (resident since before anything in flight: no event, no cross-stream wait --
+ * a dependency between two hardware queues costs the lane ~10 us of start latency per batch). */
+#define DPE_STREAM_NONE ((dpe_stream_t)(intptr_t)-1)
 int dpe_pipe_create(const dpe_bcs_config *bcsCfg, const dpe_bcm_config *bcmCfg, int32_t inFlight /* 1..8 */, dpe_pipe **out);
 int dpe_pipe_destroy(dpe_pipe *p);                       /* waits for the lanes, then destroys their handles */
 int dpe_pipe_in_flight(const dpe_pipe *p);

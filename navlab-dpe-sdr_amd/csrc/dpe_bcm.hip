@@ -516,7 +516,7 @@ __device__ static inline bool ref_pair_index_dev(const double *R, const double *
     *ciOut = floor(idx + 1);                                                // :1799
     return true;
 }
-__global__ __launch_bounds__(64) void bcm_refpair_eval_kernel(BcmPortsDev p, int K, double rxTime, double fs, int S, int L, int lPower,
+__global__ __launch_bounds__(64) void bcm_refpair_eval_kernel(BcmPortsDev p, int K, double rxTime, const double *__restrict__ rxTimeDev, double fs, int S, int L, int lPower,
                                                                const double *__restrict__ grid64, const float2 *__restrict__ bank, int maxK,
                                                                const unsigned long long *__restrict__ cand, unsigned long long capacity,
                                                                float *__restrict__ scores, long long pitch, BcmDevWin *__restrict__ hostWin,
@@ -524,6 +524,7 @@ __global__ __launch_bounds__(64) void bcm_refpair_eval_kernel(BcmPortsDev p, int
 {
     const unsigned long long nAll = cand[0], n = nAll < capacity ? nAll : capacity;
     if (nAll > capacity && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&hostWin->bad, 2);
+    if (rxTimeDev) rxTime = *rxTimeDev;   // (the prepared form: the receiver time is the channel manager's device port)
     const int nLag = 2 * L + 1;
     for (unsigned long long j = (unsigned long long)blockIdx.x * 64 + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 64) {
         const unsigned long long wi = cand[1 + j];
@@ -596,6 +597,8 @@ struct dpe_bcm {
     long long refPatched = 0;               // points patched by the last Update (diagnostic)
     dpe::BcmPortsDev refPorts{};            // the device ports of the dpe_bcm_update_dev in progress (referencePair on the device)
     double refRxTime = 0.0;
+    const double *refRxTime_d = nullptr;    // the prepared form: rxTime as a device port of the attached channel manager (dpe_bcm_hook_set_ref_ports)
+    bool refPortsAttached = false;
     unsigned long long *refPatched_d = nullptr;
     std::vector<dpe_bcm_window> win_h;
     dpe::BcmDevWin *devWin_h = nullptr, *devWin_hd = nullptr;   // pinned [2]: window frame of a device-parameter Update (written by bcm_prep_kernel),
@@ -1162,7 +1165,7 @@ static int bcm_update_impl(dpe_bcm *h, const float *codeBank_dev, const float *c
         const unsigned gx = (unsigned)((G + 256 * 8 - 1) / (256 * 8));
         hipLaunchKernelGGL(bcm_refpair_candidates_kernel, dim3(gx > 1024 ? 1024 : gx, 1), dim3(256), 0, stream, h->posGrid_d, G, h->sv_d,
                            h->cfg.maxChannels, h->cfg.lagHalfWidth, 5e-4, h->refCand_d, h->refCap);
-        hipLaunchKernelGGL(bcm_refpair_eval_kernel, dim3(64), dim3(64), 0, stream, h->refPorts, (int)nChan, h->refRxTime, h->cfg.samplingFrequency,
+        hipLaunchKernelGGL(bcm_refpair_eval_kernel, dim3(64), dim3(64), 0, stream, h->refPorts, (int)nChan, h->refRxTime, h->refRxTime_d, h->cfg.samplingFrequency,
                            h->cfg.samplesPerWindow, h->cfg.lagHalfWidth, h->cfg.lPower, h->posGrid64_d, reinterpret_cast<const float2 *>(codeBank_dev),
                            h->cfg.maxChannels, h->refCand_d, h->refCap, h->posScores_d, h->posPitch, h->devWin_hd + use, h->refPatched_d);
         hipLaunchKernelGGL(bcm_zero_pos_keys_kernel, dim3(1), dim3(64), 0, stream, keys, 1);
@@ -1199,6 +1202,7 @@ int dpe_bcm_update_dev(dpe_bcm *h, const float *codeBank_dev, const float *carrB
     const size_t W = h->cfg.maxWindows, maxK = h->cfg.maxChannels;
     h->refPorts = p;
     h->refRxTime = rxTime;
+    h->refRxTime_d = nullptr;
     hipLaunchKernelGGL(bcm_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, (int)nChan, rxTime, (const double *)nullptr, h->cfg.samplingFrequency,
                        (double)h->cfg.numFFTPoints, h->cfg.samplesPerWindow, h->cfg.lagHalfWidth, h->cfg.binHalfWidth, (long long)h->cfg.numFFTPoints,
                        h->sv_d, h->sv_d + W * maxK, h->devWin_hd + (h->cur ^ 1));   // (the frame of the key set this Update reduces into)
@@ -1209,9 +1213,26 @@ int dpe_bcm_update_prepared(dpe_bcm *h, const float *codeBank_dev, const float *
 {
     DPE_REQUIRE(h, "[BatchCorrManifold] Update: null argument");
     DPE_REQUIRE(nChan >= 1 && nChan <= h->cfg.maxChannels, "[BatchCorrManifold] Update: nChan %d out of range", nChan);
-    DPE_REQUIRE(!h->refPair, "[BatchCorrManifold] Update: referencePair needs the port arrays (dpe_bcm_update_dev) or the host form of the inputs: "
-                             "the prepared blocks hold the expansion coefficients only");
+    // referencePair (batchcorrmanifold.cu:1798-1812): the prepared blocks hold expansion coefficients only, so the fp64 re-evaluation
+    // reads the port arrays of the channel manager that wrote them (handed over at dpe_chm_dev_attach) -- the same device-side
+    // candidates / re-evaluation / patch / arg-max kernels as dpe_bcm_update_dev, nothing read back
+    DPE_REQUIRE(!h->refPair || h->refPortsAttached, "[BatchCorrManifold] Update: referencePair needs the port arrays: attach the device-resident channel "
+                                                    "manager (dpe_chm_dev_attach), or use dpe_bcm_update_dev / the host form of the inputs");
+    DPE_REQUIRE(!h->refPair || (h->cfg.writeScores && !h->cfg.weightedMean),
+                "[BatchCorrManifold] Update: referencePair on the device patches the scores in place: it needs writeScores and no weightedMean");
     return bcm_update_impl(h, codeBank_dev, carrBank_dev, 1, nChan, nullptr, nullptr, stream);
+}
+
+int dpe_bcm_hook_set_ref_ports(dpe_bcm *h, const dpe_bcm_ports_dev *ports, const double *rxTime_dev)
+{
+    using namespace dpe;
+    DPE_REQUIRE(h, "[BatchCorrManifold] hook: null handle");
+    if (!ports) { h->refPortsAttached = false; h->refRxTime_d = nullptr; return 0; }
+    h->refPorts = BcmPortsDev{ports->xCurrkk1, ports->enu2ecef, ports->satStates, ports->codePhaseEnd, ports->codeFrequency, ports->carrierFrequency,
+                              ports->cpRefTOW, ports->cpElapsedEnd, ports->cpRef, ports->dopplerSign, ports->dimT};
+    h->refRxTime_d = rxTime_dev;
+    h->refPortsAttached = true;
+    return 0;
 }
 
 int dpe_bcm_hook_get(dpe_bcm *h, dpe_bcm_hook *out)

@@ -307,6 +307,7 @@ int dpe_chm_dev_destroy(dpe_chm_dev *h)
     }
     if (h->bcm) {
         (void)dpe_bcm_hook_set_publish(h->bcm, 1);
+        (void)dpe_bcm_hook_set_ref_ports(h->bcm, nullptr, nullptr);
         (void)dpe_bcm_hook_set_owner(h->bcm, nullptr, nullptr);
     }
     (void)hipFree(h->st_d);
@@ -336,6 +337,11 @@ int dpe_chm_dev_attach(dpe_chm_dev *h, dpe_bcs *bcs, dpe_bcm *bcm, int32_t fixRi
         DPE_REQUIRE(h->hm.maxChannels >= h->K, "[cuChanMgr] attach: the BatchCorrManifold handle holds %d channels, %d tracked", h->hm.maxChannels, h->K);
         if (dpe_bcm_hook_set_owner(bcm, chm_dev_detach, h)) return -1;
         h->bcm = bcm;
+        {
+            dpe_bcm_ports_dev pm{};
+            const double *rx = nullptr;
+            if (dpe_chm_dev_ports(h, nullptr, &pm, &rx, nullptr, nullptr, nullptr) || dpe_bcm_hook_set_ref_ports(bcm, &pm, rx)) return -1;
+        }
         if (dpe_bcm_hook_set_publish(bcm, 0)) return -1;   // chm_k1 reads the keys on the device; the fix goes out through the ring
         if (!h->ring_h) {
             DPE_CHECK_HIP(hipHostMalloc((void **)&h->ring_h, sizeof(dpe_fix_record) * (size_t)fixRingDepth, hipHostMallocDefault));

@@ -121,8 +121,10 @@ int dpe_pipe_acquire(dpe_pipe *p, dpe_stream_t inputStream, int64_t *ticket, dpe
     dpe_pipe::Lane &l = p->lanes[(size_t)p->nextLane];
     DPE_REQUIRE(l.ticket < 0 || l.committed, "[Pipe] acquire: batch %lld on this lane was acquired but never committed", l.ticket);
     // the lane starts once everything the caller enqueued on inputStream so far (the samples' producer) is done
-    DPE_CHECK_HIP(hipEventRecord(l.in, (hipStream_t)inputStream));
-    DPE_CHECK_HIP(hipStreamWaitEvent(l.stream, l.in, 0));
+    if (inputStream != DPE_STREAM_NONE) {
+        DPE_CHECK_HIP(hipEventRecord(l.in, (hipStream_t)inputStream));
+        DPE_CHECK_HIP(hipStreamWaitEvent(l.stream, l.in, 0));
+    }
     l.ticket = p->next++;
     p->nextLane = (p->nextLane + 1) % p->active;
     l.committed = false;

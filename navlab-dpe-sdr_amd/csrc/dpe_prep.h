@@ -172,4 +172,7 @@ int dpe_bcm_create_sharing(const dpe_bcm_config *cfg, dpe_bcm *donor, dpe_bcm **
 // enable = 0: the device-parameter Updates of this handle leave keys and counts in device memory only (no ticket, no stores over the
 // host link at the end of the scan); dpe_bcm_results then fetches them with a copy.  Set by dpe_chm_dev_attach.
 int dpe_bcm_hook_set_publish(dpe_bcm *h, int enable);
+// referencePair with dpe_bcm_update_prepared: the attached channel manager's port arrays and its rxTime port, for the fp64 re-evaluation
+// of the affected grid points (ports = nullptr: detached)
+int dpe_bcm_hook_set_ref_ports(dpe_bcm *h, const dpe_bcm_ports_dev *ports, const double *rxTime_dev);
 }

@@ -139,7 +139,12 @@ def _ptr(x):
     return C.c_void_p(int(x))
 
 
+STREAM_NONE = "none"      # Pipe.submit / acquire: the samples are already resident (DPE_STREAM_NONE: no cross-stream wait)
+
+
 def _stream(stream):
+    if isinstance(stream, str) and stream == STREAM_NONE:
+        return C.c_void_p(-1)
     if stream is None:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -44,6 +44,17 @@ namespace dsp {
 
 static inline dpe_stream_t flow_stream(void *flowStream) { return *(dpe_stream_t *)flowStream; }
 
+// The library this host was compiled against: a module that calls into libdpe_hip.so checks at Start that the loaded library
+// speaks the header's ABI (struct layouts, status-bit meanings, entry points; DPE_ABI_VERSION in include/dpe_hip.h).
+#define DPE_MOD_CHECK_ABI()                                                                                                  \
+    do {                                                                                                                     \
+        if (dpe_abi_version() != DPE_ABI_VERSION) {                                                                          \
+            std::cerr << "[" << ModuleName << "] Start: libdpe_hip.so has ABI version " << dpe_abi_version()                 \
+                      << ", this host was built against version " << DPE_ABI_VERSION << std::endl;                          \
+            return -1;                                                                                                       \
+        }                                                                                                                    \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------
 class DPInit : public Module {
   public:
@@ -166,6 +177,7 @@ class SampleBlock : public Module {
     int Start(void *) override
     {
         if (running) return 0;
+        DPE_MOD_CHECK_ABI();
         if (SamplingFrequency <= 0 || SampleLength <= 0) DPE_MOD_FAIL("SamplingFrequency / SampleLength not set");
         if (InputSourceType != 0) DPE_MOD_FAIL("InputSourceType " << (int)InputSourceType << ": only the file source (0) is built");
         fd = ::open(Filename, O_RDONLY);
@@ -312,6 +324,7 @@ class BatchCorrScores : public Module {
     int Start(void *) override
     {
         if (Started) { std::clog << "[" << ModuleName << "] Start: Already Started." << std::endl; return 0; }
+        DPE_MOD_CHECK_ABI();
         if (!inputs[0] || !inputs[9]) DPE_MOD_FAIL("Start: inputs not connected");
         dpe_bcs_config cfg = {};
         cfg.samplesPerWindow = (int32_t)inputs[0]->VectorLength;          // batchcorrscores.cu:752
@@ -483,6 +496,7 @@ class BatchCorrManifold : public Module {
     int Start(void *) override
     {
         if (Started) { std::clog << "[" << ModuleName << "] Start: Already Started." << std::endl; return 0; }
+        DPE_MOD_CHECK_ABI();
         if (!inputs[0] || !inputs[1] || !inputs[6] || !inputs[7] || !inputs[11]) DPE_MOD_FAIL("Start: inputs not connected");
         const int dimP[4] = {posDim, posDim, posDim, posDim}, dimV[4] = {velDim, velDim, velDim, velDim};   // :2328-2329
         const double sp[4] = {spacing, spacing, spacing, spacing};                                         // :2332
@@ -693,6 +707,7 @@ class cuChanMgr : public Module {
     int Start(void *) override
     {
         if (h) { std::clog << "[" << ModuleName << "] Start: Already Started." << std::endl; return 0; }
+        DPE_MOD_CHECK_ABI();
         for (int i = 0; i < 14; ++i)
             if (!inputs[i]) DPE_MOD_FAIL("Start: input " << expectedInputs[i].Name << " not connected");
         K = (int)inputs[1]->VectorLength;
@@ -796,6 +811,7 @@ class cuChanMgrDev : public Module {
     int Start(void *flowStream) override
     {
         if (h) { std::clog << "[" << ModuleName << "] Start: Already Started." << std::endl; return 0; }
+        DPE_MOD_CHECK_ABI();
         for (int i = 0; i < 12; ++i)
             if (!inputs[i]) DPE_MOD_FAIL("Start: input " << expectedInputs[i].Name << " not connected");
         if (!bcs || !bcm || !bcs->Handle() || !bcm->Handle()) DPE_MOD_FAIL("Start: BatchCorrScores / BatchCorrManifold must be started first");

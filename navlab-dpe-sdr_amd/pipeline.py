@@ -16,10 +16,11 @@ def bank_half_widths(pos_grid, vel_grid, fs, nfft):
 
 
 def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), init_delta=(0, 0, 0, 0), K=None,
-                    lpower=1, enable_ekf=False):
+                    lpower=1, enable_ekf=False, reference_pair=False, keep_scores=False):
     """iq_windows: int16 [W, 2S] (host).  Returns fixes [W, 8] (= xCurrk1k1 per window) and the raw
     per-window result dicts.  One window per Update, fix fed back to the channel manager.
-    enable_ekf: route the fix through cuEKF's real filter (EnableEKF=true) instead of the shipped pass-through."""
+    enable_ekf: route the fix through cuEKF's real filter (EnableEKF=true) instead of the shipped pass-through.
+    reference_pair: dpe_bcm_config.referencePair; keep_scores: every result dict also carries the window's position scores."""
     import torch
     iq_windows = np.ascontiguousarray(iq_windows)
     W, S2 = iq_windows.shape
@@ -30,7 +31,7 @@ def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
     bcs = engine.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_channels=K)
     bcs.Start()
     bcm = engine.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos_grid, vel_grid, LPower=lpower, lag_half_width=L,
-                                   bin_half_width=B, max_channels=K)
+                                   bin_half_width=B, max_channels=K, reference_pair=reference_pair)
     bcm.Start()
     cm = engine.ChanMgr.from_handoff(ho, S / fs, K)
     x = np.array(ho["X_ECEF"], dtype=np.float64).copy()
@@ -45,6 +46,8 @@ def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
         bcs.Update(iq_d[w], cs)
         bcm.Update(bcs.CodeScores, bcs.CarrScores, bw, ce)
         r = bcm.results()[0]
+        if keep_scores:
+            r["posScores"] = bcm.read_scores()[0][0].copy()
         ekf.Update(r["zVal"], r["RVal"])    # EKF_PassMeas (the ML point is the new state) or the filter
         xk1k1, xkk1 = ekf.xCurrk1k1.copy(), ekf.xCurrkk1.copy()
         fixes[w] = xk1k1
@@ -57,11 +60,14 @@ def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
 
 
 def run_device_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), init_delta=(0, 0, 0, 0), K=None, lpower=1,
-                    ring_depth=64, stream=None):
+                    ring_depth=64, stream=None, reference_pair=False, keep_scores=False):
     """The same loop with nothing read back per window: the channel manager lives on the device (engine.ChanMgrDev), forms
     the measurement from the scan's keys, passes it through and writes the next window's parameter blocks; the host enqueues
         BatchCorrScores.UpdatePrepared -> BatchCorrManifold.UpdatePrepared -> ChanMgrDev.step
-    for every window and collects the fixes from the pinned ring afterwards (at most ring_depth - 1 windows ahead)."""
+    for every window and collects the fixes from the pinned ring afterwards (at most ring_depth - 1 windows ahead).
+    reference_pair: dpe_bcm_config.referencePair (the prepared form re-evaluates from the attached manager's port arrays);
+    keep_scores (tests): waits for every window and keeps its position scores, its code banks and the channel manager's outputs the
+    window was scored with (`inputs` = ChanMgrDev.outputs() before the window) -- the loop then does read back."""
     import torch
     iq_windows = np.ascontiguousarray(iq_windows)
     W, S2 = iq_windows.shape
@@ -72,7 +78,7 @@ def run_device_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
     bcs = engine.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_channels=K)
     bcs.Start()
     bcm = engine.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos_grid, vel_grid, LPower=lpower, lag_half_width=L,
-                                   bin_half_width=B, max_channels=K)
+                                   bin_half_width=B, max_channels=K, reference_pair=reference_pair)
     bcm.Start()
     cm = engine.ChanMgrDev.from_handoff(ho, S / fs, K, time_grid)
     cm.attach(bcs, bcm, ring_depth)
@@ -85,9 +91,17 @@ def run_device_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
         while w - got >= ring_depth - 1:          # never more than the ring holds ahead of the fixes already collected
             results.append(cm.fix(got))
             got += 1
+        inputs = cm.outputs(stream=stream) if keep_scores else None     # (the previous window's time update has run: fix() flushed it)
         bcs.UpdatePrepared(iq_d[w], K, stream)
         bcm.UpdatePrepared(bcs.CodeScores, bcs.CarrScores, K, stream)
         cm.step(stream)
+        if keep_scores:
+            while got <= w:
+                results.append(cm.fix(got))
+                got += 1
+            results[w]["posScores"] = bcm.read_scores(stream)[0][0].copy()
+            results[w]["codeBank"] = bcs.read_banks(stream)[0][0].copy()
+            results[w]["inputs"] = inputs
     while got < W:
         results.append(cm.fix(got))
         got += 1

@@ -238,3 +238,40 @@ def test_manager_and_attached_handles_may_be_destroyed_in_any_order(order):
         bcm.Stop(); bcs.Stop()
     else:
         bcm.Stop(); cm.Stop(); bcs.Stop()
+
+
+def test_reference_pair_mode_in_the_device_resident_loop(oracle):
+    """referencePair (batchcorrmanifold.cu:1798-1812: floor(idx) / floor(idx + 1) two apart when an fp64 index sits one rounding step
+    below 2^m) through dpe_bcm_update_prepared: the prepared blocks hold expansion coefficients only, so the fp64 re-evaluation of the
+    affected grid points reads the port arrays of the attached channel manager (handed over at dpe_chm_dev_attach) -- candidates,
+    patch and re-derived arg-max on the device, nothing read back.  S / 2 = 4096; uniform grids on the handoff geometry, where the
+    branch occurs.  Which points take the branch is a one-ulp property of the inputs, so the device loop is not compared with the
+    host-driven loop (their channel managers agree to 1e-12, not to the last bit) but with the FAITHFUL oracle evaluated on the device
+    manager's own outputs for each window: ordinary points within the reference's own index noise, the branch's points -- which
+    the oracle reports -- within 5e-6, the arg-max the first maximum of the patched scores; and the mode changed something."""
+    o = oracle
+    fs, S, K, W = 2.5e6, 8192, 6, 4
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=1, amp=200.0)
+    ho = dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV)
+    g = dpe.synth.uniform_grid(5, 1.0)
+    tg = np.zeros(1)
+    L, B = dpe.pipeline.bank_half_widths(g, g, fs, dpe.engine.carr_fft_len(S))
+    fd, rd, status = dpe.pipeline.run_device_loop(iq, ho, fs, g, g, time_grid=tg, K=K, ring_depth=8, reference_pair=True, keep_scores=True)
+    fp, rp, _ = dpe.pipeline.run_device_loop(iq, ho, fs, g, g, time_grid=tg, K=K, ring_depth=8, reference_pair=False, keep_scores=True)
+    assert status == 0
+    from tests import helpers
+    branch = changed = 0
+    for w in range(W):
+        _, e, win = rd[w]["inputs"]
+        sp, _ = o.bcm_pos(e["satState"], rd[w]["codeBank"], S // 2 - L, win["xCurrkk1"][0], g, win["enu2ecef"][0], e["codeFrequency"], e["cpRefTOW"],
+                          e["cpElapsedEnd"], e["cpRef"], e["codePhaseEnd"], float(win["rxTime"][0]), fs, S, 1)
+        q = o.bcm_pos_quirks()
+        got = rd[w]["posScores"]
+        assert np.abs(got - sp).max() < helpers.POS_REF_NOISE * sp.max(), w
+        if len(q):
+            assert np.abs(got[q] - sp[q]).max() < 5e-6 * sp.max(), w
+            branch += len(q)
+        assert rd[w]["posIndex"] == int(np.argmax(got)) and rd[w]["posScore"] == got.max(), w
+        changed += int(np.sum(np.abs(got - rp[w]["posScores"]) > 1e-3 * sp.max()))
+    assert branch > 0, "the case must exercise the branch"
+    assert changed > 0       # ... and without the mode those points carry the continuous interpolation's value
