@@ -26,15 +26,17 @@ extern "C" {
 #endif
 
 /* Diagnostic environment switches, read ONCE when a handle is created and never on the Update path (all default off;
- * results stay within the stated tolerances, only kernel selection / tile shapes change):  DPE_BCS_NO_BANK16=1 (batches
- * use the single-window bank kernel), DPE_BCS_NO_WIDE=1 (no boundary-difference kernel for +-32-lag windows),
- * DPE_BCS_NO_CHIP=1 / DPE_BCS_NO_CHIP2=1 (no chip-boundary kernel / not its second form), DPE_BCS_NO_FUSE=1 (single
- * windows run the separate DC-sum kernel), DPE_BCS_FORCE_FFT=1 (full-length FFT form), DPE_BCS_TPB16=n / DPE_BCS_CHIP_TPB=n /
- * DPE_BCS_CHIP2_P=n (tiles or passes per block of the batch / chip kernels), DPE_BCM_NO_POLL=1 (dpe_bcm_results always
- * waits for the stream), DPE_ACQ_NO_FUSED=1 (the acquisition searches keep the rocFFT chain instead of the fused transform
- * kernels), DPE_ACQ_NO_PACK=1 / DPE_ACQ_NO_FWD_PACK=1 (non-coherent search: round 4's radix-10 kernel + four-pass transforms / the forward
- * transform left to rocFFT), DPE_ACQ_STATS_LDS=1 (peak statistics through the LDS-row kernel also for short rows), DPE_COMM_TIMEOUT_S (rendezvous time-out).  Ablation switches that skip work (DPE_BCS_CHIP_DBG,
- * DPE_BCS_FAT, DPE_BCM_SPLIT) exist only in builds with -DDPE_EXPERIMENTS. */
+ * results stay within the stated tolerances, only kernel selection / tile shapes change).  Each selects another of the forms the
+ * parity tests hold against the oracle and against each other:  DPE_BCS_NO_BANK16=1 (batches use the single-window bank kernel),
+ * DPE_BCS_NO_CHIP=1 / DPE_BCS_NO_CHIP2=1 (no chip-boundary kernel / not its second form), DPE_BCS_NO_FUSE=1 (single windows run the
+ * separate DC-sum kernel), DPE_BCS_NO_SUMRIDE=1 / DPE_BCS_SUMRIDE_MIN=n / DPE_BCS_RIDE_SPIN=n (DC sums of chip2 batches: separate
+ * kernel / smallest riding batch / polls before a block sums its window itself), DPE_BCS_FORCE_FFT=1 (full-length FFT form),
+ * DPE_BCS_TPB16=n / DPE_BCS_CHIP_TPB=n / DPE_BCS_CHIP2_P=n (tiles or passes per block of the batch / chip kernels),
+ * DPE_BCM_NO_POLL=1 (dpe_bcm_results always waits for the stream), DPE_ACQ_NO_FUSED=1 (the acquisition searches keep the rocFFT
+ * chain instead of the fused transform kernels), DPE_ACQ_NO_PACK=1 / DPE_ACQ_NO_FWD_PACK=1 (non-coherent search: radix-10 kernel +
+ * four-pass transforms / the forward transform left to rocFFT), DPE_COMM_TIMEOUT_S (rendezvous time-out).  Switches whose A/B is
+ * settled (DPE_BCS_NO_WIDE, DPE_BCS_RIDE_LA, DPE_ACQ_NO_FUSED_FWD, DPE_ACQ_STATS_LDS) and the ablations that skip work
+ * (DPE_BCS_CHIP_DBG, DPE_BCS_FAT, DPE_BCM_SPLIT) exist only in builds with -DDPE_EXPERIMENTS. */
 #define DPE_MAX_CHAN 37            /* CONST_PRN_MAX, consthelper.h:13 */
 #define DPE_MAX_LAG_HALF_WIDTH 292  /* widest code-lag bank of the windowed stage-1 kernels: +-32 and four 65-lag chunks per side */
 #define DPE_ABI_VERSION 4   /* 2: dpe_bcm_config.referencePair, pitched score rows, sizes in dpe_bcm_results_from_keys, *_update_dev;

@@ -1123,7 +1123,7 @@ struct dpe_bcs {
     dpe_bcs_config cfg;
     int LH;             // internal lag half width (4,8,16,32)
     int nSub, nBlk, tilesPerBlock, nMom;
-    bool wideAllowed = true;     // DPE_BCS_NO_WIDE=1 in the environment at create: dense kernel only (A/B tests)
+    bool wideAllowed = true;     // (-DDPE_EXPERIMENTS builds: DPE_BCS_NO_WIDE=1 at create keeps the dense kernel)
     bool bank16Allowed = true;   // DPE_BCS_NO_BANK16=1: never the 16-samples-per-lane batch kernel (A/B tests)
     bool fuseAllowed = true;     // DPE_BCS_NO_FUSE=1: always the separate DC-sum kernel (A/B tests)
     bool chipAllowed = true;     // DPE_BCS_NO_CHIP=1: never the chip-boundary kernel (A/B tests)
@@ -1157,7 +1157,7 @@ struct dpe_bcs {
     unsigned rideEpoch = 0;                     // cycles 1 .. 3
     int rideW = 0, rideSlots = 0;               // the slot set the last such launch wrote
     bool rideAllowed = true;                    // DPE_BCS_NO_SUMRIDE=1: DC-sum kernel in front of the chip2 kernel, as before (A/B runs)
-    int rideLA = 4;                             // look-ahead of the sum blocks in windows (DPE_BCS_RIDE_LA)
+    int rideLA = 4;                             // look-ahead of the sum blocks in windows (-DDPE_EXPERIMENTS builds: DPE_BCS_RIDE_LA)
     int rideSpin = dpe::kRideSpinDefault;       // polls after which a correlator block sums its window itself (DPE_BCS_RIDE_SPIN; tests force 1)
     int rideMinW = 48;                          // smallest batch that takes the riding form (measured at H: 8 / 16 windows slower, 32 equal, 64 -1.2 %, 128 -2.6 %); DPE_BCS_SUMRIDE_MIN
     dpe::BcsChanDev *chan_d = nullptr;
@@ -1269,7 +1269,9 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     if (h->rideWord_d) (void)hipMemset(h->rideWord_d, 0, sizeof(unsigned long long) * W * kSumSlots);
     h->rideAllowed = !(getenv("DPE_BCS_NO_SUMRIDE") && atoi(getenv("DPE_BCS_NO_SUMRIDE")) != 0);
     if (getenv("DPE_BCS_SUMRIDE_MIN") && atoi(getenv("DPE_BCS_SUMRIDE_MIN")) >= 1) h->rideMinW = atoi(getenv("DPE_BCS_SUMRIDE_MIN"));
+#ifdef DPE_EXPERIMENTS
     if (getenv("DPE_BCS_RIDE_LA") && atoi(getenv("DPE_BCS_RIDE_LA")) >= 1) h->rideLA = atoi(getenv("DPE_BCS_RIDE_LA"));
+#endif
     if (getenv("DPE_BCS_RIDE_SPIN") && atoi(getenv("DPE_BCS_RIDE_SPIN")) >= -1) h->rideSpin = atoi(getenv("DPE_BCS_RIDE_SPIN"));
     h->chan_d = dev_alloc<BcsChanDev>(W * K);
     // chip-boundary kernel (dpe_bcs_chip.h): lag windows of 17..31 samples (wider: chunks of 64 lags) at sampling rates where a
@@ -1357,7 +1359,9 @@ int dpe_bcs_create(const dpe_bcs_config *cfg, dpe_bcs **out)
     }
     h->idxNext_h.assign(W * K, 0);
     h->chan_h = h->chanBase_h;
+#ifdef DPE_EXPERIMENTS
     h->wideAllowed = getenv("DPE_BCS_NO_WIDE") == nullptr;
+#endif
     h->bank16Allowed = getenv("DPE_BCS_NO_BANK16") == nullptr;
     h->fuseAllowed = getenv("DPE_BCS_NO_FUSE") == nullptr;
     h->chipAllowed = getenv("DPE_BCS_NO_CHIP") == nullptr;

@@ -548,9 +548,6 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
         const float r = mask_pm1(rMask);
         const bool sd1 = !kPure && __builtin_amdgcn_inverse_ballot_w64(sideMask);
 
-#ifdef DPE_C2_PRIO_SLOTS   // (experiment: issue priority for the arithmetic-dense sample stage)
-        __builtin_amdgcn_s_setprio(DPE_C2_PRIO_SLOTS);
-#endif
         // ---- 1. the chip's samples in the lane's rotating frame: u_i, and vv = sum of all u_i (first moment, by Abel summation)
         f2 u[L1], uX, run = f2{0.f, 0.f}, vv = f2{0.f, 0.f};
         {
@@ -577,12 +574,10 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
             uX = run;
             vv += run;
         }
-#ifdef DPE_C2_PRIO_SLOTS
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef DPE_C2_PRIO_TAIL    // (experiment: issue priority for the latency-bound stages -- scan, LDS stores, moments, gather)
-        __builtin_amdgcn_s_setprio(DPE_C2_PRIO_TAIL);
-#endif
+        // issue priority for the latency-bound stages of the pass (scan, LDS stores, moments, gather): their few instructions between
+        // waits go out ahead of another wave's sample stage, which has plenty more to issue (round 6: 0.5388 -> 0.5350 ms per 128 windows
+        // at H in alternating runs; the priority on the sample stage instead: 0.545)
+        __builtin_amdgcn_s_setprio(2);
         // ---- 2. chip offsets: wipe-off at the chip's frame origin, 64-lane scan of the chip totals, Q -> LDS (centred)
         double ph = fma((double)((own ? e : 0) + CI), ch.carrStep, ch.ri);   // wipe-off at the lane frame's origin
         ph -= floor(ph);
@@ -733,9 +728,7 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
         // (Measured in round 3 and dropped: an offsets-only list with two batches of reads in flight: 0.578 against 0.565 ms per
         // 128 windows at H.  The LDS array is 60 % busy; what a wave waits for is its queue, not one round trip.)
         __builtin_amdgcn_wave_barrier();   // the next pass overwrites sQ
-#ifdef DPE_C2_PRIO_TAIL
         __builtin_amdgcn_s_setprio(0);
-#endif
     }
     };   // passes
     // side of a pure tile: chips below cB = the chip that starts at the nav-bit boundary lie before it (the host selects this
