@@ -177,23 +177,6 @@ __device__ __forceinline__ void acq_idft10(af2 (&v)[10])
 #include "dpe_acq_pack.h"
 #include "dpe_acq_mixed.h"
 namespace dpe {
-// per-PRN peak statistics (acq_stats_kernel / acq_stats_small_body below), and their arguments that do not depend on the PRN (a struct:
-// the fused search kernel carries them too -- its last block of a PRN runs the statistics)
-struct AcqStats {
-    float peak, maxRest;
-    int ci, di;
-    double sum;
-    long long cnt;
-    double lo, hi;
-};
-struct AcqStatsArgs {
-    int maskS, iLo, iHi;
-    double fLo, fHi;
-    int *codeIdx, *doppIdx;
-    AcqStats *out;
-};
-constexpr size_t kAcqStatsLds = 2 * 2048 * 4 + (8 + 4 + 2 + 16) * 4 + (128 + 16 + 2) * 4 + 4 * 8 + 16;   // acq_stats_small_body: histogram + its small arrays
-__device__ void acq_stats_small_body(char *lds, const float *surf, const float *mp, int p, int B, int M, AcqStatsArgs a);
 constexpr int kAcqFusedLen = 2500;
 constexpr int kAcqFusedBins = 6;     // bins per block: 21 x 32 blocks are resident at once (three per CU) on 256 CUs
 constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequences: = 25 (mod 32), so that the 25-lane groups of
@@ -209,12 +192,10 @@ constexpr int kAcqSubStride = 281;   // LDS stride of the ten 250-point sub-sequ
 template <bool ALIAS>
 __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Rc,
                                                               const float2 *__restrict__ tw, int B, int nSeg, int binsPerBlock, int pOffset,
-                                                              float *__restrict__ surf, unsigned int *__restrict__ mpBits,
-                                                              unsigned int *__restrict__ tickets, AcqStatsArgs stats)
+                                                              float *__restrict__ surf, unsigned int *__restrict__ mpBits)
 {
     constexpr int N = kAcqFusedLen, SS = kAcqSubStride;
-    __shared__ __align__(16) float2 sA[10 * SS], sB[10 * SS];
-    static_assert(sizeof(float2) * 10 * SS >= kAcqStatsLds, "the statistics of the last block run in the transposes' LDS");
+    __shared__ float2 sA[10 * SS], sB[10 * SS];
     __shared__ float2 sW250[256], sW25[32];   // W250^n = tw[10 n], W25^n = tw[100 n]: the twiddles of passes 2 and 3
     const int t = threadIdx.x, p = blockIdx.y, bx = blockIdx.x;
     const bool act = t < 250;
@@ -352,22 +333,6 @@ __global__ __launch_bounds__(256, 3) void acq_corr2500_kernel(const float2 *__re
     if (!ALIAS && act) {
 #pragma unroll
         for (int q = 0; q < 10; ++q) atomicMax(&mpBits[(size_t)p * N + t + 250 * q], __float_as_uint(mx[q]));
-    }
-    if constexpr (!ALIAS) {
-        // The peak statistics of this PRN by the LAST of its blocks (tickets != nullptr: coherent / textbook searches): a ticket per PRN,
-        // cleared with the maxima at the start of every search.  The statistics block of one PRN runs beside the transforms of the others
-        // instead of a launch of one block per PRN behind them all (9 us of a 54 us coherent search).
-        if (tickets) {
-            __shared__ unsigned int sLast;
-            __threadfence();          // this block's surface rows and maxima are visible device-wide before its ticket is
-            __syncthreads();
-            if (t == 0) sLast = atomicAdd(&tickets[p], 1u) == gridDim.x - 1 ? 1u : 0u;
-            __syncthreads();
-            if (sLast) {
-                __threadfence();      // (acquire: the other blocks' rows and maxima)
-                acq_stats_small_body(reinterpret_cast<char *>(sA), surf, reinterpret_cast<const float *>(mpBits), p, B, N, stats);
-            }
-        }
     }
 }
 
@@ -608,6 +573,13 @@ __global__ __launch_bounds__(256) void acq_fine_peak_kernel(const float2 *__rest
 // between the order statistics floor(pos) and floor(pos)+1, pos = (M-1) q / 100): the order statistics are EXACT -- an
 // 8-bit-digit radix select over the bit patterns (non-negative floats order like unsigned integers) -- and the
 // interpolation repeats the host expression; only the fp64 summation order of the trimmed mean differs from a serial loop.
+struct AcqStats {
+    float peak, maxRest;
+    int ci, di;
+    double sum;
+    long long cnt;
+    double lo, hi;
+};
 
 __device__ __forceinline__ unsigned int block_sum_u32(unsigned int v, unsigned int *sTmp)
 {
@@ -915,24 +887,16 @@ __device__ __forceinline__ unsigned int wave_scan_addu(unsigned int v)
 }
 
 constexpr int kAcqStatsR = 10;   // delays per thread: rows up to 2 560
-// Peak statistics of PRN p by one block of 256 threads (row in registers, reductions on the vector ALU); lds: kAcqStatsLds bytes, 16-byte
-// aligned, nobody else's at the time.  Called by acq_stats_small_kernel and -- coherent / textbook searches at 2 500 delays -- by the LAST
-// block of a PRN inside acq_corr2500_kernel (a ticket per PRN), where it runs beside the other PRNs' transforms instead of behind them all.
-__device__ __forceinline__ void acq_stats_small_body(char *lds, const float *surf, const float *mp, const int p, const int B, const int M, const AcqStatsArgs a)
+__global__ __launch_bounds__(256) void acq_stats_small_kernel(const float *__restrict__ surf, const float *__restrict__ mp, int B, int M, int maskS, int iLo,
+                                                              double fLo, int iHi, double fHi, int *__restrict__ codeIdx, int *__restrict__ doppIdx,
+                                                              AcqStats *__restrict__ out)
 {
     constexpr int R = kAcqStatsR;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int maskS = a.maskS, iLo = a.iLo, iHi = a.iHi;
-    const double fLo = a.fLo, fHi = a.fHi;
-    int *codeIdx = a.codeIdx, *doppIdx = a.doppIdx;
-    AcqStats *out = a.out;
-    unsigned int *hist = reinterpret_cast<unsigned int *>(lds);                       // [2 * 2048]
-    unsigned int *sTmp = hist + 2 * 2048, *sSel = sTmp + 8, *sCnt = sSel + 4;         // [8], [4], [2]
-    unsigned int(*sWu)[4] = reinterpret_cast<unsigned int(*)[4]>(sCnt + 2);           // [4][4]
-    float(*sCand)[64] = reinterpret_cast<float(*)[64]>(sCnt + 2 + 16);                // [2][64]
-    float(*sWf)[4] = reinterpret_cast<float(*)[4]>(sCnt + 2 + 16 + 128);              // [4][4]
-    float *sF = reinterpret_cast<float *>(sCnt + 2 + 16 + 128 + 16);                  // [2]
-    double *sWd = reinterpret_cast<double *>(lds + ((2 * 2048 * 4 + (8 + 4 + 2 + 16 + 128 + 16 + 2) * 4 + 7) & ~(size_t)7));   // [4]
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ unsigned int hist[2 * 2048];
+    __shared__ unsigned int sTmp[8], sSel[4], sCnt[2], sWu[4][4];
+    __shared__ float sCand[2][64], sWf[4][4], sF[2];
+    __shared__ double sWd[4];
     const float *m = mp + (size_t)p * M;
     float rv[R];
 #pragma unroll
@@ -1157,12 +1121,6 @@ __device__ __forceinline__ void acq_stats_small_body(char *lds, const float *sur
     }
 }
 
-__global__ __launch_bounds__(256) void acq_stats_small_kernel(const float *__restrict__ surf, const float *__restrict__ mp, int B, int M, AcqStatsArgs a)
-{
-    __shared__ __align__(16) char lds[kAcqStatsLds];
-    acq_stats_small_body(lds, surf, mp, (int)blockIdx.x, B, M, a);
-}
-
 }  // namespace dpe
 
 struct dpe_acq {
@@ -1249,7 +1207,7 @@ int dpe_acq_create(const dpe_acq_config *cfg, dpe_acq **out)
     }
     h->Y_d = dev_alloc<float2>(wantFused ? 1 : wantPack ? B * S : (size_t)h->chunk * B * S);   // (packed form: the bins' decimated spectra)
     h->surf_d = dev_alloc<float>(P * B * (size_t)h->M);
-    h->mp_d = dev_alloc<float>(P * (size_t)h->M + P);   // + one ticket per PRN behind the maxima (the fused search's statistics block), cleared with them
+    h->mp_d = dev_alloc<float>(P * (size_t)h->M);
     h->peakIdx_d = dev_alloc<int>(2 * P);
     if (hipHostMalloc((void **)&h->stats_h, P * sizeof(AcqStats), hipHostMallocDefault) != hipSuccess) h->stats_h = nullptr;
     if (h->stats_h && hipHostGetDevicePointer((void **)&h->stats_hd, h->stats_h, 0) != hipSuccess) h->stats_hd = nullptr;
@@ -1369,30 +1327,22 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
     DPE_REQUIRE(h && samples_dev, "[Acquisition] search: null argument");
     hipStream_t st = (hipStream_t)stream_;
     const int S = h->SX, B = h->B, P = h->P, M = h->M;
-    // percentile positions of _trim_mean(max_percode, 10): pos = (M - 1) q / 100, q = 5 and 95 (numpy.percentile)
-    const double posLo = (double)(M - 1) * 5.0 / 100.0, posHi = (double)(M - 1) * 95.0 / 100.0;
-    const int iLo = (int)std::floor(posLo), iHi = (int)std::floor(posHi);
-    const int maskS = (int)std::ceil(h->cfg.samplingFrequency / kFCA);                      // :96-99
-    const AcqStatsArgs sargs = {maskS, iLo, iHi, posLo - (double)iLo, posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P, h->stats_hd};
-    // coherent / textbook searches at 2 500 delays: the last block of a PRN inside acq_corr2500_kernel runs its statistics (no launch behind)
-    const bool statsInSearch = h->fused && h->fusedLen == kAcqFusedLen && M <= 256 * kAcqStatsR;
-    unsigned int *tickets = reinterpret_cast<unsigned int *>(h->mp_d + (size_t)P * M);
     if (h->packForm && h->fwdPack) {
         hipLaunchKernelGGL(acq_fwd25k_pack_kernel, dim3(B), dim3(512), kPkLdsBytes, st, samples_dev, h->cfg.binStartHz, h->cfg.binStepHz,
-                           1.0 / h->cfg.samplingFrequency, h->tw2_d, h->tw25k_d, h->Y_d, h->mp_d, (long long)P * M + P);
+                           1.0 / h->cfg.samplingFrequency, h->tw2_d, h->tw25k_d, h->Y_d, h->mp_d, (long long)P * M);
     } else if (h->fused && h->fusedLen == kAcqFusedLen && h->fusedFwd && h->cfg.mode != 0) {
         // textbook mode (N rows of 2 500 per bin): wipe-off and the forward transform in one launch, 0.271 -> 0.260 ms per 32-PRN window.
         // (Coherent mode keeps the two launches: one block per bin would have to fold ten periods -- a hundred sin / cos pairs per
         // thread on 125 blocks -- and measured 0.066 against 0.060 ms.)
         hipLaunchKernelGGL(acq_wipe_fft2500_kernel, dim3(B, h->cfg.mode == 0 ? 1 : h->N), dim3(512), 0, st, samples_dev, h->cfg.mode == 0 ? h->N : 1,
-                           h->cfg.binStartHz, h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->tw_d, h->X_d, h->mp_d, (long long)P * M + P);
+                           h->cfg.binStartHz, h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->tw_d, h->X_d, h->mp_d, (long long)P * M);
     } else {
         if (h->cfg.mode == 0)
             hipLaunchKernelGGL(acq_wipe_fold_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, samples_dev, M, h->N,
-                               h->cfg.binStartHz, h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M + P);
+                               h->cfg.binStartHz, h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M);
         else
             hipLaunchKernelGGL(acq_wipe_kernel, dim3((S + 1023) / 1024, B), dim3(256), 0, st, samples_dev, S, B, h->cfg.binStartHz,
-                               h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M + P);
+                               h->cfg.binStepHz, 1.0 / h->cfg.samplingFrequency, h->X_d, h->mp_d, (long long)P * M);
         if (h->planFwd.exec(st, h->X_d)) return -1;
     }
     if (h->fused && h->fusedLen != kAcqFusedLen) {
@@ -1413,7 +1363,7 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         // block, 800 blocks = one round plus 32 stragglers, measured 0.265)
         const int bpb = h->cfg.mode == 0 ? kAcqFusedBins : 1;
         hipLaunchKernelGGL(acq_corr2500_kernel<false>, dim3((B + bpb - 1) / bpb, P), dim3(256), 0, st, h->X_d, h->Rc_d, h->tw_d,
-                           B, h->cfg.mode == 0 ? 1 : h->N, bpb, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), statsInSearch ? tickets : nullptr, sargs);
+                           B, h->cfg.mode == 0 ? 1 : h->N, bpb, 0, h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
     }
     for (int p0 = 0; !h->fused && p0 < P; p0 += h->chunk) {
         const int pc = std::min(h->chunk, P - p0);
@@ -1438,7 +1388,7 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                                    h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
             } else
                 hipLaunchKernelGGL(acq_corr2500_kernel<true>, dim3(B, pc), dim3(256), 0, st, h->Y_d, (const float2 *)nullptr, h->tw_d, B, h->N, 1, p0,
-                                   h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d), (unsigned int *)nullptr, sargs);
+                                   h->surf_d, reinterpret_cast<unsigned int *>(h->mp_d));
             continue;
         }
         hipLaunchKernelGGL(acq_mul_kernel, dim3((S + 1023) / 1024, B, pc), dim3(256), 0, st, h->X_d,
@@ -1450,7 +1400,11 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
                            h->cfg.mode == 0 ? 1 : h->N, h->cfg.mode == 0 ? 1 : 0, B, h->surf_d + (size_t)p0 * B * M,
                            reinterpret_cast<unsigned int *>(h->mp_d) + (size_t)p0 * M);
     }
-    if (!statsInSearch) {
+    {
+        // percentile positions of _trim_mean(max_percode, 10): pos = (M - 1) q / 100, q = 5 and 95 (numpy.percentile)
+        const double posLo = (double)(M - 1) * 5.0 / 100.0, posHi = (double)(M - 1) * 95.0 / 100.0;
+        const int iLo = (int)std::floor(posLo), iHi = (int)std::floor(posHi);
+        const int maskS = (int)std::ceil(h->cfg.samplingFrequency / kFCA);                      // :96-99
         // (the kernel's static LDS is ~17 KB: the row joins it only while the sum stays below the 64 KB a launch gets without
         //  an opt-in -- M <= 10 240 -- and is read from memory beyond)
         const int rowInLds = (size_t)M * sizeof(float) <= 40 * 1024 ? 1 : 0;
@@ -1459,8 +1413,13 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
 #else
         constexpr bool statsLds = false;
 #endif
+        // (folding these statistics into the search kernel -- the last block of a PRN, a ticket per PRN, the maxima as 64-bit {value, ~bin}
+        //  keys -- was built in round 6 and is slower: all blocks of a coherent search are resident at once, so every PRN's last block ends
+        //  with the launch and nothing overlaps; 0.0544 -> 0.0584 ms coherent, 0.244 -> 0.2535 textbook.  With a device-scope fence per
+        //  block instead of atomics-only hand-over: 0.131 / 0.684 -- an L2 write-back per block.  DESIGN_LOG.md A.12)
         if (M <= 256 * kAcqStatsR && !statsLds)
-            hipLaunchKernelGGL(acq_stats_small_kernel, dim3(P), dim3(256), 0, st, h->surf_d, h->mp_d, B, M, sargs);
+            hipLaunchKernelGGL(acq_stats_small_kernel, dim3(P), dim3(256), 0, st, h->surf_d, h->mp_d, B, M, maskS, iLo, posLo - (double)iLo, iHi,
+                               posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P, h->stats_hd);
         else
         hipLaunchKernelGGL(acq_stats_kernel, dim3(P), dim3(256), rowInLds ? (size_t)M * sizeof(float) : 0, st, h->surf_d, h->mp_d, B, M,
                            rowInLds, maskS, iLo, posLo - (double)iLo, iHi, posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P,
