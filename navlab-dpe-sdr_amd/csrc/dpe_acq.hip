@@ -1416,7 +1416,7 @@ int dpe_acq_search(dpe_acq *h, const int16_t *samples_dev, dpe_stream_t stream_)
         // (folding these statistics into the search kernel -- the last block of a PRN, a ticket per PRN, the maxima as 64-bit {value, ~bin}
         //  keys -- was built in round 6 and is slower: all blocks of a coherent search are resident at once, so every PRN's last block ends
         //  with the launch and nothing overlaps; 0.0544 -> 0.0584 ms coherent, 0.244 -> 0.2535 textbook.  With a device-scope fence per
-        //  block instead of atomics-only hand-over: 0.131 / 0.684 -- an L2 write-back per block.  DESIGN_LOG.md A.12)
+        //  block instead of atomics-only hand-over: 0.131 / 0.684 -- an L2 write-back per block.  DESIGN_LOG.md A.15)
         if (M <= 256 * kAcqStatsR && !statsLds)
             hipLaunchKernelGGL(acq_stats_small_kernel, dim3(P), dim3(256), 0, st, h->surf_d, h->mp_d, B, M, maskS, iLo, posLo - (double)iLo, iHi,
                                posHi - (double)iHi, h->peakIdx_d, h->peakIdx_d + P, h->stats_hd);

@@ -393,6 +393,8 @@ int dpe_chm_dev_set_ekf(dpe_chm_dev *h, const dpe_ekf_config *cfg)
     memcpy(e[0].Pk1k1, cfg->P0, sizeof(e[0].Pk1k1));
     memcpy(e[0].xk1k1, cfg->x0, sizeof(e[0].xk1k1));
     memcpy(e[0].xkk1, cfg->x0, sizeof(e[0].xkk1));
+    e[0].coupled = cfg->coupleVelocity ? 1 : 0;                               // (the structure the device step exploits: dpe_chm_dev.h, ekf_dev_step)
+    e[0].Tc = cfg->sampleLength;
     (void)hipFree(h->ekf_d);
     h->ekf_d = dev_alloc<EkfDev>(1);
     DPE_REQUIRE(h->ekf_d, "[cuChanMgr] set_ekf: device allocation failed");

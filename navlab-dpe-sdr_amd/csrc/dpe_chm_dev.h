@@ -263,6 +263,10 @@ struct EkfDev {
     double lpfVals[20];
     double lpfAvg;
     int lpfIdx, failed;   // failed: S was singular in some window (the state is then held for that window, bit 32 of the status)
+    // the structure dpe_ekf_create gives F and H, which the device form exploits (see ekf_dev_step): H = I; F = I, plus Tc on [i][i + 4],
+    // i < 4, when `coupled`
+    int coupled, pad;
+    double Tc;
 };
 struct ChmKArgs {
     ChmDevState *st;
@@ -454,51 +458,74 @@ __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double
     return true;
 }
 // StepUpdate (:660-721) with the measurement z and R = I as BatchCorrManifold emits it (:2003-2011), then StepPredict (:626-656).
-// Returns false when S is singular (state untouched).  sm: kEkfDevScratch doubles of LDS.  The filter's operands (H, F, P, x, the speed
-// average's taps) are staged in LDS once: read from device memory by every product they were a chain of ~1 us round trips in a kernel
-// of 64 threads (twelve products and three dependent loads for the speed average: 7.3 of the window's 47 us).
+// Returns false when S is singular (state untouched).  sm: kEkfDevScratch doubles of LDS.
+// Round 6: eight of the ten 8 x 8 products have H or F as a factor, and dpe_ekf_create fixes their structure -- H = I, F = I (+ Tc on
+// [i][i + 4], i < 4).  A dot product of the host form, s = 0.0; s += a[i][k] * b[k][j] for k = 0 .. 7 without fused multiply-add, then
+// reduces to its structural terms IN THE SAME ORDER: the exact-zero factors contribute +-0.0, which leaves a sum that started at +0.0
+// unchanged (and +0.0 + x = x exactly, -0.0 included: it becomes +0.0 in both forms -- hence the literal "0.0 +" below).  So
+//   H X = X H^T = 0.0 + X,      (F X)[i][j] = (0.0 + X[i][j]) + Tc X[i + 4][j]  (i < 4),      (X F^T)[i][j] = (0.0 + X[i][j]) + X[i][j + 4] Tc  (j < 4)
+// give the host form's doubles bit for bit with one or two operations per element instead of sixteen LDS reads and eight dependent
+// multiply-adds; the two dense products (K = P S^-1 and (I - K) P) and the LU inverse stay as they were.  chm_k1 with the filter:
+// 11.7 -> see profiles/r6_closed_loop_device.txt.
 constexpr int kEkfDevScratch = 11 * 64, kEkfDevXk = 640, kEkfDevX1 = 648;   // (x_k+1|k and x_k|k stay at these offsets of the scratch)
-__device__ static inline bool ekf_dev_step(EkfDev *e, const double *z, double *sm, int *piv)
+// the filter's operands of lane l, requested at the top of chm_k1 -- beside the keys and the grid rows of the measurement, not behind them
+// (one ~1.5 us round trip to device memory off the kernel's dependent chain)
+struct EkfPre {
+    double p, xk, lpf, lpfAvg, Tc;
+    int lpfIdx, coupled;
+};
+__device__ static inline EkfPre ekf_dev_prefetch(const EkfDev *e)
+{
+    const int l = threadIdx.x;
+    EkfPre r;
+    r.p = e->Pkk1[l];
+    r.xk = l < 8 ? e->xkk1[l] : 0.0;
+    r.lpf = l < 20 ? e->lpfVals[l] : 0.0;
+    r.lpfAvg = e->lpfAvg;
+    r.Tc = e->Tc;
+    r.lpfIdx = e->lpfIdx;
+    r.coupled = e->coupled;
+    return r;
+}
+__device__ static inline bool ekf_dev_step(EkfDev *e, const EkfPre &pre, const double *z, double *sm, int *piv)
 {
 #pragma clang fp contract(off)
-    const int l = threadIdx.x;
+    const int l = threadIdx.x, i = l >> 3, j = l & 7;
     double *T = sm, *S = sm + 64, *Sinv = sm + 128, *lu = sm + 192, *y = sm + 256, *tmp = sm + 320;
-    double *H = sm + 384, *F = sm + 448, *P = sm + 512, *P1 = sm + 576, *xk = sm + 640, *x1 = sm + 648, *lpf = sm + 656, *lpfAvgS = sm + 676;
-    H[l] = e->H[l];
-    F[l] = e->F[l];
-    P[l] = e->Pkk1[l];
-    if (l < 8) xk[l] = e->xkk1[l];
-    if (l < 20) lpf[l] = e->lpfVals[l];
-    int lpfIdx = 0;
-    double lpfAvg = 0.0;
-    if (l == 0) { lpfIdx = e->lpfIdx; lpfAvg = e->lpfAvg; }
+    double *P = sm + 512, *P1 = sm + 576, *xk = sm + 640, *x1 = sm + 648, *lpf = sm + 656, *lpfAvgS = sm + 676;
+    const bool coupled = pre.coupled != 0;
+    const double Tc = pre.Tc;
+    const double p = pre.p;
+    P[l] = p;
+    if (l < 8) xk[l] = pre.xk;
+    if (l < 20) lpf[l] = pre.lpf;
+    int lpfIdx = pre.lpfIdx;
+    double lpfAvg = pre.lpfAvg;
+    const double pz = 0.0 + p;                                     // H P = P H^T = 0.0 + P
+    S[l] = (0.0 + pz) + ((l % 9 == 0) ? 1.0 : 0.0);                // S = (H P) H^T + R
+    T[l] = pz;                                                     // P H^T, the first factor of K
     __syncthreads();
-    if (l < 8) {                                                   // y = z - H x_k|k-1
-        double s = z[l];
-        for (int k = 0; k < 8; ++k) s -= H[l * 8 + k] * xk[k];
-        y[l] = s;
-    }
-    ekf_dev_mul(H, P, false, T);                                   // S = H P H^T + R
-    ekf_dev_mul(T, H, true, S);
-    S[l] += (l % 9 == 0) ? 1.0 : 0.0;
-    __syncthreads();
+    if (l < 8) y[l] = z[l] - xk[l];                                // y = z - H x_k|k-1
     if (!ekf_dev_invert(S, lu, Sinv, piv)) return false;
-    ekf_dev_mul(P, H, true, T);                                    // K = P H^T S^-1
-    ekf_dev_mul(T, Sinv, false, tmp);
-    e->K[l] = tmp[l];
-    __syncthreads();
+    ekf_dev_mul(T, Sinv, false, tmp);                              // K = (P H^T) S^-1
+    const double kv = tmp[l];
+    e->K[l] = kv;
     if (l < 8) {                                                   // x_k|k = x_k|k-1 + K y
         double s = xk[l];
         for (int k = 0; k < 8; ++k) s += tmp[l * 8 + k] * y[k];
         x1[l] = s;
         e->xk1k1[l] = s;
     }
-    ekf_dev_mul(tmp, H, false, T);                                 // P_k|k = (I - K H) P_k|k-1
-    T[l] = -T[l];
-    if (l % 9 == 0) T[l] += 1.0;
+    {                                                              // P_k|k = (I - K H) P_k|k-1, K H = 0.0 + K
+        double t = -(0.0 + kv);
+        if (l % 9 == 0) t += 1.0;
+        __syncthreads();                                           // (the reads of tmp above)
+        T[l] = t;
+    }
     __syncthreads();
     ekf_dev_mul(T, P, false, P1);
-    e->Pk1k1[l] = P1[l];
+    const double p1 = P1[l];
+    e->Pk1k1[l] = p1;
     // ---- StepPredict with GetQVal (:733-742) and EKF_Update_Q (:42-78)
     if (l == 0) {
         const double v = sqrt(x1[4] * x1[4] + x1[5] * x1[5] + x1[6] * x1[6]);
@@ -510,28 +537,37 @@ __device__ static inline bool ekf_dev_step(EkfDev *e, const double *z, double *s
         e->lpfIdx = lpfIdx;
     }
     __syncthreads();
-    {
-        const double av = lpfAvgS[0];
-        const double q = 1.0 + 250.0 / fmin(fmax(av * av, 50.0), 125.0);
-        double q0 = 0.0;
-        if (l == 4 * 8 + 4 || l == 5 * 8 + 5 || l == 6 * 8 + 6) q0 = q;
-        if (l == 7 * 8 + 7) q0 = (2.5e-10) * (2.5e-10) * kC * kC;   // Q_CLOCK_DRIFT, cuekf.h:28
-        S[l] = q0;                                                 // (S is free again: Q0)
-    }
-    __syncthreads();
-    ekf_dev_mul(F, S, false, T);                                   // Q = F Q0 F^T
-    ekf_dev_mul(T, F, true, tmp);
-    const double qv = tmp[l];
+    const double av = lpfAvgS[0];
+    const double q = 1.0 + 250.0 / fmin(fmax(av * av, 50.0), 125.0);
+    const auto q0 = [&](int r, int c) -> double {                  // Q0: diagonal
+        if (r != c) return 0.0;
+        if (r == 4 || r == 5 || r == 6) return q;
+        if (r == 7) return (2.5e-10) * (2.5e-10) * kC * kC;        // Q_CLOCK_DRIFT, cuekf.h:28
+        return 0.0;
+    };
+    const auto fq = [&](int r, int c) -> double {                  // (F Q0)[r][c]
+        double s = 0.0 + q0(r, c);
+        if (coupled && r < 4) s += Tc * q0(r + 4, c);
+        return s;
+    };
+    double qv = 0.0 + fq(i, j);                                    // Q = (F Q0) F^T
+    if (coupled && j < 4) qv += fq(i, j + 4) * Tc;
     e->Q[l] = qv;
     if (l < 8) {                                                   // x_k+1|k = F x_k|k
-        double s = 0.0;
-        for (int k = 0; k < 8; ++k) s += F[l * 8 + k] * x1[k];
+        double s = 0.0 + x1[l];
+        if (coupled && l < 4) s += Tc * x1[l + 4];
         xk[l] = s;                                                 // (left in the scratch for the caller: kEkfDevXk)
         e->xkk1[l] = s;
     }
-    ekf_dev_mul(F, P1, false, T);                                  // P_k+1|k = F P F^T + Q
-    ekf_dev_mul(T, F, true, S);
-    e->Pkk1[l] = S[l] + qv;
+    {                                                              // P_k+1|k = (F P) F^T + Q
+        double t = 0.0 + p1;
+        if (coupled && i < 4) t += Tc * P1[l + 32];
+        T[l] = t;
+        __syncthreads();
+        double s2 = 0.0 + t;
+        if (coupled && j < 4) s2 += T[l + 4] * Tc;
+        e->Pkk1[l] = s2 + qv;
+    }
     __syncthreads();
     return true;
 }
@@ -547,6 +583,8 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
     const double rxTime = st->rxTime, T = st->T;
     const int ds = st->dopplerSign;
     if (k == 0) sFlags = 0;
+    EkfPre ekfPre{};
+    if (a.meas && a.ekf) ekfPre = ekf_dev_prefetch(a.ekf);
     Chan c;
     if (k < K) c = st->ch[k];
     double z[8];
@@ -580,7 +618,7 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
     }
     if (a.meas && a.ekf) {   // EnableEKF = true: StepUpdate + StepPredict on the measurement (block-uniform branch; all 64 lanes work)
         __syncthreads();
-        const bool ok = sFlags == 0 && ekf_dev_step(a.ekf, sZ, sEkf, sPiv);
+        const bool ok = sFlags == 0 && ekf_dev_step(a.ekf, ekfPre, sZ, sEkf, sPiv);
         __syncthreads();
         if (k < 8) {
             if (ok) { sX1[k] = sEkf[kEkfDevX1 + k]; sXk[k] = sEkf[kEkfDevXk + k]; }
