@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-T=r5
+T=${1:-r6}
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --acq coherent > $R/gpurun_out/${T}_acq_bench.json 2> $R/gpurun_out/${T}_acq_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_acq_stats -- python3 $R/bench.py --acq coherent > $R/gpurun_out/${T}_acq_bench_under_rocprof.json 2> $R/gpurun_out/${T}_acq_stats.err

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 evidence: scripts/collect_profiles.sh for R / H / M, the acquisition line under rocprofv3, SQ counters for R and H.
+# Round evidence (tag = first argument, default r6): scripts/collect_profiles.sh for R / H / M, the acquisition line under rocprofv3, SQ counters for R and H.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-T=${1:-r5}
+T=${1:-r6}
 cd $R
 bash scripts/collect_profiles.sh ${T}_R > /dev/null 2>&1
 DPE_BENCH_ARGS="--config H" bash scripts/collect_profiles.sh ${T}_H > /dev/null 2>&1
