@@ -506,7 +506,12 @@ __device__ static inline bool ekf_dev_step(EkfDev *e, const EkfPre &pre, const d
     T[l] = pz;                                                     // P H^T, the first factor of K
     __syncthreads();
     if (l < 8) y[l] = z[l] - xk[l];                                // y = z - H x_k|k-1
+#if defined(DPE_EXPERIMENTS) && defined(DPE_EKF_SKIP_INV)   // (timing attribution only: wrong results)
+    Sinv[l] = S[l];
+    __syncthreads();
+#else
     if (!ekf_dev_invert(S, lu, Sinv, piv)) return false;
+#endif
     ekf_dev_mul(T, Sinv, false, tmp);                              // K = (P H^T) S^-1
     const double kv = tmp[l];
     e->K[l] = kv;

@@ -14,7 +14,7 @@ with open(dpe.workload.HANDOFF_CSV) as f, open("/tmp/lt/handoff.csv", "w") as g:
         g.write("bytes_read,0\n" if line.startswith("bytes_read") else line)
 PY
 cd /tmp && export TMPDIR=/tmp
-EXE=$R/navlab-dpe-sdr_amd/dpe_flow
+EXE=${DPE_FLOW_EXE:-$R/navlab-dpe-sdr_amd/dpe_flow}
 for V in "" "--ekf"; do
   T=lt_pass; [ -n "$V" ] && T=lt_ekf
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T -- $EXE --samples /tmp/lt/s.dat --handoff /tmp/lt/handoff.csv --out /tmp/lt/X.csv --iters 400 --grid-dim 25 --spacing 1.0 --device-loop $V > /dev/null 2> $R/gpurun_out/$T.err

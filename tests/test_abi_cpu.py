@@ -49,6 +49,9 @@ def test_no_cpu_fallback(built):
         bcs.Start()          # hipMalloc fails -> error, never a CPU path
     with pytest.raises(dpe.DpeError):
         bcs.Update(0, dpe.engine.chan_start_array([2], [0.0], [0.0], [1.023e6], [0.0], [0], [0]))
+    g = dpe.synth.rand_grid(3, 64)
+    with pytest.raises(dpe.DpeError):      # the batches-in-flight form creates its lanes' handles at once: the same loud failure
+        dpe.Pipe(2.5e6, 50000, g, g, lag_half_width=4, bin_half_width=20, max_windows=2, max_channels=8, in_flight=2)
 
 
 def test_chanmgr_matches_oracle(built, oracle):

@@ -139,7 +139,7 @@ def test_chip_kernel_falls_back_when_not_eligible():
     _check(case, 31, 16)
 
 
-N_C2 = int(os.environ.get("DPE_FUZZ_CHIP2_CASES", "10"))
+N_C2 = int(os.environ.get("DPE_FUZZ_CHIP2_CASES", "30"))
 
 
 @pytest.mark.parametrize("i", range(N_C2))
