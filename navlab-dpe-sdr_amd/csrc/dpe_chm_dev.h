@@ -398,45 +398,65 @@ __device__ static inline void ekf_dev_mul(const double *a, const double *b, bool
     c[l] = s;
     __syncthreads();
 }
-// inverse through LU with partial pivoting (getrf + getri, cuekf.cu:681-694); false: singular.  (The pivot search and the two
-// substitutions work on registers: with the candidate row as an LDS address the search was seven dependent round trips per column, and
-// the back substitution re-read its own column of the inverse from LDS -- ~6 us of an 8 x 8 inverse.)
+// inverse through LU with partial pivoting (getrf + getri, cuekf.cu:681-694); false: singular.
+// Round 6: the FACTORISATION runs on registers -- lane l = (r, kk) holds lu[r][kk]; the block is one wave, so a column's eight values
+// are eight v_readlane pairs (wave-uniform: the pivot search is the host form's, first largest |.| at or below the diagonal), the row
+// swap and the pivot row's element are one ds_bpermute round trip per column, and nothing waits at a barrier.  Through LDS it was five
+// dependent round trips and four barriers per column, ~4 of the ~5.5 us the filter adds to chm_k1.  Every element still sees the host
+// form's operations in the host form's order: lu[r][c] /= lu[c][c]; lu[r][k] -= lu[r][c] * lu[c][k] (no fused multiply-add).  The two
+// substitutions (one column of the inverse per lane, 28 dependent multiply-subtracts each) read the factors back from LDS as before.
+__device__ __forceinline__ double ekf_readlane_d(double v, int lane)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double *inv, int *piv)
 {
 #pragma clang fp contract(off)
     const int l = threadIdx.x, r = l >> 3, kk = l & 7;
-    lu[l] = a[l];
-    if (l < 8) piv[l] = l;
-    __syncthreads();
-#pragma unroll 1
+    double x = a[l];
+    int pv = l;                      // lanes 0 .. 7: piv[l]
+    bool singular = false;
+#pragma unroll
     for (int c = 0; c < 8; ++c) {
         double col[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) col[q] = lu[q * 8 + c];
-        int p = c;   // (every lane finds the same pivot row: the first largest |.| at or below the diagonal)
-        double best = -1.0;
+        for (int q = 0; q < 8; ++q) col[q] = ekf_readlane_d(x, q * 8 + c);
+        int p = c;                   // (every lane finds the same pivot row: the first largest |.| at or below the diagonal)
+        double best = fabs(col[c]), pivVal = col[c];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = c + 1; q < 8; ++q) {
             const double av = fabs(col[q]);
-            if (q == c) best = av;
-            if (q > c && av > best) { best = av; p = q; }
+            if (av > best) { best = av; p = q; pivVal = col[q]; }
         }
-        if (best == 0.0) return false;
-        __syncthreads();
-        if (p != c) {
-            if (r == 0) { const double t = lu[p * 8 + kk]; lu[p * 8 + kk] = lu[c * 8 + kk]; lu[c * 8 + kk] = t; }
-            if (l == 0) { const int t = piv[p]; piv[p] = piv[c]; piv[c] = t; }
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (best == 0.0) { singular = true; break; }
+        // the row swap and the pivot row's element of this lane's column, both from the values before the swap: one round trip
+        const int src = (r == c) ? p * 8 + kk : (r == p) ? c * 8 + kk : l;
+        const double xs = __shfl(x, src, 64), xck = __shfl(x, p * 8 + kk, 64);
+        const int ps = (l == c) ? p : (l == p) ? c : l;
+        pv = __shfl(pv, ps, 64);
+        x = xs;
+        // this lane's row's element of column c after the swap
+        double xc = col[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) xc = (r == q) ? col[q] : xc;
+        if (r == p) xc = col[c];
+        if (r == c) xc = pivVal;
+        if (r > c) {
+            const double f = xc / pivVal;
+            if (kk == c) x = f;
+            else if (kk > c) x -= f * xck;
         }
-        __syncthreads();
-        const double f = (r > c) ? lu[r * 8 + c] / lu[c * 8 + c] : 0.0;
-        __syncthreads();
-        if (r > c && kk == c) lu[r * 8 + c] = f;
-        if (r > c && kk > c) lu[r * 8 + kk] -= f * lu[c * 8 + kk];
-        __syncthreads();
     }
+    if (singular) return false;      // (wave-uniform)
+    lu[l] = x;
+    if (l < 8) piv[l] = pv;
+    __syncthreads();
     if (l < 8) {   // one column of the inverse per lane
         const int cl = l;
-        double y[8], x[8];
+        double y[8], xx[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             double s = (piv[i] == cl) ? 1.0 : 0.0;
@@ -448,11 +468,11 @@ __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double
         for (int i = 7; i >= 0; --i) {
             double s = y[i];
 #pragma unroll
-            for (int k = i + 1; k < 8; ++k) s -= lu[i * 8 + k] * x[k];
-            x[i] = s / lu[i * 8 + i];
+            for (int k = i + 1; k < 8; ++k) s -= lu[i * 8 + k] * xx[k];
+            xx[i] = s / lu[i * 8 + i];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) inv[i * 8 + cl] = x[i];
+        for (int i = 0; i < 8; ++i) inv[i * 8 + cl] = xx[i];
     }
     __syncthreads();
     return true;
