@@ -367,6 +367,9 @@ int dpe_comm_create(int32_t rank, int32_t nRanks, const char *rendezvousPath, in
 int dpe_comm_wrap_nccl(void *ncclComm, int32_t rank, int32_t nRanks, dpe_comm **out);
 int dpe_comm_destroy(dpe_comm *c);
 int dpe_comm_rank(const dpe_comm *c, int32_t *rank, int32_t *nRanks);
+/* One thread drives a communicator.  Its collectives may go to different streams from call to call (the lanes of a dpe_pipe): on the RCCL
+ * backend every call first makes its stream wait, on the device, for the previous call's completion when that one was enqueued on another
+ * stream -- two collectives of one communicator are never in flight at once; every rank must issue them in the same order. */
 int dpe_comm_allreduce_max_u64(dpe_comm *c, uint64_t *data_dev, int64_t count, dpe_stream_t stream);
 int dpe_comm_allgather(dpe_comm *c, const void *send_dev, void *recv_dev, int64_t bytesPerRank, dpe_stream_t stream);
 /* Arg-max exchange of the LAST Update: all-reduce(MAX) in place on the handle's device keys ([nWindows][2]); with keys_host

@@ -132,7 +132,29 @@ struct dpe_comm {
     unsigned long long seq = 0;
     std::vector<unsigned char> host;   // staging of the host-file transport
     std::vector<std::string> mine;     // payload files this rank still has in the directory
+    // One communicator, several streams (the lanes of a dpe_pipe alternate): two collectives of the same communicator must never be in
+    // flight at once, so every RCCL call first makes its stream wait for the previous call's event when that one went to ANOTHER stream.
+    // Every rank alternates its lanes in the same order, so the chain is the same on every rank.
+    hipEvent_t lastDone = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool haveLast = false;
 };
+
+namespace {
+int chain_before(dpe_comm *c, hipStream_t stream)
+{
+    if (c->haveLast && c->lastStream != stream) DPE_CHECK_HIP(hipStreamWaitEvent(stream, c->lastDone, 0));
+    return 0;
+}
+int chain_after(dpe_comm *c, hipStream_t stream)
+{
+    if (!c->lastDone) DPE_CHECK_HIP(hipEventCreateWithFlags(&c->lastDone, hipEventDisableTiming));
+    DPE_CHECK_HIP(hipEventRecord(c->lastDone, stream));
+    c->lastStream = stream;
+    c->haveLast = true;
+    return 0;
+}
+}  // namespace
 
 namespace {
 
@@ -279,6 +301,7 @@ int dpe_comm_destroy(dpe_comm *c)
 {
     if (!c) return 0;
     if (c->nccl && c->ownsNccl) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->lastDone) (void)hipEventDestroy(c->lastDone);
     // the last payload files of this rank: a peer may still be reading the newest one (it is stamped with this run's
     // nonce, so a later run never mistakes it for its own), everything older is unread
     while (c->mine.size() > 1) {
@@ -302,9 +325,10 @@ int dpe_comm_allreduce_max_u64(dpe_comm *c, uint64_t *data_dev, int64_t count, d
     DPE_REQUIRE(c && data_dev && count > 0, "[dpe_comm] allreduce: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
     if (c->backend == DPE_COMM_RCCL) {
+        if (chain_before(c, stream)) return -1;
         const ncclResult_t r = g_rccl.AllReduce(data_dev, data_dev, (size_t)count, ncclUint64, ncclMax, c->nccl, stream);
         DPE_REQUIRE(r == ncclSuccess, "[dpe_comm] ncclAllReduce: %s", g_rccl.GetErrorString(r));
-        return 0;
+        return chain_after(c, stream);
     }
     std::vector<uint64_t> mine((size_t)count);
     DPE_CHECK_HIP(hipMemcpyAsync(mine.data(), data_dev, sizeof(uint64_t) * count, hipMemcpyDeviceToHost, stream));
@@ -323,9 +347,10 @@ int dpe_comm_allgather(dpe_comm *c, const void *send_dev, void *recv_dev, int64_
     DPE_REQUIRE(c && send_dev && recv_dev && bytesPerRank > 0, "[dpe_comm] allgather: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
     if (c->backend == DPE_COMM_RCCL) {
+        if (chain_before(c, stream)) return -1;
         const ncclResult_t r = g_rccl.AllGather(send_dev, recv_dev, (size_t)bytesPerRank, ncclUint8, c->nccl, stream);
         DPE_REQUIRE(r == ncclSuccess, "[dpe_comm] ncclAllGather: %s", g_rccl.GetErrorString(r));
-        return 0;
+        return chain_after(c, stream);
     }
     std::vector<unsigned char> mine((size_t)bytesPerRank);
     DPE_CHECK_HIP(hipMemcpyAsync(mine.data(), send_dev, (size_t)bytesPerRank, hipMemcpyDeviceToHost, stream));
