@@ -575,7 +575,7 @@ const char *dpe_bcs_stage1_kernel(dpe_bcs *h);
 int dpe_bcm_profile(dpe_bcm *h, int32_t enable, float *ms, int32_t *count);
 
 /* Graph replay (an option, NOT the low-latency path on this ROCm: measured on MI355X / ROCm 7.2 a replayed single-window step
- * takes 73 us against 45 us for the eager launches, profiles/r6_closed_loop_device.txt -- hipGraphLaunch costs more than the 2 + 1
+ * takes 75 us against 47 us for the eager launches, profiles/r6_closed_loop_device.txt -- hipGraphLaunch costs more than the 2 + 1
  * launches it replaces; leave it off unless a later runtime changes that).  With enable != 0 an Update whose shape and device pointers repeat (the per-window
  * call of a running receiver, one entry per SampleBlock ring slot) is captured once as a hipGraph and
  * replayed with a single launch afterwards; the pinned parameter blocks are re-read on every replay, so
