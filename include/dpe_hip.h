@@ -348,7 +348,9 @@ int dpe_pipe_lane(dpe_pipe *p, int64_t ticket, dpe_bcs **bcs, dpe_bcm **bcm, dpe
 /* dpe_bcm_results of that batch: waits for ITS lane only -- later batches keep running. */
 int dpe_pipe_results(dpe_pipe *p, int64_t ticket, dpe_bcm_result *results);
 /* Stream-ordered hand-backs (no host wait): `stream` continues once stage 1 of the batch has read its samples (a SampleBlock ring
- * slot may then be refilled: sampleblock.cu:421-447) / once every committed batch is complete. */
+ * slot may then be refilled: sampleblock.cu:421-447) / once every committed batch is complete.  samples_consumed also takes a
+ * ticket whose lane has been dealt again (a ring deeper than the lanes): it then waits for stage 1 of the later batch on that
+ * lane, which is behind this batch's in the lane's stream order. */
 int dpe_pipe_samples_consumed(dpe_pipe *p, int64_t ticket, dpe_stream_t stream);
 int dpe_pipe_join(dpe_pipe *p, dpe_stream_t stream);
 int dpe_pipe_synchronize(dpe_pipe *p);                   /* host wait for all lanes */

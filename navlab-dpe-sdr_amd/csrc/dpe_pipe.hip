@@ -27,6 +27,8 @@ struct dpe_pipe {
     long long next = 0;            // ticket of the next batch
     int active = 0;                // lanes batches are dealt to (dpe_pipe_set_in_flight; <= lanes.size())
     int nextLane = 0;
+    static constexpr int kHist = 256;
+    int laneHist[kHist] = {};      // lane of ticket t at [t % kHist], for the last kHist tickets (samples_consumed on an overtaken ticket)
 };
 
 static dpe_pipe::Lane *lane_of(dpe_pipe *p, int64_t ticket, const char *who)
@@ -126,6 +128,7 @@ int dpe_pipe_acquire(dpe_pipe *p, dpe_stream_t inputStream, int64_t *ticket, dpe
         DPE_CHECK_HIP(hipStreamWaitEvent(l.stream, l.in, 0));
     }
     l.ticket = p->next++;
+    p->laneHist[l.ticket % dpe_pipe::kHist] = p->nextLane;
     p->nextLane = (p->nextLane + 1) % p->active;
     l.committed = false;
     l.stage1Marked = false;
@@ -207,10 +210,20 @@ int dpe_pipe_results(dpe_pipe *p, int64_t ticket, dpe_bcm_result *results)
 
 int dpe_pipe_samples_consumed(dpe_pipe *p, int64_t ticket, dpe_stream_t stream)
 {
-    dpe_pipe::Lane *l = lane_of(p, ticket, "samples_consumed");
-    if (!l) return -1;
-    DPE_REQUIRE(l->committed, "[Pipe] samples_consumed: batch %lld was not committed", (long long)ticket);
-    DPE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, l->stage1, 0));
+    DPE_REQUIRE(p && ticket >= 0 && ticket < p->next, "[Pipe] samples_consumed: ticket %lld was never issued", (long long)ticket);
+    for (auto &l : p->lanes)
+        if (l.ticket == ticket) {
+            DPE_REQUIRE(l.committed, "[Pipe] samples_consumed: batch %lld was not committed", (long long)ticket);
+            DPE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, l.stage1, 0));
+            return 0;
+        }
+    // An overtaken ticket (a ring deeper than the lanes): its lane has been dealt again, and a lane takes a new batch only after the one
+    // before was committed, so the latest record of that lane's stage-1 event is at or after this batch's in the lane's stream order.
+    if (ticket >= p->next - dpe_pipe::kHist) {
+        DPE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, p->lanes[(size_t)p->laneHist[ticket % dpe_pipe::kHist]].stage1, 0));
+        return 0;
+    }
+    for (auto &l : p->lanes) DPE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, l.stage1, 0));   // older than the history: every lane
     return 0;
 }
 

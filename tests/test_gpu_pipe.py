@@ -156,3 +156,27 @@ def test_pipe_argument_errors():
     with pytest.raises(dpe.DpeError, match="never issued"):
         p.lane(0)
     p.close()
+
+
+def test_cpp_host_drives_the_pipe(tmp_path):
+    """host/test_pipe.cpp: a C++ program that sees nothing but include/dpe_hip.h replays six batches open-loop -- a three-slot ring of
+    pinned blocks and device slots in front of two lanes, refills ordered by dpe_pipe_samples_consumed, each batch collected while the
+    next one runs -- and compares every result with the one-stream calls (dpe_bcs_update + dpe_bcm_update) bit for bit."""
+    import os
+    import subprocess
+    cfg = dpe.workload.CONFIG_R
+    fs, S, K, L, B = cfg["fs"], cfg["S"], cfg["K"], cfg["L"], cfg["B"]
+    W, nB, G = 8, 6, 10000
+    iq, cs, ce, bw = dpe.workload.build_windows(W * nB, fs, S, K, seed=21, amp=cfg["amp"])
+    _, _, pos, vel, _ = dpe.workload.build_grids(G)
+    (tmp_path / "meta.txt").write_text("%r %d %d %d %d %d %d %d %d\n" % (fs, S, K, W, nB, L, B, pos.shape[0], vel.shape[0]))
+    iq.tofile(tmp_path / "iq.bin")
+    np.ascontiguousarray(cs).tofile(tmp_path / "cs.bin")
+    np.ascontiguousarray(ce).tofile(tmp_path / "ce.bin")
+    np.ascontiguousarray(bw).tofile(tmp_path / "win.bin")
+    np.ascontiguousarray(pos, dtype=np.float64).tofile(tmp_path / "pos.bin")
+    np.ascontiguousarray(vel, dtype=np.float64).tofile(tmp_path / "vel.bin")
+    exe = os.path.join(os.path.dirname(dpe.engine.LIB_PATH), "test_pipe")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "6 batches x 8 windows, 0 results differ" in r.stdout
