@@ -388,7 +388,13 @@ constexpr double kChmH = 0.0009765625;
 // ---- cuEKF on the device: the 8 x 8 fp64 steps of dpe_ekf.hip with one lane per matrix element (a block of 64 threads).
 // Every element is formed by the same operations in the same order as the host form (sums over k = 0 .. 7 ascending, no fused
 // multiply-add), so the two give the same doubles.  sm: 6 x 64 doubles of LDS scratch.
-__device__ static inline void ekf_dev_mul(const double *a, const double *b, bool bT, double *c)
+#if defined(DPE_EXPERIMENTS) && defined(DPE_EKF_STAMPS)   // (timing attribution: shader-clock stamps of the phases of chm_k1, left in the fix record's two
+#define DPE_EKF_STAMP(i) do { if (threadIdx.x == 0) dpe_ekf_stamps[i] = __builtin_readcyclecounter(); } while (0)   // out-of-window counts)
+__shared__ unsigned long long dpe_ekf_stamps[10];
+#else
+#define DPE_EKF_STAMP(i) do { } while (0)
+#endif
+__device__ static inline double ekf_dev_mul(const double *a, const double *b, bool bT, double *c)
 {
 #pragma clang fp contract(off)
     const int l = threadIdx.x, i = l >> 3, j = l & 7;
@@ -397,19 +403,87 @@ __device__ static inline void ekf_dev_mul(const double *a, const double *b, bool
     __syncthreads();   // (c may alias a or b)
     c[l] = s;
     __syncthreads();
+    return s;          // (this lane's element: the caller need not read it back)
 }
 // inverse through LU with partial pivoting (getrf + getri, cuekf.cu:681-694); false: singular.
-// Round 6: the FACTORISATION runs on registers -- lane l = (r, kk) holds lu[r][kk]; the block is one wave, so a column's eight values
-// are eight v_readlane pairs (wave-uniform: the pivot search is the host form's, first largest |.| at or below the diagonal), the row
-// swap and the pivot row's element are one ds_bpermute round trip per column, and nothing waits at a barrier.  Through LDS it was five
-// dependent round trips and four barriers per column, ~4 of the ~5.5 us the filter adds to chm_k1.  Every element still sees the host
-// form's operations in the host form's order: lu[r][c] /= lu[c][c]; lu[r][k] -= lu[r][c] * lu[c][k] (no fused multiply-add).  The two
-// substitutions (one column of the inverse per lane, 28 dependent multiply-subtracts each) read the factors back from LDS as before.
+// Round 6: the FACTORISATION runs on registers -- lane l = (r, kk) holds lu[r][kk]; the block is one wave, so a column's values at or
+// below the diagonal are v_readlane pairs (wave-uniform: the pivot search is the host form's, first largest |.| at or below the
+// diagonal), the row swap and the pivot row's element are one ds_bpermute round trip per column, a lane's own row's element of the
+// column is a DPP row broadcast (rows c and p change places, so behind the swap row p holds the old diagonal element -- a uniform
+// value -- and every other row below the diagonal what it held before), and nothing waits at a barrier.  Through LDS it was five
+// dependent round trips and four barriers per column.  A lone wave is ISSUE-bound here (shader-clock stamps, scripts/ekf_stamps.py:
+// 954 clocks per column at ~150 instructions, most of them selects): the DPP form of the own-row element replaced a 38-instruction
+// select chain per column, and the pivot search became a scalar chain (below): chm_k1 with the filter 9.7-9.9 -> 8.8-9.0 us.  (Measured and
+// dropped: the divisions with the divisor's reciprocal refined once, off the chain -- three dependent operations per quotient instead
+// of thirteen, bit-identical under an exponent-range guard -- were SLOWER, 9.65-9.9 against 8.75-9.0 us on one box: the guards and
+// selects add instructions, and what this wave pays for is instructions, ~5 clocks each, not the latency of a chain.)  Every element still sees the host form's operations in the host form's order: lu[r][c] /= lu[c][c];
+// lu[r][k] -= lu[r][c] * lu[c][k] (no fused multiply-add).  The two substitutions (one column of the inverse per lane, 28 dependent
+// multiply-subtracts each) read the factors back from LDS as before.
 __device__ __forceinline__ double ekf_readlane_d(double v, int lane)
 {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// lane N of every 16-lane row to all lanes of the row (row_newbcast); lane l + 4 of the row to lane l (row_shl:4, zero beyond the row)
+template <int N>
+__device__ __forceinline__ double ekf_row_bcast_d(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + N, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + N, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double ekf_row_shl4_d(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x104, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x104, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// column C of the factorisation; false: the column is zero at and below the diagonal (singular)
+template <int C>
+__device__ __forceinline__ bool ekf_lu_column(double &x, int &pv, int l, int r, int kk)
+{
+#pragma clang fp contract(off)
+    // The pivot row: the first largest |.| at or below the diagonal, as the host form finds it.  The candidates are wave-uniform
+    // (v_readlane pairs), and |a| > |b| on finite doubles is the unsigned order of their magnitude bits: the search is a chain of scalar
+    // subtract-with-borrow / select steps -- five scalar instructions per candidate; as v_cmp_gt_f64 on scalar operands every step
+    // was a vector compare between two scalar selects, each waiting for the other pipe.  (NaN-free input: a NaN in S makes every
+    // later state NaN in either form.)
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    unsigned bLo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, C * 8 + C);
+    unsigned bHi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), C * 8 + C) & 0x7fffffffu;
+    int p = C;
+#pragma unroll
+    for (int q = C + 1; q < 8; ++q) {
+        const unsigned cLo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, q * 8 + C);
+        const unsigned cHi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), q * 8 + C) & 0x7fffffffu;
+        unsigned t;
+        asm("s_sub_u32 %3, %0, %4\n\ts_subb_u32 %3, %1, %5\n\ts_cselect_b32 %0, %4, %0\n\ts_cselect_b32 %1, %5, %1\n\ts_cselect_b32 %2, %6, %2"
+            : "+s"(bLo), "+s"(bHi), "+s"(p), "=&s"(t)
+            : "s"(cLo), "s"(cHi), "s"(q)
+            : "scc");
+    }
+    if ((bLo | bHi) == 0u) return false;
+    const double pivVal = ekf_readlane_d(x, p * 8 + C);
+    const double diagOld = ekf_readlane_d(x, C * 8 + C);   // (row p holds it behind the swap)
+    // this lane's own row's element of column C before the swap: lane (r, C) = lane C or 8 + C of the lane's 16-lane row
+    const double ownEven = ekf_row_bcast_d<C>(x), ownOdd = ekf_row_bcast_d<8 + C>(x);
+    const double own = (r & 1) ? ownOdd : ownEven;
+    // the row swap and the pivot row's element of this lane's column, both from the values before the swap: one round trip
+    const int src = (r == C) ? p * 8 + kk : (r == p) ? C * 8 + kk : l;
+    const double xs = __shfl(x, src, 64), xck = __shfl(x, p * 8 + kk, 64);
+    const int ps = (l == C) ? p : (l == p) ? C : l;
+    pv = __shfl(pv, ps, 64);
+    x = xs;
+    if (r > C) {
+        const double xc = (r == p) ? diagOld : own;   // this lane's row's element of column C after the swap
+        const double f = xc / pivVal;
+        if (kk == C) x = f;
+        else if (kk > C) x -= f * xck;
+    }
+    return true;
 }
 __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double *inv, int *piv)
 {
@@ -417,49 +491,23 @@ __device__ static inline bool ekf_dev_invert(const double *a, double *lu, double
     const int l = threadIdx.x, r = l >> 3, kk = l & 7;
     double x = a[l];
     int pv = l;                      // lanes 0 .. 7: piv[l]
-    bool singular = false;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        double col[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) col[q] = ekf_readlane_d(x, q * 8 + c);
-        int p = c;                   // (every lane finds the same pivot row: the first largest |.| at or below the diagonal)
-        double best = fabs(col[c]), pivVal = col[c];
-#pragma unroll
-        for (int q = c + 1; q < 8; ++q) {
-            const double av = fabs(col[q]);
-            if (av > best) { best = av; p = q; pivVal = col[q]; }
-        }
-        p = __builtin_amdgcn_readfirstlane(p);
-        if (best == 0.0) { singular = true; break; }
-        // the row swap and the pivot row's element of this lane's column, both from the values before the swap: one round trip
-        const int src = (r == c) ? p * 8 + kk : (r == p) ? c * 8 + kk : l;
-        const double xs = __shfl(x, src, 64), xck = __shfl(x, p * 8 + kk, 64);
-        const int ps = (l == c) ? p : (l == p) ? c : l;
-        pv = __shfl(pv, ps, 64);
-        x = xs;
-        // this lane's row's element of column c after the swap
-        double xc = col[0];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) xc = (r == q) ? col[q] : xc;
-        if (r == p) xc = col[c];
-        if (r == c) xc = pivVal;
-        if (r > c) {
-            const double f = xc / pivVal;
-            if (kk == c) x = f;
-            else if (kk > c) x -= f * xck;
-        }
-    }
+    const bool singular = !(ekf_lu_column<0>(x, pv, l, r, kk) && ekf_lu_column<1>(x, pv, l, r, kk) && ekf_lu_column<2>(x, pv, l, r, kk) &&
+                            ekf_lu_column<3>(x, pv, l, r, kk) && ekf_lu_column<4>(x, pv, l, r, kk) && ekf_lu_column<5>(x, pv, l, r, kk) &&
+                            ekf_lu_column<6>(x, pv, l, r, kk) && ekf_lu_column<7>(x, pv, l, r, kk));
     if (singular) return false;      // (wave-uniform)
+    DPE_EKF_STAMP(3);
     lu[l] = x;
-    if (l < 8) piv[l] = pv;
+    (void)piv;
+    int pvRow[8];                    // (wave-uniform: the row permutation, from lanes 0 .. 7)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pvRow[i] = __builtin_amdgcn_readlane(pv, i);
     __syncthreads();
     if (l < 8) {   // one column of the inverse per lane
         const int cl = l;
         double y[8], xx[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            double s = (piv[i] == cl) ? 1.0 : 0.0;
+            double s = (pvRow[i] == cl) ? 1.0 : 0.0;
 #pragma unroll
             for (int k = 0; k < i; ++k) s -= lu[i * 8 + k] * y[k];
             y[i] = s;
@@ -512,34 +560,35 @@ __device__ static inline bool ekf_dev_step(EkfDev *e, const EkfPre &pre, const d
 #pragma clang fp contract(off)
     const int l = threadIdx.x, i = l >> 3, j = l & 7;
     double *T = sm, *S = sm + 64, *Sinv = sm + 128, *lu = sm + 192, *y = sm + 256, *tmp = sm + 320;
-    double *P = sm + 512, *P1 = sm + 576, *xk = sm + 640, *x1 = sm + 648, *lpf = sm + 656, *lpfAvgS = sm + 676;
+    double *P = sm + 512, *P1 = sm + 576, *xk = sm + 640, *x1 = sm + 648;
     const bool coupled = pre.coupled != 0;
     const double Tc = pre.Tc;
     const double p = pre.p;
     P[l] = p;
-    if (l < 8) xk[l] = pre.xk;
-    if (l < 20) lpf[l] = pre.lpf;
-    int lpfIdx = pre.lpfIdx;
-    double lpfAvg = pre.lpfAvg;
+    const int lpfIdx = __builtin_amdgcn_readfirstlane(pre.lpfIdx);
+    const double lpfAvg0 = pre.lpfAvg;
     const double pz = 0.0 + p;                                     // H P = P H^T = 0.0 + P
     S[l] = (0.0 + pz) + ((l % 9 == 0) ? 1.0 : 0.0);                // S = (H P) H^T + R
     T[l] = pz;                                                     // P H^T, the first factor of K
+    if (l < 8) y[l] = z[l] - pre.xk;                               // y = z - H x_k|k-1
     __syncthreads();
-    if (l < 8) y[l] = z[l] - xk[l];                                // y = z - H x_k|k-1
+    DPE_EKF_STAMP(2);
 #if defined(DPE_EXPERIMENTS) && defined(DPE_EKF_SKIP_INV)   // (timing attribution only: wrong results)
     Sinv[l] = S[l];
     __syncthreads();
 #else
     if (!ekf_dev_invert(S, lu, Sinv, piv)) return false;
 #endif
-    ekf_dev_mul(T, Sinv, false, tmp);                              // K = (P H^T) S^-1
-    const double kv = tmp[l];
+    DPE_EKF_STAMP(4);
+    const double kv = ekf_dev_mul(T, Sinv, false, tmp);            // K = (P H^T) S^-1
     e->K[l] = kv;
+    double xs1 = 0.0;                                              // lanes 0 .. 7: x_k|k
     if (l < 8) {                                                   // x_k|k = x_k|k-1 + K y
-        double s = xk[l];
+        double s = pre.xk;
         for (int k = 0; k < 8; ++k) s += tmp[l * 8 + k] * y[k];
-        x1[l] = s;
+        x1[l] = s;                                                 // (left in the scratch for the caller: kEkfDevX1)
         e->xk1k1[l] = s;
+        xs1 = s;
     }
     {                                                              // P_k|k = (I - K H) P_k|k-1, K H = 0.0 + K
         double t = -(0.0 + kv);
@@ -548,21 +597,21 @@ __device__ static inline bool ekf_dev_step(EkfDev *e, const EkfPre &pre, const d
         T[l] = t;
     }
     __syncthreads();
-    ekf_dev_mul(T, P, false, P1);
-    const double p1 = P1[l];
+    DPE_EKF_STAMP(5);
+    const double p1 = ekf_dev_mul(T, P, false, P1);
+    DPE_EKF_STAMP(6);
     e->Pk1k1[l] = p1;
-    // ---- StepPredict with GetQVal (:733-742) and EKF_Update_Q (:42-78)
+    // ---- StepPredict with GetQVal (:733-742) and EKF_Update_Q (:42-78).  The block is one wave: the low-pass state is wave-uniform
+    // (every lane forms it from lanes 4 .. 6 of x_k|k and the ring entry of lane lpfIdx), so nothing is broadcast through LDS.
+    const double v4 = ekf_readlane_d(xs1, 4), v5 = ekf_readlane_d(xs1, 5), v6 = ekf_readlane_d(xs1, 6);
+    const double v = sqrt(v4 * v4 + v5 * v5 + v6 * v6);
+    const double av = lpfAvg0 - ekf_readlane_d(pre.lpf, lpfIdx) + (v / 20.0);
     if (l == 0) {
-        const double v = sqrt(x1[4] * x1[4] + x1[5] * x1[5] + x1[6] * x1[6]);
-        lpfAvg = lpfAvg - lpf[lpfIdx] + (v / 20.0);
         e->lpfVals[lpfIdx] = v / 20.0;
-        e->lpfAvg = lpfAvg;
-        lpfAvgS[0] = lpfAvg;
-        if (++lpfIdx >= 20) lpfIdx = 0;
-        e->lpfIdx = lpfIdx;
+        e->lpfAvg = av;
+        e->lpfIdx = lpfIdx + 1 >= 20 ? 0 : lpfIdx + 1;
     }
-    __syncthreads();
-    const double av = lpfAvgS[0];
+    DPE_EKF_STAMP(7);
     const double q = 1.0 + 250.0 / fmin(fmax(av * av, 50.0), 125.0);
     const auto q0 = [&](int r, int c) -> double {                  // Q0: diagonal
         if (r != c) return 0.0;
@@ -578,19 +627,21 @@ __device__ static inline bool ekf_dev_step(EkfDev *e, const EkfPre &pre, const d
     double qv = 0.0 + fq(i, j);                                    // Q = (F Q0) F^T
     if (coupled && j < 4) qv += fq(i, j + 4) * Tc;
     e->Q[l] = qv;
-    if (l < 8) {                                                   // x_k+1|k = F x_k|k
-        double s = 0.0 + x1[l];
-        if (coupled && l < 4) s += Tc * x1[l + 4];
-        xk[l] = s;                                                 // (left in the scratch for the caller: kEkfDevXk)
-        e->xkk1[l] = s;
+    {                                                              // x_k+1|k = F x_k|k
+        const double up = ekf_row_shl4_d(xs1);                     // lane l + 4's value (lanes 0 .. 3 read lanes 4 .. 7)
+        if (l < 8) {
+            double s = 0.0 + xs1;
+            if (coupled && l < 4) s += Tc * up;
+            xk[l] = s;                                             // (left in the scratch for the caller: kEkfDevXk)
+            e->xkk1[l] = s;
+        }
     }
     {                                                              // P_k+1|k = (F P) F^T + Q
         double t = 0.0 + p1;
         if (coupled && i < 4) t += Tc * P1[l + 32];
-        T[l] = t;
-        __syncthreads();
+        const double tr = ekf_row_shl4_d(t);                       // (F P)[i][j + 4]: four lanes on in the lane's own matrix row
         double s2 = 0.0 + t;
-        if (coupled && j < 4) s2 += T[l + 4] * Tc;
+        if (coupled && j < 4) s2 += tr * Tc;
         e->Pkk1[l] = s2 + qv;
     }
     __syncthreads();
@@ -608,6 +659,7 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
     const double rxTime = st->rxTime, T = st->T;
     const int ds = st->dopplerSign;
     if (k == 0) sFlags = 0;
+    DPE_EKF_STAMP(0);
     EkfPre ekfPre{};
     if (a.meas && a.ekf) ekfPre = ekf_dev_prefetch(a.ekf);
     Chan c;
@@ -643,6 +695,7 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
     }
     if (a.meas && a.ekf) {   // EnableEKF = true: StepUpdate + StepPredict on the measurement (block-uniform branch; all 64 lanes work)
         __syncthreads();
+        DPE_EKF_STAMP(1);
         const bool ok = sFlags == 0 && ekf_dev_step(a.ekf, ekfPre, sZ, sEkf, sPiv);
         __syncthreads();
         if (k < 8) {
@@ -650,6 +703,7 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
             else { sX1[k] = a.p.xkk1[k]; sXk[k] = a.p.xkk1[k]; }   // (no measurement, or S singular: hold the predicted state)
         }
         if (!ok && k == 0 && sFlags == 0) { atomicOr(&sFlags, 32); a.ekf->failed = 1; }
+        DPE_EKF_STAMP(8);
         __syncthreads();
     }
     if (k == 63) {
@@ -665,6 +719,15 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
             r->velIndex = (long long)(iv + a.velOff);
             r->posOutOfWindow = (long long)a.keys[2];
             r->velOutOfWindow = (long long)a.keys[3];
+#if defined(DPE_EXPERIMENTS) && defined(DPE_EKF_STAMPS)
+            {   // eight phase lengths in units of 4 shader clocks, 16 bits each
+                unsigned long long lo = 0ull, hi = 0ull;
+                for (int i = 0; i < 4; ++i) lo |= (((dpe_ekf_stamps[i + 1] - dpe_ekf_stamps[i]) >> 2) & 0xFFFFull) << (16 * i);
+                for (int i = 0; i < 4; ++i) hi |= (((dpe_ekf_stamps[i + 5] - dpe_ekf_stamps[i + 4]) >> 2) & 0xFFFFull) << (16 * i);
+                r->posOutOfWindow = (long long)lo;
+                r->velOutOfWindow = (long long)hi;
+            }
+#endif
             r->posScore = __uint_as_float((unsigned)(kp >> 32));
             r->velScore = __uint_as_float((unsigned)(kv >> 32));
             r->status = st->status | measBad | (sFlags & 32);
