@@ -73,7 +73,10 @@ def test_two_rank_bench_lines(exchange, port):
     assert d["headline"] is True and d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["exchange"] == exchange and d["config"]["windows_per_step"] == 4
     assert d["config"]["grid_points_per_manifold_global"] == 2 * 390625
-    assert d["roofline"]["kernel"] == "bcm_scan_kernel" and d["roofline"]["achieved"] > 0
+    # (the stanza names the kernel that took the most time in the side pass: with four windows per step and two ranks sharing the
+    # GPU the scan and the latency-bound small kernels are all ~10 us, so which one it is varies from run to run)
+    assert d["roofline"]["kernel"] in ("bcm_scan_kernel", "bcs_finalize_kernel", "bcs_bank16_kernel", "bcs_bank_kernel", "bcs_sum_kernel")
+    assert d["roofline"]["achieved"] > 0
     assert d["timing"]["timed_batches"] == 2 and len(d["timing"]["batch_ms_per_step"]) == 2
 
 
