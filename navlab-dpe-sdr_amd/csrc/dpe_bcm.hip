@@ -82,11 +82,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
     // first tile's grid points: issued before the bank fill so both latencies overlap
     float4 nxt[kPtsPerThread];
     {
-#ifdef DPE_BCM_CONTIG_TILES
-        const long long b0 = (long long)blockIdx.x * (((G + kPtsPerBlock - 1) / kPtsPerBlock + nBlkX - 1) / nBlkX) * kPtsPerBlock + tid;
-#else
         const long long b0 = (long long)blockIdx.x * kPtsPerBlock + tid;
-#endif
 #pragma unroll
         for (int it = 0; it < kPtsPerThread; ++it)
             nxt[it] = (b0 + it * 256 < G) ? grid[b0 + it * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -136,13 +132,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
     unsigned int nOob = 0;
     // "Method 1" weighted-mean estimator (optional: wsum != nullptr): sum s, sum s*{x,y,z,t}, pair-packed fp32
     f2 w0 = f2{0.f, 0.f}, w1 = w0, w2 = w0, w3 = w0, w4 = w0;
-#ifdef DPE_BCM_CONTIG_TILES
-    const long long tilesPerBlk = (nTiles + nBlkX - 1) / nBlkX, tileLo = (long long)blockIdx.x * tilesPerBlk;
-    const long long tileHi = tileLo + tilesPerBlk < nTiles ? tileLo + tilesPerBlk : nTiles;
-    for (long long tile = tileLo; tile < tileHi; ++tile) {
-#else
     for (long long tile = blockIdx.x; tile < nTiles; tile += nBlkX) {
-#endif
         const long long base = tile * kPtsPerBlock + tid;
         f2 dx[kPairs], dy[kPairs], dz[kPairs], dw[kPairs], q[kPairs], score[kPairs];
 #pragma unroll
@@ -153,11 +143,7 @@ __device__ __forceinline__ void scan_body(const ScanSide &sd, int inl, int K, in
             score[p] = f2{0.f, 0.f};
         }
         {   // prefetch the next tile of this block (whole lane in range: plain loads, no per-point predicate)
-#ifdef DPE_BCM_CONTIG_TILES
-            const long long b1 = tile + 1 < tileHi ? base + kPtsPerBlock : G;   // (the block's last tile prefetches nothing)
-#else
             const long long b1 = base + (long long)nBlkX * kPtsPerBlock;
-#endif
             if (b1 + (kPtsPerThread - 1) * 256 < G) {
 #pragma unroll
                 for (int it = 0; it < kPtsPerThread; ++it) nxt[it] = grid[b1 + it * 256];
