@@ -112,9 +112,8 @@ constexpr int kRideSpinDefault = 200000;
 #endif
 constexpr int kRideLoads = DPE_RIDE_LOADS;
    // loads in flight per lane of a sum block (24 or 32 push the kernel over its 170-register budget: scratch, 0.675 ms)
-constexpr int kRideLds = 12;     // rounds of a sum block that go straight into LDS (12 KB of the prefix array's 12.6)
 __device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, long long winStride, int S, int nW, int nSumBlk, int Lt, int sidx,
-                                               long long *__restrict__ sums, unsigned long long *__restrict__ rideWord, unsigned epoch, int4 *ldsBuf)
+                                               long long *__restrict__ sums, unsigned long long *__restrict__ rideWord, unsigned epoch)
 {
     const int w = sidx / nSumBlk, b = sidx - w * nSumBlk;
     if (w >= nW) return;
@@ -135,27 +134,9 @@ __device__ __forceinline__ void ride_sum_block(const int16_t *__restrict__ iq, l
     // kRideLoads loads in flight per lane, each under its own range check: the block is a short latency chain, and it holds a
     // correlator block's slot for that time
     int n0 = lo;
-#ifdef DPE_RIDE_LDSDMA   // experiment (round 4, measured and dropped): config H step 0.7135 against 0.700 ms without it
-    // whole chunks of (kRideLds + kRideLoads) x 64 int4: kRideLds rounds go straight into the block's LDS (global_load_lds_dwordx4: no
-    // registers -- the kernel's budget allows 16 register loads in flight, not 28), kRideLoads rounds into registers, all in flight
-    // together; the correlator blocks' prefix array is idle in a sum block.  Three memory round trips per sum block instead of five,
-    // but the LDS-direct writes land in an LDS array the correlator waves already keep 65 % busy: the launch got 0.013 ms slower
-    for (; n0 + (kRideLds + kRideLoads) * 64 <= hi; n0 += (kRideLds + kRideLoads) * 64) {
-#pragma unroll
-        for (int j = 0; j < kRideLds; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x4 + n0 + lane + 64 * j),
-                                             (__attribute__((address_space(3))) void *)(ldsBuf + 64 * j), 16, 0, 0);
-        int4 v[kRideLoads];
-#pragma unroll
-        for (int j = 0; j < kRideLoads; ++j) v[j] = x4[n0 + kRideLds * 64 + lane + 64 * j];
-#pragma unroll
-        for (int j = 0; j < kRideLoads; ++j) add4(v[j]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-direct loads have landed
-#pragma unroll
-        for (int j = 0; j < kRideLds; ++j) add4(ldsBuf[lane + 64 * j]);
-        __builtin_amdgcn_wave_barrier();   // (the next chunk's LDS-direct loads overwrite what this one read)
-    }
-#endif
+    // (round 4, measured and dropped: twelve of a chunk's rounds straight into the block's LDS with global_load_lds_dwordx4 -- three memory
+    // round trips per sum block instead of five, but the LDS-direct writes land in an array the correlator waves keep 65 % busy: config H
+    // step 0.7135 against 0.700 ms.)
     for (; n0 + kRideLoads * 64 <= hi; n0 += kRideLoads * 64) {   // whole rounds (wave-uniform bound)
         int4 v[kRideLoads];
 #pragma unroll
@@ -261,7 +242,7 @@ __global__ __launch_bounds__(64, DPE_C2_WAVES) void bcs_bank_chip2_kernel(BcsPar
             else bx = sg * bankPer + (o - rideSB);
         }
         if (sidx >= 0) {
-            ride_sum_block(iq, winStride, S, nW, nSumBlk, Lt, sidx, const_cast<long long *>(sums), rideWord, epoch, reinterpret_cast<int4 *>(sQ));
+            ride_sum_block(iq, winStride, S, nW, nSumBlk, Lt, sidx, const_cast<long long *>(sums), rideWord, epoch);
             return;
         }
     }
