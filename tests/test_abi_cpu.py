@@ -28,6 +28,19 @@ def test_header_symbols_exported(built):
     assert built.dpe_abi_version() == 4
 
 
+def test_integration_md_has_a_row_for_every_exported_symbol():
+    """INTEGRATION.md section 1b names, for every function include/dpe_hip.h declares, the reference interface it replaces (file:line)
+    or says why there is none -- one row per symbol, none missing, none stale."""
+    hdr = open(os.path.join(ROOT, "include", "dpe_hip.h")).read()
+    names = set(re.findall(r"\b(dpe_[a-z0-9_]+)\s*\(", hdr))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 1b."):]
+    sec = sec[:sec.index("\nError convention")]
+    rows = dict(re.findall(r"^\| `(dpe_[a-z0-9_]+)` \| (.+) \|$", sec, flags=re.M))
+    assert set(rows) == names, (sorted(names - set(rows)), sorted(set(rows) - names))
+    assert all(len(v) > 3 and v != "?" for v in rows.values())
+
+
 def test_ca_code_host(built, golden):
     assert np.array_equal(dpe.engine.gen_ca_code(), golden("o1_ca_chips")["chips"])
 
