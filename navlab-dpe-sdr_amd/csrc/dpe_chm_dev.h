@@ -117,7 +117,18 @@ DPE_HD static inline void rotate_state_cs(const double s[8], double ct, double s
 DPE_HD static inline void rotate_state(const double s[8], double tau, double o[8])
 {
     double ct, st;
-    sincos(-kOEDot * tau, &st, &ct);
+    const double x = -kOEDot * tau;
+#ifdef __HIP_DEVICE_COMPILE__
+    // The angle is the Earth's rotation over a signal's travel time, ~5e-6 rad: below 2^-10 the series to x^5 / x^6 are exact to the last
+    // bit (next terms x^7 / 5040 and x^8 / 40320 are < 2e-22 of sin x and < 3e-29), and the device library's sincos -- argument
+    // reduction and all, ~230 instructions of the lone wave of chm_k1, which pays ~5 clocks for each -- is not needed.
+    if (fabs(x) < 0x1p-10) {
+        const double x2 = x * x;
+        st = x * fma(x2, fma(x2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+        ct = fma(x2, fma(x2, fma(x2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    } else
+#endif
+        sincos(x, &st, &ct);
     rotate_state_cs(s, ct, st, o);
 }
 DPE_HD static inline void rotate_state_cs(const double s[8], double ct, double st, double o[8])
