@@ -91,6 +91,11 @@ def test_interleaved_batches_equal_the_one_stream_path(name, W, distinct):
         pipe.results(tickets[0][0])
     with pytest.raises(dpe.DpeError, match="never issued"):
         pipe.results(99)
+    # ... but the ring's "slot free again" may be asked about it (a ring deeper than the lanes): it is ordered behind the later batch of
+    # that lane; a ticket that was never issued is refused there too
+    pipe.samples_consumed(tickets[0][0], stream=st)
+    with pytest.raises(dpe.DpeError, match="never issued"):
+        pipe.samples_consumed(99, stream=st)
     pipe.close()
 
 
