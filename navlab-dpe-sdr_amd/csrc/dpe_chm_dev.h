@@ -689,14 +689,17 @@ __device__ static inline void chm_k1(const ChmKArgs &a)
             if (kp == 0ull || ip < 0 || ip >= a.posG) { measBad = 4; ip = 0; }
             if (kv == 0ull || iv < 0 || iv >= a.velG) { measBad = 4; iv = 0; }
             const double *g = a.posGrid + 4 * ip, *v = a.velGrid + 4 * iv, *R = a.p.enu2ecef, *cc = a.p.xkk1;
-            z[0] = R[0] * g[0] + R[1] * g[1] + R[2] * g[2] + cc[0];   // :1990-1999
-            z[1] = R[3] * g[0] + R[4] * g[1] + R[5] * g[2] + cc[1];
-            z[2] = R[6] * g[0] + R[7] * g[1] + R[8] * g[2] + cc[2];
-            z[3] = g[3] + cc[3];
-            z[4] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + cc[4];   // :2042-2051
-            z[5] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + cc[5];
-            z[6] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + cc[6];
-            z[7] = v[3] + cc[7];
+            {
+#pragma clang fp contract(off)   // (the host form's BCM_MakePosMeas / MakeVelMeas run without fused multiply-adds: the same doubles here)
+                z[0] = R[0] * g[0] + R[1] * g[1] + R[2] * g[2] + cc[0];   // :1990-1999
+                z[1] = R[3] * g[0] + R[4] * g[1] + R[5] * g[2] + cc[1];
+                z[2] = R[6] * g[0] + R[7] * g[1] + R[8] * g[2] + cc[2];
+                z[3] = g[3] + cc[3];
+                z[4] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2] + cc[4];   // :2042-2051
+                z[5] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2] + cc[5];
+                z[6] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + cc[6];
+                z[7] = v[3] + cc[7];
+            }
             if (measBad) {   // no valid score this window: hold the state (and say so)
                 for (int i = 0; i < 8; ++i) z[i] = cc[i];
                 atomicOr(&sFlags, measBad);

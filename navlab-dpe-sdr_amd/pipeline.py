@@ -16,11 +16,12 @@ def bank_half_widths(pos_grid, vel_grid, fs, nfft):
 
 
 def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), init_delta=(0, 0, 0, 0), K=None,
-                    lpower=1, enable_ekf=False, reference_pair=False, keep_scores=False):
+                    lpower=1, enable_ekf=False, reference_pair=False, keep_scores=False, couple_velocity=True):
     """iq_windows: int16 [W, 2S] (host).  Returns fixes [W, 8] (= xCurrk1k1 per window) and the raw
     per-window result dicts.  One window per Update, fix fed back to the channel manager.
     enable_ekf: route the fix through cuEKF's real filter (EnableEKF=true) instead of the shipped pass-through.
-    reference_pair: dpe_bcm_config.referencePair; keep_scores: every result dict also carries the window's position scores."""
+    reference_pair: dpe_bcm_config.referencePair; keep_scores: every result dict also carries the window's position scores;
+    couple_velocity: the filter's F couples position and velocity over one window (cuekf.cu:111-143) or is the identity (ekf.py:47)."""
     import torch
     iq_windows = np.ascontiguousarray(iq_windows)
     W, S2 = iq_windows.shape
@@ -38,7 +39,7 @@ def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
     x[:4] += np.asarray(init_delta, dtype=np.float64)
     iq_d = torch.from_numpy(iq_windows).to("cuda:0")
     fixes, results = np.zeros((W, 8)), []
-    ekf = engine.cuEKF(x, SampleLength=S / fs, EnableEKF=enable_ekf)
+    ekf = engine.cuEKF(x, SampleLength=S / fs, EnableEKF=enable_ekf, couple_velocity=couple_velocity)
     xk1k1, xkk1 = x, x
     for w in range(W):
         (cm.Start if w == 0 else cm.Update)(xk1k1, xkk1, time_grid)
@@ -60,14 +61,15 @@ def run_closed_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
 
 
 def run_device_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), init_delta=(0, 0, 0, 0), K=None, lpower=1,
-                    ring_depth=64, stream=None, reference_pair=False, keep_scores=False):
+                    ring_depth=64, stream=None, reference_pair=False, keep_scores=False, enable_ekf=False, couple_velocity=True):
     """The same loop with nothing read back per window: the channel manager lives on the device (engine.ChanMgrDev), forms
     the measurement from the scan's keys, passes it through and writes the next window's parameter blocks; the host enqueues
         BatchCorrScores.UpdatePrepared -> BatchCorrManifold.UpdatePrepared -> ChanMgrDev.step
     for every window and collects the fixes from the pinned ring afterwards (at most ring_depth - 1 windows ahead).
     reference_pair: dpe_bcm_config.referencePair (the prepared form re-evaluates from the attached manager's port arrays);
     keep_scores (tests): waits for every window and keeps its position scores, its code banks and the channel manager's outputs the
-    window was scored with (`inputs` = ChanMgrDev.outputs() before the window) -- the loop then does read back."""
+    window was scored with (`inputs` = ChanMgrDev.outputs() before the window) -- the loop then does read back.
+    enable_ekf: cuEKF's filter inside the measurement kernel (dpe_chm_dev_set_ekf) instead of the pass-through; the fixes are then x_k|k."""
     import torch
     iq_windows = np.ascontiguousarray(iq_windows)
     W, S2 = iq_windows.shape
@@ -85,6 +87,8 @@ def run_device_loop(iq_windows, ho, fs, pos_grid, vel_grid, time_grid=(0.0,), in
     x = np.array(ho["X_ECEF"], dtype=np.float64).copy()
     x[:4] += np.asarray(init_delta, dtype=np.float64)
     iq_d = torch.from_numpy(iq_windows).to("cuda:0")
+    if enable_ekf:
+        cm.set_ekf(S / fs, x, couple_velocity=couple_velocity)
     cm.Start(x, stream)
     fixes, results, got = np.zeros((W, 8)), [], 0
     for w in range(W):

@@ -275,3 +275,45 @@ def test_reference_pair_mode_in_the_device_resident_loop(oracle):
         changed += int(np.sum(np.abs(got - rp[w]["posScores"]) > 1e-3 * sp.max()))
     assert branch > 0, "the case must exercise the branch"
     assert changed > 0       # ... and without the mode those points carry the continuous interpolation's value
+
+
+@pytest.mark.parametrize("couple", [True, False])
+def test_device_filter_equals_the_host_filter_with_and_without_velocity_coupling(couple):
+    """EnableEKF = true with F = I + T on [i][i + 4] (EKF_MakeDPERandomWalkFMatrix, cuekf.cu:111-143) and with F = I (ekf.py:47).  The
+    filter inside the measurement kernel (one lane per matrix element, the structure of F and H exploited, LU on registers with a scalar
+    pivot search) is the host filter (dpe_ekf_*, pinned by fixture O10) operation for operation: fed with the measurements the DEVICE loop
+    formed (its zVal port, read back window by window), the host filter reproduces the device's x_k|k BIT FOR BIT over the whole run.
+    (The two closed loops as wholes agree to ~1e-15 only: the ENU matrix in the measurement comes from either manager's own sin / cos.)"""
+    import torch
+    W, fs, S, K = 60, 2.5e6, 50000, 8
+    iq, _, _, _ = dpe.workload.build_windows(W, fs, S, K, seed=5, amp=200.0, velocity=np.array([4.0, -2.0, 1.0]))
+    ho = dpe.handoff.read_handoff(dpe.workload.HANDOFF_CSV)
+    pos = dpe.synth.uniform_grid(9, 1.0)
+    vel = dpe.synth.rand_grid(4, 6561, half=(6.0, 6.0, 6.0, 3.0))
+    nfft = dpe.engine.carr_fft_len(S)
+    L, B = dpe.pipeline.bank_half_widths(pos, vel, fs, nfft)
+    bcs = dpe.engine.BatchCorrScores(fs, samples_per_window=S, lag_half_width=L, bin_half_width=B, max_channels=K)
+    bcs.Start()
+    bcm = dpe.engine.BatchCorrManifold(fs, S, bcs.NumFFTPoints, pos, vel, LPower=1, lag_half_width=L, bin_half_width=B, max_channels=K)
+    bcm.Start()
+    cm = dpe.engine.ChanMgrDev.from_handoff(ho, S / fs, K, (0.0,))
+    cm.attach(bcs, bcm, 64)
+    x = np.array(ho["X_ECEF"], dtype=np.float64).copy()
+    cm.set_ekf(S / fs, x, couple_velocity=couple)
+    z_dev = cm.ports()[5]
+    iq_d = torch.from_numpy(np.ascontiguousarray(iq)).to("cuda:0")
+    cm.Start(x, None)
+    host = dpe.engine.cuEKF(x, SampleLength=S / fs, EnableEKF=True, couple_velocity=couple)
+    worst = 0.0
+    for w in range(W):
+        bcs.UpdatePrepared(iq_d[w], K, None)
+        bcm.UpdatePrepared(bcs.CodeScores, bcs.CarrScores, K, None)
+        cm.step(None)
+        r = cm.fix(w)
+        assert r["status"] == 0
+        z = dpe.engine.d2h(z_dev, 64, np.float64)          # the measurement this window's filter step consumed
+        host.Update(z, np.eye(8))
+        assert np.array_equal(host.xCurrk1k1, r["zVal"]), (w, np.abs(host.xCurrk1k1 - r["zVal"]).max())
+        worst = max(worst, np.abs(r["zVal"][:3] - x[:3]).max())
+    assert worst < 50.0
+    host.Stop(); cm.Stop(); bcm.Stop(); bcs.Stop()
