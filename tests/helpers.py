@@ -228,5 +228,10 @@ def assert_parity(gpu, ref, tol=2e-5, check_scores=True, pos_ref_noise=None):
             R = ref["R"][w].reshape(3, 3)
             c = ref["centre"][w]
             zm = np.concatenate([R @ zp[:3] + c[:3], [zp[3] + c[3]], R @ zv[:3] + c[4:7], [zv[3] + c[7]]])
-            assert np.abs(gr["zValMean"][:4] - zm[:4]).max() < 1e-3 and np.abs(gr["zValMean"][4:] - zm[4:]).max() < 1e-4
+            # Truncated banks (pairs outside the window): up to two points per window may keep / drop a whole SV contribution at a bank
+            # edge against the fp64 oracle (set aside in the score check above); each moves the weighted mean by at most its share of the
+            # score sum times the grid's extent.  (Found by the sweep at DPE_FUZZ_SEED=777, case 250: L = 1, 2 204 points.)
+            ep = 2 * ref["pos_x"][w].max() / ref["pos_x"][w].sum() * 2 * np.abs(ref["pos_grid"]).max() if rr["posOutOfWindowX"] > 0 else 0.0
+            ev = 2 * ref["vel"][w].max() / ref["vel"][w].sum() * 2 * np.abs(ref["vel_grid"]).max() if rr["velOutOfWindow"] > 0 else 0.0
+            assert np.abs(gr["zValMean"][:4] - zm[:4]).max() < 1e-3 + ep and np.abs(gr["zValMean"][4:] - zm[4:]).max() < 1e-4 + ev
     return worst
