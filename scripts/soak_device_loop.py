@@ -15,3 +15,11 @@ bad = sum(1 for w in range(W) if res_d[w]["posIndex"] != res_h[w]["posIndex"] or
 print("device-loop soak: %d windows, status %d, %d windows with a different grid point, max |fix difference| %.3g m (host-driven %.1f s, device loop %.1f s in Python)"
       % (W, status, bad, np.abs(fixes_d - fixes_h).max(), t1 - t0, t2 - t1))
 assert status == 0 and bad == 0
+# ... and with cuEKF's filter inside the measurement kernel: the two closed loops agree to the managers' own sin / cos (~1e-15 relative); the
+# filter's arithmetic itself is compared bit for bit in tests/test_gpu_chm_dev.py
+for couple in (True, False):
+    fh, _ = dpe.pipeline.run_closed_loop(iq, ho, fs, pos, vel, time_grid=tg, K=K, enable_ekf=True, couple_velocity=couple)
+    fd, _, st = dpe.pipeline.run_device_loop(iq, ho, fs, pos, vel, time_grid=tg, K=K, ring_depth=8, enable_ekf=True, couple_velocity=couple)
+    rel = np.abs(fd - fh).max(0) / np.maximum(np.abs(fh).max(0), 1.0)
+    print("device-loop soak with the filter (velocity coupling %s): %d windows, status %d, max relative state difference %.3g" % (couple, W, st, rel.max()))
+    assert st == 0 and rel.max() < 1e-12
